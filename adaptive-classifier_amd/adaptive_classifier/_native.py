@@ -1,0 +1,133 @@
+"""ctypes binding of libacamd.so (the C ABI declared in include/acamd.h).
+
+The library is the product: there is NO CPU or eager-PyTorch fallback behind these wrappers.
+If the shared object is missing or a call fails, an exception is raised.
+PyTorch is used only for device memory (tensor.data_ptr()) and streams.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libacamd.so")
+_CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+_lib = None
+
+c_void_p, c_int, c_int64, c_size_t, c_float, c_uint64 = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float, ctypes.c_uint64)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into libacamd.so (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", _CSRC])
+    return _LIB_PATH
+
+
+class ac_head_dims(ctypes.Structure):
+    _fields_ = [("D", c_int), ("H1", c_int), ("H2", c_int), ("C", c_int)]
+
+
+class ac_bert_config(ctypes.Structure):
+    _fields_ = [("hidden", c_int), ("layers", c_int), ("heads", c_int), ("intermediate", c_int),
+                ("vocab", c_int), ("max_pos", c_int), ("type_vocab", c_int), ("ln_eps", c_float)]
+
+
+class ac_bert_weights(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b",
+        "qkv_w", "qkv_b", "ao_w", "ao_b", "ln1_g", "ln1_b",
+        "ff1_w", "ff1_b", "ff2_w", "ff2_b", "ln2_g", "ln2_b")]
+
+
+# name -> (restype, argtypes); must list every symbol include/acamd.h declares
+_SIGNATURES = {
+    "ac_last_error": (ctypes.c_char_p, []),
+    "ac_version": (c_int, []),
+    "ac_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_size_t)]),
+    "ac_knn_l2_topk_workspace": (c_int, [c_int64, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "ac_knn_l2_topk": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64,
+                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "ac_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ac_proto_scores": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ac_synth_unit_rows": (c_int, [c_void_p, c_int64, c_int64, c_int, c_uint64, c_int64, c_void_p]),
+    "ac_linear_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                              c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "ac_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_int64,
+                            c_float, c_void_p, c_int64, c_void_p]),
+    "ac_head_param_count": (c_int64, [ctypes.POINTER(ac_head_dims)]),
+    "ac_head_workspace": (c_int, [ctypes.POINTER(ac_head_dims), c_int, ctypes.POINTER(c_size_t)]),
+    "ac_head_forward": (c_int, [ctypes.POINTER(ac_head_dims), c_void_p, c_void_p, c_int64, c_int, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
+    "ac_head_fwd_bwd_ce": (c_int, [ctypes.POINTER(ac_head_dims), c_void_p, c_void_p, c_int64, c_void_p,
+                                   c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
+    "ac_fisher_accumulate": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
+    "ac_ewc_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    "ac_ewc_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
+                                  c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p,
+                                  c_void_p, c_void_p]),
+    "ac_bert_workspace": (c_int, [ctypes.POINTER(ac_bert_config), c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "ac_bert_encode_cls": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p,
+                                   c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
+                                   c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libacamd.so once.  Raises NativeError if it is absent -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise NativeError(
+                f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(make -C {_CSRC}). There is no CPU fallback for the MI355X hot path.")
+        L = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            if not hasattr(L, name) and os.environ.get("AC_DEV_PARTIAL") == "1":
+                continue                # development only: library still being brought up
+            fn = getattr(L, name)       # AttributeError => header/library mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ac_last_error()
+        raise NativeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise NativeError("no MI355X visible to PyTorch (torch.cuda.is_available() is False); "
+                          "the hot path has no CPU fallback")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor as a void*; None -> NULL."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def device_info():
+    cu, lds, hbm = c_int(0), c_int(0), c_size_t(0)
+    check(lib().ac_device_info(ctypes.byref(cu), ctypes.byref(lds), ctypes.byref(hbm)), "ac_device_info")
+    return {"cus": cu.value, "lds_per_block": lds.value, "hbm_bytes": hbm.value}

@@ -1,0 +1,179 @@
+"""HipFlatL2Index: the `faiss.IndexFlatL2` protocol used by memory.py, on MI355X HBM.
+
+Protocol kept (reference call sites in /root/reference/src/adaptive_classifier/memory.py):
+  IndexFlatL2(d) :34,164,182,242 | .add(x[n,d]) :159,172,190 | .search(x[nq,d], k) :114 |
+  .remove_ids(ids) :158 (compacting) | .ntotal :106,113
+
+Rows live in one resident, row-major fp32 device matrix with a 16-byte aligned, zero padded
+leading dimension (growth by doubling, so `add` is amortised O(1) like faiss's vector).
+search() is one call into the C ABI (`ac_knn_l2_topk`): exact squared L2, ascending, ties to
+the lower id.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native as nv
+
+
+def knn_workspace_bytes(N, D, nq, k):
+    b = ctypes.c_size_t(0)
+    nv.check(nv.lib().ac_knn_l2_topk_workspace(N, D, nq, k, ctypes.byref(b)), "ac_knn_l2_topk_workspace")
+    return b.value
+
+
+def knn_l2_topk(P, N, D, Q, k, row_offset=0, out=None, workspace=None, stats=None):
+    """Low-level device call.  P: [>=N, ldP] fp32 cuda tensor, Q: [nq, >=D] fp32 cuda tensor.
+
+    Returns (dist fp32 [nq,k], ids int64 [nq,k]) on the same device.  Asynchronous.
+    """
+    nv.require_gpu()
+    assert P.dtype == torch.float32 and Q.dtype == torch.float32 and P.is_cuda and Q.is_cuda
+    assert P.stride(1) == 1 and Q.stride(1) == 1
+    nq = Q.shape[0]
+    dev = Q.device
+    if out is None:
+        outD = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        outI = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    else:
+        outD, outI = out
+    need = knn_workspace_bytes(N, D, nq, k)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = nv.lib().ac_knn_l2_topk(
+            nv.ptr(P), N, P.stride(0), D, nv.ptr(Q), nq, Q.stride(0), k, row_offset,
+            nv.ptr(outD), nv.ptr(outI), nv.ptr(workspace), workspace.numel(),
+            nv.ptr(stats), nv.stream_ptr(dev))
+    nv.check(rc, "ac_knn_l2_topk")
+    return outD, outI
+
+
+class HipFlatL2Index:
+    """Drop-in for faiss.IndexFlatL2 as used by PrototypeMemory."""
+
+    def __init__(self, d, device=None):
+        nv.require_gpu()
+        self.d = int(d)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.ld = (self.d + 3) // 4 * 4
+        self._n = 0
+        self._store = torch.zeros((0, self.ld), dtype=torch.float32, device=self.device)
+        self._ws = None
+        self._stats = torch.zeros(4, dtype=torch.int32, device=self.device)
+
+    # -- faiss protocol ------------------------------------------------------------------
+    @property
+    def ntotal(self):
+        return self._n
+
+    def _as_rows(self, x):
+        if isinstance(x, torch.Tensor):
+            t = x.detach().to(dtype=torch.float32)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        t = t.reshape(-1, self.d)
+        return t
+
+    def _reserve(self, n):
+        if n <= self._store.shape[0]:
+            return
+        cap = max(n, 2 * self._store.shape[0], 64)
+        new = torch.zeros((cap, self.ld), dtype=torch.float32, device=self.device)
+        if self._n:
+            new[: self._n] = self._store[: self._n]
+        self._store = new
+
+    def add(self, x):
+        rows = self._as_rows(x)
+        m = rows.shape[0]
+        if m == 0:
+            return
+        self._reserve(self._n + m)
+        self._store[self._n: self._n + m, : self.d] = rows.to(self.device, non_blocking=True)
+        self._n += m
+
+    def add_device_rows(self, rows):
+        """Adopt an existing [n, ld] device matrix without copying (large synthetic stores)."""
+        assert rows.is_cuda and rows.dtype == torch.float32 and rows.stride(1) == 1
+        assert rows.stride(0) % 4 == 0 and rows.stride(0) >= self.ld and rows.data_ptr() % 16 == 0
+        self._store = rows
+        self._n = rows.shape[0]
+
+    def remove_ids(self, ids):
+        if isinstance(ids, torch.Tensor):
+            ids = ids.detach().cpu().numpy()
+        ids = np.unique(np.asarray(ids).reshape(-1).astype(np.int64))
+        ids = ids[(ids >= 0) & (ids < self._n)]
+        if ids.size == 0:
+            return 0
+        keep = torch.ones(self._n, dtype=torch.bool, device=self.device)
+        keep[torch.from_numpy(ids).to(self.device)] = False
+        kept = self._store[: self._n][keep]             # IndexFlat compacts: later rows shift down
+        self._store[: kept.shape[0]] = kept
+        self._n = kept.shape[0]
+        return int(ids.size)
+
+    def reset(self):
+        self._n = 0
+
+    def search_device(self, q, k):
+        """q: [nq, d] fp32 tensor (any device) -> (dist, ids) CUDA tensors; no host sync."""
+        q = q.detach().to(device=self.device, dtype=torch.float32)
+        if q.dim() == 1:
+            q = q.unsqueeze(0)
+        q = q.contiguous()
+        need = knn_workspace_bytes(self._n, self.d, q.shape[0], k)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+        return knn_l2_topk(self._store, self._n, self.d, q, k, workspace=self._ws, stats=self._stats)
+
+    def search(self, x, k):
+        """faiss signature: numpy in, (float32 [nq,k], int64 [nq,k]) numpy out."""
+        q = self._as_rows(x)
+        D, I = self.search_device(q, int(k))
+        return D.cpu().numpy(), I.cpu().numpy()
+
+    @property
+    def exact_fallbacks(self):
+        """Queries of the last search() that needed the exact fp64 fallback sweep."""
+        return int(self._stats[0].item())
+
+
+def topk_merge(D_in, I_in):
+    """[shards, nq, k] per-shard ascending lists -> global (dist, ids) [nq, k] (ac_topk_merge)."""
+    nv.require_gpu()
+    S, nq, k = D_in.shape
+    D_in = D_in.contiguous()
+    I_in = I_in.contiguous()
+    outD = torch.empty((nq, k), dtype=torch.float32, device=D_in.device)
+    outI = torch.empty((nq, k), dtype=torch.int64, device=D_in.device)
+    with torch.cuda.device(D_in.device):
+        nv.check(nv.lib().ac_topk_merge(nv.ptr(D_in), nv.ptr(I_in), S, nq, k, nv.ptr(outD), nv.ptr(outI),
+                                        nv.stream_ptr(D_in.device)), "ac_topk_merge")
+    return outD, outI
+
+
+def proto_scores(D, I):
+    """memory.py:117,129-130 on device: softmax(exp(-d)) over each query's valid hits."""
+    nv.require_gpu()
+    D = D.contiguous()
+    I = I.contiguous()
+    out = torch.empty_like(D)
+    with torch.cuda.device(D.device):
+        nv.check(nv.lib().ac_proto_scores(nv.ptr(D), nv.ptr(I), D.shape[0], D.shape[1], nv.ptr(out),
+                                          nv.stream_ptr(D.device)), "ac_proto_scores")
+    return out
+
+
+def synth_unit_rows(n, D, seed, row_offset=0, device=None, ld=None):
+    """Deterministic unit-norm rows generated on the device (bit-identical to oracle/synth.py)."""
+    nv.require_gpu()
+    device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    ld = ld or (D + 3) // 4 * 4
+    out = torch.empty((n, ld), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        nv.check(nv.lib().ac_synth_unit_rows(nv.ptr(out), n, ld, D, seed, row_offset, nv.stream_ptr(device)),
+                 "ac_synth_unit_rows")
+    return out

@@ -1,0 +1,855 @@
+// kNN site of the hot path: exact squared-L2 top-k over the prototype store.
+// Replaces faiss.IndexFlatL2.search as called at
+//   /root/reference/src/adaptive_classifier/memory.py:113-114
+// (third-party faiss-cpu>=1.7.4, requirements.txt:4 -- not vendored).
+//
+// Three kernels, all on one stream, no host synchronisation:
+//
+//  1. knn_sweep<TQ>   the HBM sweep.  Every prototype row is read from HBM exactly once per
+//                     query tile of TQ queries.  The query tile lives in LDS, pre-scaled by -2
+//                     and pre-arranged in MFMA B-fragment order; prototype rows stream
+//                     HBM -> VGPR (float4 per lane, no LDS round trip: nothing is shared between
+//                     waves) and go straight into v_mfma_f32_32x32x2_f32 / _16x16x4_f32 as the
+//                     A operand.  acc[row][query] = |p|^2 - 2 q.p  (|p|^2 is folded in by one
+//                     extra MFMA whose A operand is the lane's running sum of squares).
+//                     Each lane owns ONE query column, so the running threshold tau_q is one
+//                     register; a candidate is pushed to the block's per-query LDS list only if
+//                     acc < tau_q (rare after warm-up).  Lists are pruned to the k' = k+pad best
+//                     by a wave-level rank-by-counting pass, which also tightens tau_q.
+//  2. knn_merge_rerank  per query: radix-select the k' best of the G per-block lists, recompute
+//                     those k' distances exactly (fp64 sum of (p-q)^2), order by (exact, id),
+//                     emit top-k, and certify with an fp32 error bound that no unseen row can
+//                     beat the k-th (see acamd.h "exactness contract").
+//  3. knn_exact_fallback  only for queries whose certificate failed: a plain fp64 sweep.
+//
+// Roofline: algorithmic bytes per sweep = N*D*4; MFMA time at TQ=32 is
+// 16 B/clk/CU (> the 10.3 B/clk/CU HBM feed), so the sweep is HBM-bound for nq <= 32.
+#include "common.h"
+
+#include <float.h>
+#include <math.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWaves = 8;               // waves per sweep block (2 per SIMD)
+constexpr int kThreads = kWaves * 64;
+constexpr int kGroup = 8;               // float4 loads in flight per lane per buffer
+constexpr int kPad = 8;                 // extra candidates kept beyond k
+constexpr int kMergeMaxCand = 16384;    // G * k' limit (merge kernel keeps them in LDS)
+constexpr int kLdsLimit = 160 * 1024;
+
+template <int TQ> struct Shape;
+template <> struct Shape<32> {
+    static constexpr int ROWS = 32, KSPLIT = 2, NACC = 16, KCOLS = 8;
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    static __device__ __forceinline__ int acc_row(int r, int lane) {
+        return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+};
+template <> struct Shape<16> {
+    static constexpr int ROWS = 16, KSPLIT = 4, NACC = 4, KCOLS = 16;
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // C/D layout: col = lane & 15, row = 4 * (lane >> 4) + r
+    static __device__ __forceinline__ int acc_row(int r, int lane) {
+        return 4 * (lane >> 4) + r;
+    }
+};
+
+struct SweepParams {
+    const float* P;
+    int64_t N;
+    int64_t ldP;
+    const float* Q;
+    int64_t ldQ;
+    int D;        // logical dim
+    int Dp;       // round_up(D, 4): float4 loads at col < Dp are in bounds (zero padded)
+    int ng;       // k-groups per tile: ceil(Dp / (KCOLS * kGroup))
+    int nq;
+    int kp;       // candidates kept per block and per query (k + pad)
+    int cap;      // list capacity, power of two, >= 2 * kp
+    int G;        // row groups (blocks per query tile)
+    int nqt;      // query tiles
+    int64_t ntiles;   // ceil(N / (kWaves * ROWS))
+    float* part_d;    // [nqt*TQ][G][kp]
+    int32_t* part_i;  // [nqt*TQ][G][kp]
+    float* part_maxnorm;  // [G * nqt]
+    const float* zeros;   // >= 16 B of zeros, 16-byte aligned (tail-group loads)
+};
+
+// monotone map float -> uint32 (ascending float order == ascending unsigned order)
+__device__ __forceinline__ uint32_t fkey(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+// XCD-aware block id remap (cdna guide T1, bijective form): hardware places block b on XCD
+// b % 8; give each XCD a contiguous range of virtual ids so that the nqt query-tile blocks
+// of one row group (consecutive virtual ids) share one L2.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    const int x = b & 7, s = b >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + s;
+}
+
+// Wave-level prune of one candidate list: keep the kp smallest by (d, id), written back in
+// ascending order; update cnt and tau.  n <= cap <= 512.
+template <int MAXPER>
+__device__ __forceinline__ void prune_list(float* ld, int32_t* li, int* cnt_p, float* tau_p,
+                                           int cap, int kp, int lane) {
+    int n = *cnt_p;
+    if (n > cap) n = cap;
+    float myd[MAXPER];
+    int32_t myi[MAXPER];
+    int rank[MAXPER];
+#pragma unroll
+    for (int e = 0; e < MAXPER; ++e) {
+        const int s = lane + 64 * e;
+        const bool v = s < n;
+        myd[e] = v ? ld[s] : INFINITY;
+        myi[e] = v ? li[s] : 0x7fffffff;
+        rank[e] = 0;
+    }
+    for (int s = 0; s < n; ++s) {
+        const float d = ld[s];        // wave-uniform address: LDS broadcast
+        const int32_t i = li[s];
+#pragma unroll
+        for (int e = 0; e < MAXPER; ++e)
+            rank[e] += (d < myd[e] || (d == myd[e] && i < myi[e])) ? 1 : 0;
+    }
+    // all reads above are complete for the whole wave before any lane writes (lockstep)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+    for (int e = 0; e < MAXPER; ++e) {
+        const int s = lane + 64 * e;
+        if (s < n && rank[e] < kp) {
+            ld[rank[e]] = myd[e];
+            li[rank[e]] = myi[e];
+            if (rank[e] == kp - 1) *tau_p = myd[e];
+        }
+    }
+    if (lane == 0) *cnt_p = n < kp ? n : kp;
+}
+
+__device__ __forceinline__ void prune_dispatch(float* ld, int32_t* li, int* cnt_p, float* tau_p,
+                                               int cap, int kp, int lane) {
+    if (cap <= 64) prune_list<1>(ld, li, cnt_p, tau_p, cap, kp, lane);
+    else if (cap <= 128) prune_list<2>(ld, li, cnt_p, tau_p, cap, kp, lane);
+    else if (cap <= 256) prune_list<4>(ld, li, cnt_p, tau_p, cap, kp, lane);
+    else prune_list<8>(ld, li, cnt_p, tau_p, cap, kp, lane);
+}
+
+template <int TQ>
+__global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
+    typedef Shape<TQ> S;
+    typedef typename S::acc_t acc_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nblk = prm.G * prm.nqt;
+    const int v = xcd_remap(blockIdx.x, nblk);
+    const int qt = v % prm.nqt;
+    const int g = v / prm.nqt;
+
+    // ---- LDS carve-up (all offsets multiples of 16) ----
+    const int nslots = prm.ng * kGroup * 64;          // float4 slots of the query tile
+    f32x4* Qs = reinterpret_cast<f32x4*>(smem);
+    float* list_d = reinterpret_cast<float*>(smem + (size_t)nslots * 16);
+    int32_t* list_i = reinterpret_cast<int32_t*>(list_d + (size_t)TQ * prm.cap);
+    int* cnt = reinterpret_cast<int*>(list_i + (size_t)TQ * prm.cap);
+    float* tau_s = reinterpret_cast<float*>(cnt + TQ);
+    float* wmax_s = tau_s + TQ;                       // [kWaves]
+
+    // ---- stage the query tile: slot (kb, ksub, j) = -2 * Q[qt*TQ + j][KCOLS*kb + 4*ksub ..+3] ----
+    {
+        const int c4_per_q = prm.ng * kGroup * S::KSPLIT;   // float4 columns per query (padded)
+        const int total = TQ * c4_per_q;
+        for (int t = tid; t < total; t += kThreads) {
+            const int j = t / c4_per_q;
+            const int c4 = t - j * c4_per_q;
+            const int kb = c4 / S::KSPLIT, ksub = c4 - kb * S::KSPLIT;
+            const int qrow = qt * TQ + j;
+            const int col = 4 * c4;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (qrow < prm.nq && col < prm.D) {
+                const float* src = prm.Q + (size_t)qrow * prm.ldQ + col;
+                val.x = -2.f * src[0];
+                if (col + 1 < prm.D) val.y = -2.f * src[1];
+                if (col + 2 < prm.D) val.z = -2.f * src[2];
+                if (col + 3 < prm.D) val.w = -2.f * src[3];
+            }
+            Qs[kb * 64 + ksub * TQ + j] = val;
+        }
+        for (int t = tid; t < TQ; t += kThreads) {
+            cnt[t] = 0;
+            tau_s[t] = (qt * TQ + t < prm.nq) ? INFINITY : -INFINITY;
+        }
+    }
+    __syncthreads();
+
+    const int j = lane % TQ;            // query column this lane owns in the C/D layout
+    const int ksub = lane / S::ROWS;    // k sub-slice this lane feeds in the A/B layout
+    const int arow = lane % S::ROWS;    // tile row this lane feeds in the A layout
+    float tau = tau_s[j];
+    float wave_maxnorm = 0.f;
+
+    // tiles of this block: T = it * G + g
+    const int64_t my_tiles = (prm.ntiles > g) ? (prm.ntiles - 1 - g) / prm.G + 1 : 0;
+    const int ng = prm.ng;
+    const int64_t total = my_tiles * ng;
+
+    f32x4 buf[2][kGroup];
+    // prefetch state (flattened group counter -> tile, group)
+    int64_t pf_tile = 0;
+    int pf_grp = 0;
+    const float* pf_ptr;
+    auto tile_rowptr = [&](int64_t it) -> const float* {
+        int64_t row = (it * prm.G + g) * (int64_t)(kWaves * S::ROWS) + wave * S::ROWS + arow;
+        if (row > prm.N - 1) row = prm.N - 1;
+        return prm.P + (size_t)row * prm.ldP;
+    };
+    pf_ptr = tile_rowptr(0);
+
+#define AC_PREFETCH(B)                                                                   \
+    do {                                                                                 \
+        const int kb0 = pf_grp * kGroup;                                                 \
+        if ((kb0 + kGroup) * S::KCOLS <= prm.Dp) { /* wave-uniform: whole group in bounds */ \
+            _Pragma("unroll") for (int u = 0; u < kGroup; ++u)                           \
+                buf[B][u] = *reinterpret_cast<const f32x4*>(pf_ptr + 4 * ksub + (kb0 + u) * S::KCOLS); \
+        } else { /* tail group: out-of-range float4s are fetched from a zero block instead */ \
+            _Pragma("unroll") for (int u = 0; u < kGroup; ++u) {                         \
+                const int col = (kb0 + u) * S::KCOLS + 4 * ksub;                         \
+                const float* src = col < prm.Dp ? pf_ptr + col : prm.zeros;              \
+                buf[B][u] = *reinterpret_cast<const f32x4*>(src);                        \
+            }                                                                            \
+        }                                                                                \
+        if (++pf_grp == ng) { pf_grp = 0; ++pf_tile; pf_ptr = tile_rowptr(pf_tile); }    \
+    } while (0)
+
+    acc_t acc;
+    float nsq = 0.f;
+    int64_t cur_tile = 0;
+    int cur_grp = 0;
+
+    auto epilogue = [&]() {
+        // fold |p|^2 in: A = this lane's partial sum of squares, B = 1
+        acc = S::mfma(nsq, 1.0f, acc);
+        // row norm for the error-bound certificate
+        float rn = nsq;
+#pragma unroll
+        for (int o = S::ROWS; o < 64; o <<= 1) rn += __shfl_xor(rn, o);
+        wave_maxnorm = fmaxf(wave_maxnorm, rn);
+
+        const int64_t row_base = (cur_tile * prm.G + g) * (int64_t)(kWaves * S::ROWS) + wave * S::ROWS;
+        bool maybe = false;
+#pragma unroll
+        for (int r = 0; r < S::NACC; ++r) maybe |= (acc[r] < tau);
+        unsigned done = 0;
+        bool pend = __any(maybe) != 0;
+        for (;;) {
+            bool lane_pend = false;
+            if (pend) {
+#pragma unroll
+                for (int r = 0; r < S::NACC; ++r) {
+                    const int64_t row = row_base + S::acc_row(r, lane);
+                    const float d = acc[r];
+                    if (!((done >> r) & 1u) && d < tau && row < prm.N) {
+                        const int slot = atomicAdd(&cnt[j], 1);
+                        if (slot < prm.cap) {
+                            list_d[j * prm.cap + slot] = d;
+                            list_i[j * prm.cap + slot] = (int32_t)row;
+                            done |= 1u << r;
+                        } else {
+                            lane_pend = true;
+                        }
+                    }
+                }
+            }
+            // one barrier per tile: decide (uniformly) whether lists must be pruned
+            int over = 0;
+            if (tid < TQ) over = cnt[tid] > (prm.cap - prm.cap / 4);
+            const int need = __syncthreads_or((int)lane_pend | over);
+            if (!need) break;
+            for (int q = wave; q < TQ; q += kWaves) {
+                if (cnt[q] > prm.kp)
+                    prune_dispatch(list_d + q * prm.cap, list_i + q * prm.cap, &cnt[q], &tau_s[q],
+                                   prm.cap, prm.kp, lane);
+            }
+            __syncthreads();
+            tau = tau_s[j];
+            pend = true;   // re-test un-pushed entries against the tightened tau
+        }
+        nsq = 0.f;
+    };
+
+#define AC_COMPUTE(B)                                                                    \
+    do {                                                                                 \
+        if (cur_grp == 0) {                                                              \
+            _Pragma("unroll") for (int r = 0; r < S::NACC; ++r) acc[r] = 0.f;            \
+        }                                                                                \
+        const f32x4* qsrc = Qs + (size_t)cur_grp * kGroup * 64 + lane;                   \
+        f32x4 bq = qsrc[0];                                                              \
+        _Pragma("unroll") for (int u = 0; u < kGroup; ++u) {                             \
+            const f32x4 a = buf[B][u];                                                   \
+            const f32x4 b = bq;                                                          \
+            if (u + 1 < kGroup) bq = qsrc[(u + 1) * 64]; /* LDS read one step ahead */   \
+            acc = S::mfma(a.x, b.x, acc);                                                \
+            nsq = fmaf(a.x, a.x, nsq); nsq = fmaf(a.y, a.y, nsq);                        \
+            acc = S::mfma(a.y, b.y, acc);                                                \
+            nsq = fmaf(a.z, a.z, nsq); nsq = fmaf(a.w, a.w, nsq);                        \
+            acc = S::mfma(a.z, b.z, acc);                                                \
+            acc = S::mfma(a.w, b.w, acc);                                                \
+            __builtin_amdgcn_sched_barrier(0); /* keep the per-load consume order */     \
+        }                                                                                \
+        if (++cur_grp == ng) { epilogue(); cur_grp = 0; ++cur_tile; }                    \
+    } while (0)
+
+    // Loads are issued unconditionally (past the end they re-read the last row, clamped in
+    // tile_rowptr) so that every path has the same number of loads in flight: a load inside a
+    // branch makes hipcc's s_waitcnt accounting wait on the buffer it has just issued.
+    if (total > 0) {
+        AC_PREFETCH(0);
+        for (int64_t gg = 0; gg < total; gg += 2) {
+            AC_PREFETCH(1);
+            AC_COMPUTE(0);
+            AC_PREFETCH(0);
+            if (gg + 1 < total) AC_COMPUTE(1);
+        }
+    }
+#undef AC_PREFETCH
+#undef AC_COMPUTE
+
+    // ---- final: sort + cut every list to kp, write the block's partial result ----
+    __syncthreads();
+    for (int q = wave; q < TQ; q += kWaves) {
+        prune_dispatch(list_d + q * prm.cap, list_i + q * prm.cap, &cnt[q], &tau_s[q], prm.cap,
+                       prm.kp, lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int n = cnt[q];
+        const size_t base = ((size_t)(qt * TQ + q) * prm.G + g) * prm.kp;
+        for (int e = lane; e < prm.kp; e += 64) {
+            prm.part_d[base + e] = e < n ? list_d[q * prm.cap + e] : INFINITY;
+            prm.part_i[base + e] = e < n ? list_i[q * prm.cap + e] : -1;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) wave_maxnorm = fmaxf(wave_maxnorm, __shfl_xor(wave_maxnorm, o));
+    if (lane == 0) wmax_s[wave] = wave_maxnorm;
+    __syncthreads();
+    if (tid == 0) {
+        float m = 0.f;
+        for (int w = 0; w < kWaves; ++w) m = fmaxf(m, wmax_s[w]);
+        prm.part_maxnorm[v] = m;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// merge + exact re-rank + certificate.  One block (256 threads) per query.
+// --------------------------------------------------------------------------------------
+struct MergeParams {
+    const float* P;
+    int64_t N;
+    int64_t ldP;
+    const float* Q;
+    int64_t ldQ;
+    int D;
+    int Dp;
+    int k;
+    int kp;
+    int G;
+    int nblk;       // entries of part_maxnorm
+    int nterms;     // max roundings any term of the sweep's fp32 sum passes through
+    int64_t row_offset;
+    const float* part_d;
+    const int32_t* part_i;
+    const float* part_maxnorm;
+    float* outD;
+    int64_t* outI;
+    int32_t* flags;   // [nq] 1 = certificate failed -> exact fallback
+    int32_t* stats;   // optional
+};
+
+constexpr int kMergeThreads = 256;
+
+__global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n = prm.G * prm.kp;
+    const int kp = prm.kp;
+
+    // LDS: keys[n] u64 | qrow[Dp] f32 | sel_key[kp] u64 | exact[kp] f64 | misc
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    size_t off = ac::align_up((size_t)n * 8, 16);
+    float* qrow = reinterpret_cast<float*>(smem + off);
+    off += ac::align_up((size_t)prm.Dp * 4, 16);
+    unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem + off);
+    off += (size_t)kp * 8;
+    double* exact = reinterpret_cast<double*>(smem + off);
+    off += (size_t)kp * 8;
+    int* misc = reinterpret_cast<int*>(smem + off);   // [0] count, [1] nsel, [2] nreal
+    double* dmisc = reinterpret_cast<double*>(misc + 4);  // [0] qnorm2, [1] exact k-th
+
+    // composite key = fkey(d) << 32 | (uint32) id ; padding (id < 0) sorts last
+    const float* pd = prm.part_d + (size_t)q * n;
+    const int32_t* pi = prm.part_i + (size_t)q * n;
+    int nreal_local = 0;
+    for (int t = tid; t < n; t += kMergeThreads) {
+        const int32_t id = pi[t];
+        unsigned long long key = ~0ull;
+        if (id >= 0) {
+            key = ((unsigned long long)fkey(pd[t]) << 32) | (uint32_t)id;
+            ++nreal_local;
+        }
+        keys[t] = key;
+    }
+    for (int c = tid; c < prm.Dp; c += kMergeThreads)
+        qrow[c] = c < prm.D ? prm.Q[(size_t)q * prm.ldQ + c] : 0.f;
+    if (tid < 4) misc[tid] = 0;
+    __syncthreads();
+    atomicAdd(&misc[2], nreal_local);
+    __syncthreads();
+    const int nreal = misc[2];
+    const int nsel = nreal < kp ? nreal : kp;     // how many candidates we re-rank
+
+    // ---- MSB-first binary radix select of the nsel-th smallest composite key ----
+    unsigned long long prefix = 0, T64 = ~0ull;
+    if (nsel > 0) {
+        int want = nsel;   // rank (1-based) still to locate inside the current prefix class
+        for (int bit = 63; bit >= 0; --bit) {
+            const unsigned long long himask = (bit == 63) ? 0ull : (~0ull << (bit + 1));
+            int c0 = 0;
+            for (int t = tid; t < n; t += kMergeThreads) {
+                const unsigned long long key = keys[t];
+                c0 += ((key & himask) == prefix && !((key >> bit) & 1ull)) ? 1 : 0;
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) c0 += __shfl_xor(c0, o);
+            if (lane == 0 && c0) atomicAdd(&misc[0], c0);
+            __syncthreads();
+            const int tot0 = misc[0];
+            __syncthreads();
+            if (tid == 0) misc[0] = 0;
+            if (tot0 >= want) {
+                // the wanted key has this bit = 0
+            } else {
+                want -= tot0;
+                prefix |= (1ull << bit);
+            }
+            __syncthreads();
+        }
+        T64 = prefix;
+    }
+    // ---- compact the selected candidates (key <= T64) ----
+    for (int t = tid; t < n; t += kMergeThreads) {
+        const unsigned long long key = keys[t];
+        if (nsel > 0 && key <= T64 && key != ~0ull) {
+            const int s = atomicAdd(&misc[1], 1);
+            if (s < kp) sel[s] = key;
+        }
+    }
+    __syncthreads();
+    const int ns = misc[1] < kp ? misc[1] : kp;    // == nsel (composite keys of real rows are unique)
+
+    // ---- exact fp64 distances of the selected rows; |q|^2 ----
+    const int nc4 = prm.Dp >> 2;
+    for (int s = wave; s < ns; s += kMergeThreads / 64) {
+        const int32_t id = (int32_t)(uint32_t)(sel[s] & 0xffffffffull);
+        const f32x4* prow = reinterpret_cast<const f32x4*>(prm.P + (size_t)id * prm.ldP);
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int c4 = lane; c4 < nc4; c4 += 64) {
+            const f32x4 p = prow[c4];
+            const f32x4 qq = *reinterpret_cast<const f32x4*>(qrow + 4 * c4);
+            const double e0 = (double)p.x - (double)qq.x, e1 = (double)p.y - (double)qq.y;
+            const double e2 = (double)p.z - (double)qq.z, e3 = (double)p.w - (double)qq.w;
+            a0 = fma(e0, e0, a0); a1 = fma(e1, e1, a1); a2 = fma(e2, e2, a2); a3 = fma(e3, e3, a3);
+        }
+        double a = (a0 + a1) + (a2 + a3);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o);
+        if (lane == 0) exact[s] = a;
+    }
+    if (wave == 0) {
+        double a = 0;
+        for (int c = lane; c < prm.Dp; c += 64) a = fma((double)qrow[c], (double)qrow[c], a);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o);
+        if (lane == 0) { dmisc[0] = a; dmisc[1] = INFINITY; }
+    }
+    __syncthreads();
+
+    // ---- final order by (exact, id); emit top-k ----
+    const int kout = prm.k;
+    for (int t = tid; t < ns; t += kMergeThreads) {
+        const double dt = exact[t];
+        const uint32_t it = (uint32_t)(sel[t] & 0xffffffffull);
+        int rank = 0;
+        for (int s = 0; s < ns; ++s) {
+            const double ds = exact[s];
+            const uint32_t is = (uint32_t)(sel[s] & 0xffffffffull);
+            rank += (ds < dt || (ds == dt && is < it)) ? 1 : 0;
+        }
+        if (rank < kout) {
+            prm.outD[(size_t)q * kout + rank] = (float)dt;
+            prm.outI[(size_t)q * kout + rank] = (int64_t)it + prm.row_offset;
+        }
+        if (rank == kout - 1) dmisc[1] = dt;
+    }
+    for (int t = ns + tid; t < kout; t += kMergeThreads) {   // k > N: faiss-style padding
+        prm.outD[(size_t)q * kout + t] = FLT_MAX;
+        prm.outI[(size_t)q * kout + t] = -1;
+    }
+    __syncthreads();
+
+    // ---- certificate ----
+    if (tid == 0) {
+        int ok = 1;
+        if (prm.N > (int64_t)kp) {
+            float mx = 0.f;
+            for (int b = 0; b < prm.nblk; ++b) mx = fmaxf(mx, prm.part_maxnorm[b]);
+            const double qn2 = dmisc[0];
+            const double pn = sqrt((double)mx * 1.001), qn = sqrt(qn2);
+            // fp32 fma-chain roundoff of |p|^2 - 2 q.p: every term passes through at most
+            // nterms roundings, so |err| <= gamma_n * (|p|^2 + 2 sum|q_i p_i|) <= gamma_n (|p|+|q|)^2
+            const double gamma = 1.01 * (double)prm.nterms * 5.9604644775390625e-08;  // n * 2^-24
+            const double E = gamma * (pn + qn) * (pn + qn) + 1e-30;
+            const double a_last = (double)fkey_inv((uint32_t)(T64 >> 32));
+            // every row that was NOT re-ranked has sweep value >= a_last, hence exact
+            // distance >= a_last - E + |q|^2.  The k-th re-ranked must beat that strictly.
+            const double kth = dmisc[1];
+            ok = (ns >= kout) && (kth < a_last - E + qn2);
+        }
+        prm.flags[q] = ok ? 0 : 1;
+        if (!ok && prm.stats) atomicAdd(&prm.stats[0], 1);
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// exact fallback: fp64 sweep for the (rare) queries whose certificate failed.
+// One block per query; exits immediately unless flagged.
+// --------------------------------------------------------------------------------------
+constexpr int kFbThreads = 512;
+constexpr int kFbWaves = kFbThreads / 64;
+constexpr int kFbCap = 1024;          // list capacity (k <= 248 -> prune keeps k)
+constexpr int kFbRound = 32;          // rows per wave between barriers
+
+__global__ __launch_bounds__(kFbThreads) void knn_exact_fallback(MergeParams prm) {
+    const int q = blockIdx.x;
+    if (!prm.flags[q]) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* ld = reinterpret_cast<double*>(smem);                  // [kFbCap]
+    int32_t* li = reinterpret_cast<int32_t*>(ld + kFbCap);         // [kFbCap]
+    float* qrow = reinterpret_cast<float*>(li + kFbCap);           // [Dp]
+    int* misc = reinterpret_cast<int*>(qrow + ac::align_up((size_t)prm.Dp, 4));  // [0] cnt
+    double* tau_d = reinterpret_cast<double*>(misc + 4);
+    int32_t* tau_i = reinterpret_cast<int32_t*>(tau_d + 1);
+
+    for (int c = tid; c < prm.Dp; c += kFbThreads)
+        qrow[c] = c < prm.D ? prm.Q[(size_t)q * prm.ldQ + c] : 0.f;
+    if (tid == 0) { misc[0] = 0; *tau_d = INFINITY; *tau_i = 0x7fffffff; }
+    __syncthreads();
+    const int nc4 = prm.Dp >> 2;
+    const int k = prm.k;
+
+    auto prune = [&]() {
+        // block-wide rank-by-counting over cnt <= kFbCap entries (2 per thread)
+        const int n = misc[0] < kFbCap ? misc[0] : kFbCap;
+        double myd[2]; int32_t myi[2]; int rank[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int s = tid + kFbThreads * e;
+            myd[e] = s < n ? ld[s] : INFINITY;
+            myi[e] = s < n ? li[s] : 0x7fffffff;
+            rank[e] = 0;
+        }
+        for (int s = 0; s < n; ++s) {
+            const double d = ld[s]; const int32_t i = li[s];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) rank[e] += (d < myd[e] || (d == myd[e] && i < myi[e])) ? 1 : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int s = tid + kFbThreads * e;
+            if (s < n && rank[e] < k) {
+                ld[rank[e]] = myd[e]; li[rank[e]] = myi[e];
+                if (rank[e] == k - 1) { *tau_d = myd[e]; *tau_i = myi[e]; }
+            }
+        }
+        if (tid == 0) misc[0] = n < k ? n : k;
+        __syncthreads();
+    };
+
+    for (int64_t base = 0; base < prm.N; base += (int64_t)kFbWaves * kFbRound) {
+        const double td = *tau_d; const int32_t ti = *tau_i;
+        for (int m = 0; m < kFbRound; ++m) {
+            const int64_t row = base + (int64_t)m * kFbWaves + wave;
+            if (row >= prm.N) break;
+            const f32x4* prow = reinterpret_cast<const f32x4*>(prm.P + (size_t)row * prm.ldP);
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int c4 = lane; c4 < nc4; c4 += 64) {
+                const f32x4 p = prow[c4];
+                const f32x4 qq = *reinterpret_cast<const f32x4*>(qrow + 4 * c4);
+                const double e0 = (double)p.x - (double)qq.x, e1 = (double)p.y - (double)qq.y;
+                const double e2 = (double)p.z - (double)qq.z, e3 = (double)p.w - (double)qq.w;
+                a0 = fma(e0, e0, a0); a1 = fma(e1, e1, a1); a2 = fma(e2, e2, a2); a3 = fma(e3, e3, a3);
+            }
+            double a = (a0 + a1) + (a2 + a3);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o);
+            if (lane == 0 && (a < td || (a == td && (int32_t)row < ti))) {
+                const int s = atomicAdd(&misc[0], 1);
+                if (s < kFbCap) { ld[s] = a; li[s] = (int32_t)row; }
+            }
+        }
+        __syncthreads();
+        const int c_now = misc[0];      // read between two barriers: identical for every thread
+        __syncthreads();
+        if (c_now > kFbCap - kFbWaves * kFbRound) prune();
+    }
+    prune();
+    const int n = misc[0];
+    for (int t = tid; t < k; t += kFbThreads) {
+        prm.outD[(size_t)q * k + t] = t < n ? (float)ld[t] : FLT_MAX;
+        prm.outI[(size_t)q * k + t] = t < n ? (int64_t)li[t] + prm.row_offset : -1;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// shard merge and prototype scores
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* Din, const int64_t* Iin,
+                                                         int shards, int nq, int k, float* outD,
+                                                         int64_t* outI) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = shards * k;
+    int64_t* ids = reinterpret_cast<int64_t*>(smem);
+    float* ds = reinterpret_cast<float*>(ids + n);
+    for (int t = tid; t < n; t += 256) {
+        const int s = t / k, e = t - s * k;
+        ids[t] = Iin[((size_t)s * nq + q) * k + e];
+        ds[t] = Din[((size_t)s * nq + q) * k + e];
+    }
+    for (int t = tid; t < k; t += 256) { outD[(size_t)q * k + t] = FLT_MAX; outI[(size_t)q * k + t] = -1; }
+    __syncthreads();
+    for (int t = tid; t < n; t += 256) {
+        const int64_t it = ids[t];
+        if (it < 0) continue;
+        const float dt = ds[t];
+        int rank = 0;
+        for (int s = 0; s < n; ++s) {
+            const int64_t is = ids[s];
+            if (is < 0) continue;
+            const float d = ds[s];
+            rank += (d < dt || (d == dt && (is < it || (is == it && s < t)))) ? 1 : 0;
+        }
+        if (rank < k) { outD[(size_t)q * k + rank] = dt; outI[(size_t)q * k + rank] = it; }
+    }
+}
+
+// memory.py:117 (exp(-d)) and :129-130 (softmax over the hits), one wave per query
+__global__ __launch_bounds__(64) void proto_scores_kernel(const float* D, const int64_t* I, int nq,
+                                                          int k, float* out) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    float mx = -INFINITY;
+    for (int e = lane; e < k; e += 64)
+        if (I[(size_t)q * k + e] >= 0) mx = fmaxf(mx, expf(-D[(size_t)q * k + e]));
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int e = lane; e < k; e += 64)
+        if (I[(size_t)q * k + e] >= 0) sum += expf(expf(-D[(size_t)q * k + e]) - mx);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+    for (int e = lane; e < k; e += 64) {
+        const bool v = I[(size_t)q * k + e] >= 0;
+        out[(size_t)q * k + e] = v ? expf(expf(-D[(size_t)q * k + e]) - mx) / sum : 0.f;
+    }
+}
+
+// ---- host-side planning ----
+struct Plan {
+    int TQ, kp, cap, ng, Dp, G, nqt;
+    int64_t ntiles;
+    size_t sweep_lds, merge_lds, fb_lds;
+    size_t off_part_d, off_part_i, off_maxnorm, off_flags, off_zeros, total;
+};
+
+static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
+    AC_REQUIRE(N >= 0 && N < 2147483647LL, AC_EINVAL, "knn: N=%lld out of range", (long long)N);
+    AC_REQUIRE(D >= 1 && nq >= 0, AC_EINVAL, "knn: bad D=%d nq=%d", D, nq);
+    AC_REQUIRE(k >= 1 && k <= AC_KNN_MAX_K, AC_EUNSUPPORTED,
+               "knn: k=%d outside the fused sweep's range [1,%d]", k, AC_KNN_MAX_K);
+    pl->kp = k + kPad;
+    pl->cap = next_pow2(2 * pl->kp);
+    if (pl->cap < 64) pl->cap = 64;
+    pl->Dp = (D + 3) / 4 * 4;
+    int TQ = nq > 16 ? 32 : 16;
+    for (;;) {
+        const int kcols = TQ == 32 ? 8 : 16;
+        pl->ng = (pl->Dp + kcols * kGroup - 1) / (kcols * kGroup);
+        pl->sweep_lds = (size_t)pl->ng * kGroup * 64 * 16 + (size_t)TQ * pl->cap * 8 + TQ * 8 + kWaves * 4 + 64;
+        if (pl->sweep_lds <= (size_t)kLdsLimit) break;
+        AC_REQUIRE(TQ == 32, AC_EUNSUPPORTED,
+                   "knn: D=%d with k=%d needs %zu B of LDS (> %d); unsupported", D, k, pl->sweep_lds, kLdsLimit);
+        TQ = 16;
+    }
+    pl->TQ = TQ;
+    pl->nqt = nq > 0 ? (nq + TQ - 1) / TQ : 1;
+    const int rows_per_tile = kWaves * TQ;
+    pl->ntiles = (N + rows_per_tile - 1) / rows_per_tile;
+    const ac::DevInfo& di = ac::dev_info();
+    int per_cu = (int)(kLdsLimit / pl->sweep_lds);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    int64_t G = ((int64_t)di.cus * per_cu) / pl->nqt;
+    if (G < 1) G = 1;
+    if (G > pl->ntiles) G = pl->ntiles;
+    if (G > kMergeMaxCand / pl->kp) G = kMergeMaxCand / pl->kp;
+    if (G < 1) G = 1;
+    pl->G = (int)G;
+    const size_t nqpad = (size_t)pl->nqt * TQ;
+    const size_t ncand = nqpad * pl->G * pl->kp;
+    size_t off = 0;
+    pl->off_part_d = off; off += ac::align_up(ncand * 4, 256);
+    pl->off_part_i = off; off += ac::align_up(ncand * 4, 256);
+    pl->off_maxnorm = off; off += ac::align_up((size_t)pl->G * pl->nqt * 4, 256);
+    pl->off_flags = off; off += ac::align_up((size_t)(nq > 0 ? nq : 1) * 4, 256);
+    pl->off_zeros = off; off += 256;
+    pl->total = off;
+    pl->merge_lds = ac::align_up((size_t)pl->G * pl->kp * 8, 16) + ac::align_up((size_t)pl->Dp * 4, 16) +
+                    (size_t)pl->kp * 16 + 64;
+    pl->fb_lds = (size_t)kFbCap * 12 + ac::align_up((size_t)pl->Dp, 4) * 4 + 64;
+    return AC_OK;
+}
+
+}  // namespace
+
+extern "C" int ac_knn_l2_topk_workspace(int64_t N, int D, int nq, int k, size_t* bytes) {
+    AC_REQUIRE(bytes != nullptr, AC_EINVAL, "knn workspace: bytes is NULL");
+    Plan pl;
+    int rc = make_plan(N, D, nq, k, &pl);
+    if (rc != AC_OK) return rc;
+    *bytes = pl.total;
+    return AC_OK;
+}
+
+extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, const float* d_Q,
+                              int nq, int64_t ldQ, int k, int64_t row_offset, float* d_outD,
+                              int64_t* d_outI, void* d_ws, size_t ws_bytes, int32_t* d_stats,
+                              ac_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    Plan pl;
+    int rc = make_plan(N, D, nq, k, &pl);
+    if (rc != AC_OK) return rc;
+    if (nq == 0) return AC_OK;
+    AC_REQUIRE(d_Q && d_outD && d_outI, AC_EINVAL, "knn: null pointer");
+    AC_REQUIRE(ldQ >= D, AC_EINVAL, "knn: ldQ=%lld < D=%d", (long long)ldQ, D);
+    AC_REQUIRE(ws_bytes >= pl.total && (d_ws || pl.total == 0), AC_EWORKSPACE,
+               "knn: workspace %zu < required %zu", ws_bytes, pl.total);
+    if (N > 0) {
+        AC_REQUIRE(d_P != nullptr, AC_EINVAL, "knn: d_P is NULL");
+        AC_REQUIRE(ldP >= pl.Dp && (ldP % 4) == 0, AC_EINVAL,
+                   "knn: ldP=%lld must be a multiple of 4 and >= round_up(D,4)=%d", (long long)ldP, pl.Dp);
+        AC_REQUIRE((((uintptr_t)d_P) & 15) == 0, AC_EINVAL, "knn: d_P must be 16-byte aligned");
+    }
+    char* ws = (char*)d_ws;
+    if (d_stats) AC_HIP_CHECK(hipMemsetAsync(d_stats, 0, 4 * sizeof(int32_t), stream));
+
+    MergeParams mp;
+    mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = pl.Dp;
+    mp.k = k; mp.kp = pl.kp; mp.G = pl.G; mp.nblk = pl.G * pl.nqt;
+    mp.nterms = pl.ng * kGroup * (pl.TQ == 32 ? 8 : 16) + 16;
+    mp.row_offset = row_offset;
+    mp.part_d = (const float*)(ws + pl.off_part_d);
+    mp.part_i = (const int32_t*)(ws + pl.off_part_i);
+    mp.part_maxnorm = (const float*)(ws + pl.off_maxnorm);
+    mp.outD = d_outD; mp.outI = d_outI;
+    mp.flags = (int32_t*)(ws + pl.off_flags);
+    mp.stats = d_stats;
+
+    if (N == 0) {
+        // empty shard: everything is padding; reuse the merge kernel with all-padding partials
+        AC_HIP_CHECK(hipMemsetAsync(ws + pl.off_part_i, 0xff, (size_t)pl.nqt * pl.TQ * pl.G * pl.kp * 4, stream));
+        AC_HIP_CHECK(hipMemsetAsync(ws + pl.off_maxnorm, 0, (size_t)pl.G * pl.nqt * 4, stream));
+    } else {
+        SweepParams sp;
+        sp.P = d_P; sp.N = N; sp.ldP = ldP; sp.Q = d_Q; sp.ldQ = ldQ; sp.D = D; sp.Dp = pl.Dp;
+        sp.ng = pl.ng; sp.nq = nq; sp.kp = pl.kp; sp.cap = pl.cap; sp.G = pl.G; sp.nqt = pl.nqt;
+        sp.ntiles = pl.ntiles;
+        sp.part_d = (float*)(ws + pl.off_part_d);
+        sp.part_i = (int32_t*)(ws + pl.off_part_i);
+        sp.part_maxnorm = (float*)(ws + pl.off_maxnorm);
+        sp.zeros = (const float*)(ws + pl.off_zeros);
+        AC_HIP_CHECK(hipMemsetAsync(ws + pl.off_zeros, 0, 256, stream));
+        const int nblk = pl.G * pl.nqt;
+        if (pl.TQ == 32) {
+            (void)hipFuncSetAttribute((const void*)knn_sweep<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)pl.sweep_lds);
+            hipLaunchKernelGGL(knn_sweep<32>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
+        } else {
+            (void)hipFuncSetAttribute((const void*)knn_sweep<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)pl.sweep_lds);
+            hipLaunchKernelGGL(knn_sweep<16>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
+        }
+        AC_LAUNCH_CHECK();
+    }
+    (void)hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)pl.merge_lds);
+    hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), pl.merge_lds, stream, mp);
+    AC_LAUNCH_CHECK();
+    if (N > 0) {
+        (void)hipFuncSetAttribute((const void*)knn_exact_fallback, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)pl.fb_lds);
+        hipLaunchKernelGGL(knn_exact_fallback, dim3(nq), dim3(kFbThreads), pl.fb_lds, stream, mp);
+        AC_LAUNCH_CHECK();
+    }
+    return AC_OK;
+}
+
+extern "C" int ac_topk_merge(const float* d_D_in, const int64_t* d_I_in, int shards, int nq, int k,
+                             float* d_outD, int64_t* d_outI, ac_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_REQUIRE(shards >= 1 && nq >= 0 && k >= 1, AC_EINVAL, "topk_merge: bad shape");
+    AC_REQUIRE(d_D_in && d_I_in && d_outD && d_outI, AC_EINVAL, "topk_merge: null pointer");
+    if (nq == 0) return AC_OK;
+    const size_t lds = (size_t)shards * k * 12;
+    AC_REQUIRE(lds <= 96 * 1024, AC_EUNSUPPORTED, "topk_merge: shards*k=%d too large", shards * k);
+    (void)hipFuncSetAttribute((const void*)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(256), lds, stream, d_D_in, d_I_in, shards, nq, k,
+                       d_outD, d_outI);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_proto_scores(const float* d_D, const int64_t* d_I, int nq, int k, float* d_out,
+                               ac_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_REQUIRE(nq >= 0 && k >= 1 && d_D && d_I && d_out, AC_EINVAL, "proto_scores: bad arguments");
+    if (nq == 0) return AC_OK;
+    hipLaunchKernelGGL(proto_scores_kernel, dim3(nq), dim3(64), 0, stream, d_D, d_I, nq, k, d_out);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}

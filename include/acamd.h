@@ -1,0 +1,236 @@
+/*
+ * acamd.h -- C ABI of libacamd.so: the MI355X (gfx950) hot path of
+ * codelion/adaptive-classifier's predict()/add_examples().
+ *
+ * The reference has no FFI of its own: it is Python calling three third-party
+ * native libraries (faiss, torch, transformers).  Each entry point below names
+ * the reference call site (file:line under /root/reference) whose arithmetic it
+ * replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative AC_E* code on failure;
+ *     ac_last_error() returns a per-thread message for the last failure.
+ *   - all pointers named d_* are DEVICE pointers (HBM) owned by the caller
+ *     (e.g. torch.Tensor.data_ptr()); nothing is allocated behind the caller's
+ *     back: scratch space is passed in and sized by the *_workspace() queries.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Calls
+ *     only enqueue work; they never synchronise the stream.
+ *   - the library keeps no global mutable state except the per-thread error
+ *     string and a lazily cached device-properties struct.
+ *   - fp32 arithmetic unless stated; ids are int64 like faiss::idx_t.
+ */
+#ifndef ACAMD_H
+#define ACAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AC_OK            0
+#define AC_EINVAL       -1   /* bad argument (shape, alignment, null) */
+#define AC_EUNSUPPORTED -2   /* valid request outside what the kernels cover */
+#define AC_EWORKSPACE   -3   /* workspace too small */
+#define AC_EHIP         -4   /* HIP runtime error (message has hipGetErrorString) */
+
+typedef void* ac_stream_t;
+
+const char* ac_last_error(void);
+int ac_version(void);                 /* 100*major + minor */
+int ac_device_info(int* cu_count, int* lds_bytes_per_block, size_t* hbm_bytes);
+
+/* ------------------------------------------------------------------------- *
+ *  M: PrototypeMemory kNN  (faiss.IndexFlatL2.search, memory.py:114)
+ * ------------------------------------------------------------------------- */
+
+/* Limits of the fused sweep (ac_knn_l2_topk): k <= AC_KNN_MAX_K. */
+#define AC_KNN_MAX_K 248
+
+/* Bytes of scratch ac_knn_l2_topk needs for this problem size. */
+int ac_knn_l2_topk_workspace(int64_t N, int D, int nq, int k, size_t* bytes);
+
+/*
+ * Exact squared-L2 k-nearest rows, the semantics of faiss.IndexFlatL2.search
+ * (memory.py:114): for each of the nq queries the k smallest
+ * ||P[n,:] - Q[q,:]||^2 in ascending order, ties broken by the lower row id.
+ *
+ * Exactness contract (what "bit-exact top-k" means here):
+ * the returned ids are the top-k under the *exactly computed* distance
+ * (fp64 accumulation of (p-q)^2, which is exact to 1e-16 relative for fp32
+ * inputs), and d_outD is that distance rounded once to fp32.  Internally an
+ * fp32-MFMA sweep proposes k+pad candidates per query, the candidates are
+ * re-ranked in fp64, and a per-query error-bound certificate decides whether
+ * the proposal provably contains the true top-k; queries that fail the
+ * certificate are redone by an exact fp64 sweep inside the same call.
+ *
+ *   d_P   [N, ldP] row-major fp32 prototype rows of this shard, 16-byte
+ *         aligned, ldP % 4 == 0, columns D..round_up(D,4) zero
+ *   d_Q   [nq, ldQ] row-major fp32 queries
+ *   row_offset  added to local row ids (global id of row 0 of this shard)
+ *   d_outD [nq, k] fp32, d_outI [nq, k] int64; if k > N the tail is padded
+ *         with (FLT_MAX, -1) like faiss
+ *   d_stats  optional int32[4] (may be NULL): {queries that took the exact
+ *         fallback, 0, 0, 0}
+ */
+int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D,
+                   const float* d_Q, int nq, int64_t ldQ, int k,
+                   int64_t row_offset,
+                   float* d_outD, int64_t* d_outI,
+                   void* d_ws, size_t ws_bytes, int32_t* d_stats,
+                   ac_stream_t stream);
+
+/*
+ * Merge per-shard results: in [shards, nq, k] ascending
+ * lists -> global ascending top-k by (distance, id).  Entries with id < 0 are
+ * padding.  Pure selection: no arithmetic on the distances.
+ */
+int ac_topk_merge(const float* d_D_in, const int64_t* d_I_in, int shards,
+                  int nq, int k, float* d_outD, int64_t* d_outI,
+                  ac_stream_t stream);
+
+/*
+ * memory.py:117,129-130: s = exp(-d) per hit, then softmax over the k hits of
+ * each query.  Hits with id < 0 get score 0 and are left out of the softmax.
+ */
+int ac_proto_scores(const float* d_D, const int64_t* d_I, int nq, int k,
+                    float* d_out, ac_stream_t stream);
+
+/* Deterministic synthetic rows: row r, col c = unit-normalised
+ * N(0,1) from a counter-based generator keyed on (seed, row_offset + r, c).
+ * Bit-identical to oracle/synth.py.  d_out [n, ld] fp32. */
+int ac_synth_unit_rows(float* d_out, int64_t n, int64_t ld, int D,
+                       uint64_t seed, int64_t row_offset, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  H: AdaptiveHead  (models.py:30-98) + EWC (ewc.py) + AdamW
+ * ------------------------------------------------------------------------- */
+
+/* Dense fp32 GEMM with fused epilogue on the fp32 MFMA pipe:
+ *   C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]) (+ residual[M,N])
+ * W is the torch nn.Linear layout.  act: 0 none, 1 ReLU, 2 GELU(erf).
+ * Exact fp32 fma chains (no reduced precision).  lda/ldw/ldc in elements. */
+int ac_linear_f32(const float* d_A, int64_t lda, const float* d_W, int64_t ldw,
+                  const float* d_bias, const float* d_residual, int64_t ldr,
+                  float* d_C, int64_t ldc, int M, int N, int K, int act,
+                  ac_stream_t stream);
+
+/* General fp32 GEMM C = alpha * op(A) @ op(B) + beta * C used by the head
+ * backward (dW = dY^T X, dX = dY W).  transA/transB: 0 = as stored, 1 = T. */
+int ac_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
+                const float* d_A, int64_t lda, const float* d_B, int64_t ldb,
+                float beta, float* d_C, int64_t ldc, ac_stream_t stream);
+
+/* Flat parameter block of an AdaptiveHead with hidden dims [H1, H2]
+ * (classifier.py:1241: H1 = D, H2 = D/2).  All six tensors live in ONE
+ * contiguous fp32 buffer in state_dict order
+ *   model.0.weight [H1,D] | model.0.bias [H1] | model.3.weight [H2,H1] |
+ *   model.3.bias [H2] | model.6.weight [C,H2] | model.6.bias [C]
+ * so that the optimizer step is one launch over P = ac_head_param_count(). */
+typedef struct {
+    int D, H1, H2, C;
+} ac_head_dims;
+
+int64_t ac_head_param_count(const ac_head_dims* dims);
+
+int ac_head_workspace(const ac_head_dims* dims, int B, size_t* bytes);
+
+/* models.py:71-80 in eval mode (dropout off): logits[B,C]. */
+int ac_head_forward(const ac_head_dims* dims, const float* d_params,
+                    const float* d_X, int64_t ldx, int B, float* d_logits,
+                    void* d_ws, size_t ws_bytes, ac_stream_t stream);
+
+/* One training forward+backward (classifier.py:1489-1499 / :332-345):
+ * train-mode forward with inverted dropout p (mask bytes supplied by the
+ * caller, 1 = keep, NULL = no dropout), mean cross-entropy against int64
+ * labels, backward into d_grads (same flat layout as params).  d_loss gets
+ * the scalar CE loss. */
+int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_params,
+                       const float* d_X, int64_t ldx, const int64_t* d_y,
+                       const uint8_t* d_mask1, const uint8_t* d_mask2,
+                       float dropout_p, int B, float* d_loss, float* d_grads,
+                       void* d_ws, size_t ws_bytes, ac_stream_t stream);
+
+/* ewc.py:90-92: fisher += grad^2 * inv_num_batches over the flat block. */
+int ac_fisher_accumulate(const float* d_grads, float inv_num_batches,
+                         float* d_fisher, int64_t n, ac_stream_t stream);
+
+/* ewc.py:96-116: lambda * sum(F * (p - p_old)^2) [/ batch_size]. */
+int ac_ewc_loss(const float* d_params, const float* d_fisher,
+                const float* d_old, int64_t n, float lambda_over_B,
+                float* d_out_loss, ac_stream_t stream);
+
+/*
+ * The fused EWC-regularised AdamW step (classifier.py:337-351 +
+ * torch.optim.AdamW + clip_grad_norm_):
+ *   g_i  = grad_i + 2*lambda_over_B * F_i * (p_i - pold_i)     (EWC gradient; skipped if F NULL)
+ *   coef = min(1, max_norm / (||g||_2 + 1e-6))                 (clip_grad_norm_)
+ *   p   *= 1 - lr*wd ; m = b1 m + (1-b1) coef g ; v = b2 v + (1-b2)(coef g)^2
+ *   p   -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * d_out[0] = EWC penalty lambda_over_B*sum F (p-pold)^2 (before the update),
+ * d_out[1] = ||g||_2 (before clipping).  `d_scratch` >= 1 KiB.
+ */
+int ac_ewc_adamw_step(float* d_params, const float* d_grads, float* d_m,
+                      float* d_v, const float* d_fisher, const float* d_old,
+                      int64_t n, float lambda_over_B, float max_grad_norm,
+                      float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int step, float* d_out,
+                      void* d_scratch, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  E: encoder  (classifier.py:1271-1275 -> transformers BertModel.forward)
+ * ------------------------------------------------------------------------- */
+
+typedef struct {
+    int hidden;        /* H  (768 bert-base, 1024 bert-large / e5-large-v2) */
+    int layers;        /* L */
+    int heads;         /* A, head dim = H / A */
+    int intermediate;  /* I */
+    int vocab;
+    int max_pos;
+    int type_vocab;
+    float ln_eps;      /* 1e-12 */
+} ac_bert_config;
+
+/* Device pointers to the weights, nn.Linear [out,in] layout, fp32.
+ * Per-layer arrays have `layers` entries (host arrays of device pointers). */
+typedef struct {
+    const float* word_emb;      /* [vocab, H] */
+    const float* pos_emb;       /* [max_pos, H] */
+    const float* type_emb;      /* [type_vocab, H] */
+    const float* emb_ln_g;      /* [H] */
+    const float* emb_ln_b;
+    const float* const* qkv_w;  /* [3H, H]  rows: Wq | Wk | Wv */
+    const float* const* qkv_b;  /* [3H] */
+    const float* const* ao_w;   /* [H, H] attention output dense */
+    const float* const* ao_b;
+    const float* const* ln1_g;  /* attention output LayerNorm */
+    const float* const* ln1_b;
+    const float* const* ff1_w;  /* [I, H] */
+    const float* const* ff1_b;
+    const float* const* ff2_w;  /* [H, I] */
+    const float* const* ff2_b;
+    const float* const* ln2_g;  /* output LayerNorm */
+    const float* const* ln2_b;
+} ac_bert_weights;
+
+int ac_bert_workspace(const ac_bert_config* cfg, int b, int S, size_t* bytes);
+
+/*
+ * classifier.py:1271-1275: BertModel forward in eval mode on
+ * (input_ids, token_type_ids, attention_mask) int64 [b,S], take
+ * last_hidden_state[:,0,:], L2-normalise (F.normalize eps 1e-12) and write
+ * d_out_unit_cls [b, ldo] fp32 -- directly usable as the kNN query block.
+ * d_type_ids may be NULL (all zero); d_mask may be NULL (all ones).
+ */
+int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weights* w,
+                       const int64_t* d_ids, const int64_t* d_type_ids,
+                       const int64_t* d_mask, int b, int S,
+                       float* d_out_unit_cls, int64_t ldo,
+                       void* d_ws, size_t ws_bytes, ac_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACAMD_H */

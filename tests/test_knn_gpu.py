@@ -1,0 +1,154 @@
+"""Parity of the HIP kNN path (ac_knn_l2_topk through the C ABI) against the oracle.
+
+Bar (BASELINE.json north_star): identical top-k ids; distances are the exact squared distance
+rounded to fp32 (tolerance: 1 ulp, because the fp64 summation order differs from numpy's).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_close(a, b):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    return np.all(np.abs(a - b) <= np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)))
+
+
+def _check(P, Q, k, cuda_dev, row_offset=0):
+    from adaptive_classifier import index as ix
+    from oracle import c_oracle
+    Pd = torch.from_numpy(P).to(cuda_dev)
+    ld = (P.shape[1] + 3) // 4 * 4
+    store = torch.zeros((max(P.shape[0], 1), ld), dtype=torch.float32, device=cuda_dev)
+    if P.shape[0]:
+        store[: P.shape[0], : P.shape[1]] = Pd
+    Qd = torch.from_numpy(Q).to(cuda_dev)
+    stats = torch.zeros(4, dtype=torch.int32, device=cuda_dev)
+    D, I = ix.knn_l2_topk(store, P.shape[0], P.shape[1], Qd, k, row_offset=row_offset, stats=stats)
+    torch.cuda.synchronize()
+    oD, oI = c_oracle.knn_l2_topk(P, Q, k, row_offset) if P.shape[0] else (
+        np.full((Q.shape[0], k), np.finfo(np.float32).max, np.float32), np.full((Q.shape[0], k), -1, np.int64))
+    I = I.cpu().numpy()
+    D = D.cpu().numpy()
+    assert np.array_equal(I, oI), f"id mismatch: {(I != oI).sum()} of {I.size}"
+    assert _ulp_close(D, oD)
+    return int(stats[0].item())
+
+
+@pytest.mark.parametrize("N,D,nq,k", [
+    (4, 768, 1, 4),          # the reference's own shape: one prototype per class, k = #classes
+    (100, 768, 8, 5),
+    (77, 768, 3, 77),        # k = N (banking77-like)
+    (1000, 128, 16, 16),     # bert-tiny dim
+    (5000, 768, 33, 16),     # 2 query tiles, ragged
+    (4097, 1024, 17, 32),    # e5-large dim -> TQ=16 variant by LDS budget
+    (3000, 384, 64, 1),
+    (2500, 100, 5, 10),      # D % 8 != 0 (tail group), D % 4 == 0
+    (999, 770, 7, 9),        # D % 4 != 0 (zero padded ld)
+    (20000, 768, 256, 16),
+    (300, 64, 40, 200),      # large k -> TQ=16, cap 512
+])
+def test_knn_matches_oracle(N, D, nq, k, cuda_dev):
+    from oracle import synth
+    P = synth.synth_unit_rows(N, D, seed=1)
+    Q = synth.synth_unit_rows(nq, D, seed=2)
+    _check(P, Q, k, cuda_dev)
+
+
+def test_knn_row_offset_and_unnormalised(cuda_dev):
+    rng = np.random.default_rng(0)
+    P = (rng.standard_normal((3000, 768)) * 3).astype(np.float32)
+    Q = (rng.standard_normal((9, 768)) * 0.5).astype(np.float32)
+    _check(P, Q, 8, cuda_dev, row_offset=10_000_000_000)
+
+
+def test_knn_duplicates_and_ties(cuda_dev):
+    """Exact duplicates straddling the k boundary: ids must come back lowest-first (faiss tie rule).
+    The certificate cannot separate exact ties, so these queries take the exact fallback."""
+    from oracle import synth
+    base = synth.synth_unit_rows(50, 768, seed=5)
+    P = np.concatenate([base] * 40, axis=0)           # every row appears 40 times
+    Q = base[:6].copy()
+    nfb = _check(P, Q, 16, cuda_dev)
+    assert nfb == 6
+
+
+def test_knn_k_greater_than_N_pads(cuda_dev):
+    from oracle import synth
+    P = synth.synth_unit_rows(5, 768, seed=1)
+    Q = synth.synth_unit_rows(3, 768, seed=2)
+    _check(P, Q, 12, cuda_dev)
+
+
+def test_knn_empty_index(cuda_dev):
+    Q = np.ones((2, 768), np.float32)
+    _check(np.zeros((0, 768), np.float32), Q, 4, cuda_dev)
+
+
+def test_knn_adversarial_order(cuda_dev):
+    """Rows sorted so that every later tile beats all earlier ones (worst case for the running
+    threshold: every row is pushed, lists overflow and are pruned every tile)."""
+    from oracle import synth
+    P = synth.synth_unit_rows(6000, 768, seed=7)
+    q = synth.synth_unit_rows(1, 768, seed=8)
+    d = ((P - q) ** 2).sum(1)
+    P = P[np.argsort(-d)]                              # farthest first
+    Q = np.repeat(q, 20, axis=0) + synth.synth_unit_rows(20, 768, seed=9) * 1e-3
+    _check(P, Q.astype(np.float32), 32, cuda_dev)
+
+
+def test_synth_rows_bit_identical(cuda_dev):
+    from adaptive_classifier import index as ix
+    from oracle import synth
+    for (n, D, seed, off) in [(100, 768, 1, 0), (37, 1024, 3, 12345), (5, 770, 9, 1 << 33)]:
+        dev = ix.synth_unit_rows(n, D, seed, off, device=cuda_dev)
+        ref = synth.synth_unit_rows(n, D, seed, off)
+        assert np.array_equal(dev[:, :D].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        assert float(dev[:, D:].abs().sum()) == 0.0
+
+
+def test_large_sweep_properties(cuda_dev):
+    """1M x 768 (3 GB): oracle on an 8-query subset, plus size-independent properties:
+    ascending distances, unique ids, and shard-consistency (top-k of the union of two halves ==
+    merge of the halves' top-k)."""
+    from adaptive_classifier import index as ix
+    from oracle import c_oracle
+    N, D, nq, k = 1_000_000, 768, 32, 32
+    P = ix.synth_unit_rows(N, D, 1, device=cuda_dev)
+    Q = ix.synth_unit_rows(nq, D, 2, device=cuda_dev)
+    Dd, Id = ix.knn_l2_topk(P, N, D, Q, k)
+    h = N // 2
+    D0, I0 = ix.knn_l2_topk(P[:h], h, D, Q, k)
+    D1, I1 = ix.knn_l2_topk(P[h:], N - h, D, Q, k, row_offset=h)
+    Dm, Im = ix.topk_merge(torch.stack([D0, D1]), torch.stack([I0, I1]))
+    torch.cuda.synchronize()
+    assert torch.equal(Im, Id) and torch.equal(Dm, Dd)
+    d = Dd.cpu().numpy()
+    assert np.all(np.diff(d, axis=1) >= 0)
+    i = Id.cpu().numpy()
+    assert all(len(set(r)) == k for r in i)
+    sub = 8
+    oD, oI = c_oracle.knn_l2_topk(P.cpu().numpy(), Q[:sub].cpu().numpy(), k)
+    assert np.array_equal(i[:sub], oI)
+    assert _ulp_close(d[:sub], oD)
+
+
+def test_topk_merge_and_scores(cuda_dev):
+    from adaptive_classifier import index as ix
+    from oracle import knn_oracle
+    rng = np.random.default_rng(3)
+    S, nq, k = 8, 13, 32
+    Din = np.sort(rng.random((S, nq, k)).astype(np.float32), axis=2)
+    Iin = rng.permutation(S * nq * k).reshape(S, nq, k).astype(np.int64)
+    Din[2, :, 20:] = np.finfo(np.float32).max
+    Iin[2, :, 20:] = -1
+    Din[3, 0, 0] = Din[4, 0, 0]                       # a tie across shards
+    D, I = ix.topk_merge(torch.from_numpy(Din).to(cuda_dev), torch.from_numpy(Iin).to(cuda_dev))
+    oD, oI = knn_oracle.topk_merge(Din, Iin, k)
+    assert np.array_equal(I.cpu().numpy(), oI) and np.array_equal(D.cpu().numpy(), oD)
+    sc = ix.proto_scores(D, I).cpu().numpy()
+    ref = knn_oracle.proto_scores(oD, oI)
+    assert np.allclose(sc, ref, atol=1e-6)            # fp32 exp/softmax: 1e-6 absolute
+    assert np.allclose(sc.sum(1), 1.0, atol=1e-5)     # tests/test_memory.py:84-85
