@@ -70,7 +70,7 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
     "ac_fisher_accumulate": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
-    "ac_ewc_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    "ac_ewc_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "ac_ewc_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                   c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p,
                                   c_void_p, c_void_p]),
@@ -95,8 +95,6 @@ def lib():
                 f"(make -C {_CSRC}). There is no CPU fallback for the MI355X hot path.")
         L = ctypes.CDLL(_LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
-            if not hasattr(L, name) and os.environ.get("AC_DEV_PARTIAL") == "1":
-                continue                # development only: library still being brought up
             fn = getattr(L, name)       # AttributeError => header/library mismatch, fail loudly
             fn.restype = res
             fn.argtypes = args

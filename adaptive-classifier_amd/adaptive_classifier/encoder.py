@@ -1,0 +1,134 @@
+"""HipBertEncoder: the encoder call of the hot path on MI355X.
+
+Replaces `self.model(**inputs).last_hidden_state[:, 0, :]` + `F.normalize`
+(/root/reference/src/adaptive_classifier/classifier.py:1271-1275) for BERT-architecture
+checkpoints (bert-base-uncased, bert-large, e5-large-v2, bert-tiny ...) with one native call,
+`ac_bert_encode_cls`, that writes unit-norm CLS vectors straight into a device buffer usable as the
+kNN query block (no device->host copy, cf. classifier.py:1282).
+
+Weights are taken from a transformers `BertModel` (pretrained or randomly initialised); Q/K/V
+projections are fused into one [3H, H] matrix.  Other architectures are not covered by the HIP
+encoder and raise.
+"""
+import ctypes
+
+import torch
+
+from . import _native as nv
+
+
+class _Cfg:
+    """The slice of a HF config the classifier reads (classifier.py:88,549)."""
+
+    def __init__(self, hidden_size, name_or_path):
+        self.hidden_size = hidden_size
+        self._name_or_path = name_or_path
+
+
+class HipBertEncoder:
+    def __init__(self, hf_bert, device=None):
+        nv.require_gpu()
+        cfg = hf_bert.config
+        if getattr(cfg, "model_type", "bert") != "bert":
+            raise nv.NativeError(f"HipBertEncoder covers BERT-architecture encoders, got {cfg.model_type!r}")
+        if getattr(cfg, "position_embedding_type", "absolute") not in (None, "absolute"):
+            raise nv.NativeError("HipBertEncoder: only absolute position embeddings are supported")
+        if cfg.hidden_act not in ("gelu",):
+            raise nv.NativeError(f"HipBertEncoder: hidden_act={cfg.hidden_act!r} unsupported (erf-GELU only)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.config = _Cfg(cfg.hidden_size, getattr(cfg, "_name_or_path", ""))
+        self.training = False
+        self.ccfg = nv.ac_bert_config(cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                                      cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
+                                      cfg.type_vocab_size, float(cfg.layer_norm_eps))
+        sd = {k: v.detach() for k, v in hf_bert.state_dict().items()}
+
+        def dev(t):
+            return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+        self._keep = []                      # owns the device tensors
+
+        def own(t):
+            t = dev(t)
+            self._keep.append(t)
+            return t
+
+        L = cfg.num_hidden_layers
+        per = {k: [] for k in ("qkv_w", "qkv_b", "ao_w", "ao_b", "ln1_g", "ln1_b", "ff1_w", "ff1_b",
+                               "ff2_w", "ff2_b", "ln2_g", "ln2_b")}
+        for l in range(L):
+            p = f"encoder.layer.{l}."
+            a = p + "attention.self."
+            per["qkv_w"].append(own(torch.cat([sd[a + "query.weight"], sd[a + "key.weight"], sd[a + "value.weight"]], 0)))
+            per["qkv_b"].append(own(torch.cat([sd[a + "query.bias"], sd[a + "key.bias"], sd[a + "value.bias"]], 0)))
+            per["ao_w"].append(own(sd[p + "attention.output.dense.weight"]))
+            per["ao_b"].append(own(sd[p + "attention.output.dense.bias"]))
+            per["ln1_g"].append(own(sd[p + "attention.output.LayerNorm.weight"]))
+            per["ln1_b"].append(own(sd[p + "attention.output.LayerNorm.bias"]))
+            per["ff1_w"].append(own(sd[p + "intermediate.dense.weight"]))
+            per["ff1_b"].append(own(sd[p + "intermediate.dense.bias"]))
+            per["ff2_w"].append(own(sd[p + "output.dense.weight"]))
+            per["ff2_b"].append(own(sd[p + "output.dense.bias"]))
+            per["ln2_g"].append(own(sd[p + "output.LayerNorm.weight"]))
+            per["ln2_b"].append(own(sd[p + "output.LayerNorm.bias"]))
+        self._arrays = {}
+        w = nv.ac_bert_weights()
+        w.word_emb = own(sd["embeddings.word_embeddings.weight"]).data_ptr()
+        w.pos_emb = own(sd["embeddings.position_embeddings.weight"]).data_ptr()
+        w.type_emb = own(sd["embeddings.token_type_embeddings.weight"]).data_ptr()
+        w.emb_ln_g = own(sd["embeddings.LayerNorm.weight"]).data_ptr()
+        w.emb_ln_b = own(sd["embeddings.LayerNorm.bias"]).data_ptr()
+        for k, tensors in per.items():
+            arr = (ctypes.c_void_p * L)(*[t.data_ptr() for t in tensors])
+            self._arrays[k] = arr             # host array of device pointers; must outlive the calls
+            setattr(w, k, ctypes.cast(arr, ctypes.c_void_p).value)
+        self.weights = w
+        self._ws = None
+        self.num_params = sum(t.numel() for t in self._keep)
+
+    # -- the nn.Module-ish surface classifier.py touches (:1253-1255,1278-1279,1215) ----------
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        self.training = False                 # inference-only encoder
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise nv.NativeError("HipBertEncoder is bound to its GPU; build a new one for another device")
+        return self
+
+    def workspace_bytes(self, b, S):
+        need = ctypes.c_size_t(0)
+        nv.check(nv.lib().ac_bert_workspace(ctypes.byref(self.ccfg), b, S, ctypes.byref(need)), "ac_bert_workspace")
+        return need.value
+
+    def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None):
+        """int64 [b, S] ids (+ optional type ids / mask) -> unit-norm CLS embeddings [b, H] on device."""
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        b, S = ids.shape
+        tt = None if token_type_ids is None else token_type_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        mk = None if attention_mask is None else attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        H = self.ccfg.hidden
+        if out is None:
+            out = torch.empty((b, H), dtype=torch.float32, device=self.device)
+        need = self.workspace_bytes(b, S)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            nv.check(nv.lib().ac_bert_encode_cls(
+                ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids), nv.ptr(tt), nv.ptr(mk), b, S,
+                nv.ptr(out), out.stride(0), nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
+                "ac_bert_encode_cls")
+        return out
+
+    def flops(self, b, S):
+        """Algorithmic FLOPs of one forward (dense projections + attention), for roofline reports."""
+        c = self.ccfg
+        H, I, L = c.hidden, c.intermediate, c.layers
+        T = b * S
+        dense = 2.0 * T * (4.0 * H * H + 2.0 * H * I) * L
+        attn = 4.0 * b * c.heads * S * S * (H // c.heads) * L
+        return dense + attn

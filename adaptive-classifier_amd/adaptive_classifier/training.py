@@ -1,0 +1,82 @@
+"""Native training step for AdaptiveHead: the inner loop of classifier.py:1483-1507
+(_train_adaptive_head) and :327-353 (_train_new_classes) on MI355X.
+
+One step = `ac_head_fwd_bwd_ce` (train-mode forward with the dropout masks, mean CE, backward into
+a flat gradient block) + `ac_ewc_adamw_step` (EWC gradient + clip_grad_norm_(1.0) + AdamW over the
+flat block).  Optimizer state (m, v) lives here like torch.optim.AdamW keeps it -- fresh for every
+add_examples() call, as in the reference (a new AdamW is built at classifier.py:308,1464).
+"""
+import ctypes
+
+import torch
+
+from . import _native as nv
+
+REDUCE_SCRATCH_BYTES = 8192
+
+
+class HeadTrainer:
+    def __init__(self, head, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0):
+        nv.require_gpu()
+        self.head = head
+        self.dims = head.native_dims()
+        if self.dims is None:
+            raise nv.NativeError("HeadTrainer needs an AdaptiveHead with two hidden layers")
+        self.flat = head.flat_params()
+        if not self.flat.is_cuda:
+            raise nv.NativeError("HeadTrainer: the head must live on a GPU (no CPU fallback)")
+        dev = self.flat.device
+        self.device = dev
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.grads = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.t = 0
+        self.scratch = torch.zeros(REDUCE_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.out = torch.zeros(2, dtype=torch.float32, device=dev)      # [ewc penalty, grad norm]
+        self._ws = None
+
+    def _workspace(self, B):
+        need = ctypes.c_size_t(0)
+        nv.check(nv.lib().ac_head_workspace(ctypes.byref(self.dims), B, ctypes.byref(need)), "ac_head_workspace")
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def dropout_masks(self, B, p=0.1, generator=None):
+        """Bernoulli(1-p) keep masks for the two hidden layers, uint8 [B,H1], [B,H2]."""
+        m1 = (torch.rand((B, self.dims.H1), device=self.device, generator=generator) >= p).to(torch.uint8)
+        m2 = (torch.rand((B, self.dims.H2), device=self.device, generator=generator) >= p).to(torch.uint8)
+        return m1, m2
+
+    def forward_backward(self, X, y, mask1=None, mask2=None, dropout_p=0.1):
+        """Fills self.grads and self.loss (device scalars; no host sync)."""
+        X = X.to(device=self.device, dtype=torch.float32)
+        if X.stride(-1) != 1:
+            X = X.contiguous()
+        y = y.to(device=self.device, dtype=torch.int64).contiguous()
+        B = X.shape[0]
+        ws = self._workspace(B)
+        with torch.cuda.device(self.device):
+            nv.check(nv.lib().ac_head_fwd_bwd_ce(
+                ctypes.byref(self.dims), nv.ptr(self.flat), nv.ptr(X), X.stride(0), nv.ptr(y),
+                nv.ptr(mask1), nv.ptr(mask2), dropout_p, B, nv.ptr(self.loss), nv.ptr(self.grads),
+                nv.ptr(ws), ws.numel(), nv.stream_ptr(self.device)), "ac_head_fwd_bwd_ce")
+        return self.loss
+
+    def optimizer_step(self, fisher=None, old_params=None, lambda_over_B=0.0):
+        """clip_grad_norm_ + AdamW (+ EWC gradient when fisher/old_params are given)."""
+        self.t += 1
+        with torch.cuda.device(self.device):
+            nv.check(nv.lib().ac_ewc_adamw_step(
+                nv.ptr(self.flat), nv.ptr(self.grads), nv.ptr(self.m), nv.ptr(self.v),
+                nv.ptr(fisher), nv.ptr(old_params), self.flat.numel(), lambda_over_B, self.max_grad_norm,
+                self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
+                nv.ptr(self.out), nv.ptr(self.scratch), nv.stream_ptr(self.device)), "ac_ewc_adamw_step")
+        return self.out
+
+    def step(self, X, y, mask1=None, mask2=None, dropout_p=0.1, fisher=None, old_params=None, lambda_over_B=0.0):
+        self.forward_backward(X, y, mask1, mask2, dropout_p)
+        self.optimizer_step(fisher, old_params, lambda_over_B)
+        return self.loss, self.out

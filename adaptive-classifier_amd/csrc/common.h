@@ -48,4 +48,15 @@ const DevInfo& dev_info();   // lazily queried for the current device
 
 __host__ __device__ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// gemm.hip: fp32 MFMA GEMMs shared by head.hip and bert.hip
+//   C[M,N] = epi(A[M,K] . W[N,K]^T): bias, act (0 none / 1 relu / 2 gelu-erf), optional inverted
+//   dropout mask (uint8 [M,N], kept values * mask_scale), optional residual added last.
+int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+               const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
+               const uint8_t* mask, float mask_scale, hipStream_t stream);
+//   C = alpha * op(A) op(B) + beta * C; if gate != null: C = gate[m,n] != 0 ? C * gate_scale : 0
+int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
+             const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* gate,
+             int64_t ldg, float gate_scale, hipStream_t stream);
+
 }  // namespace ac

@@ -1,0 +1,294 @@
+// fp32 GEMMs on the f32-input MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32 fma chains,
+// 157 TFLOP/s peak on MI355X).  Replaces the torch nn.Linear / autograd matmul sites of the
+// hot path: AdaptiveHead (models.py:49-69,71-80), its backward (classifier.py:1499,345) and the
+// encoder's QKV / output / FFN projections (transformers BertModel, called at classifier.py:1271).
+//
+//  gemm_tile128_nt : C[M,N] = epi(A[M,K] . W[N,K]^T), 128x128x32 block tile, 4 waves (2x2) of
+//                    64x64, operands staged through LDS in MFMA *fragment order* (a lane's
+//                    ds_read_b128 yields 4 consecutive k of its row; XOR-swizzled so both the
+//                    staging writes and the fragment reads are bank-conflict free),
+//                    register-staged double buffering, one barrier per k-tile.
+//  gemm_direct     : one 32x32 output tile per wave, operands straight from global memory in
+//                    fragment shape, K split over the block's 4 waves and reduced through LDS in
+//                    a fixed order (deterministic).  Any operand layout; used for the small
+//                    latency-bound head GEMMs (B = 32) and odd shapes.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+struct Epilogue {
+    const float* bias;      // [N] or null
+    const float* residual;  // [M, ldr] or null  (added after the activation)
+    int64_t ldr;
+    int act;
+    float alpha;            // C = alpha * acc (+ beta * Cold) before bias/act
+    float beta;
+    // inverted-dropout mask applied after the activation (train-mode head): 1 = keep
+    const uint8_t* mask;    // [M, N] or null
+    float mask_scale;
+    // relu/dropout backward gate: out = gate[row,col] != 0 ? out * gate_scale : 0
+    const float* gate;      // [M, ldg] or null
+    int64_t ldg;
+    float gate_scale;
+};
+
+__device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, int64_t row, int col,
+                                                const float* C, int64_t ldc, int N) {
+    float v = e.alpha * acc;
+    if (e.beta != 0.f) v = fmaf(e.beta, C[row * ldc + col], v);
+    if (e.bias) v += e.bias[col];
+    if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (e.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (e.mask) v = e.mask[row * (int64_t)N + col] ? v * e.mask_scale : 0.f;
+    if (e.residual) v += e.residual[row * e.ldr + col];
+    if (e.gate) v = (e.gate[row * e.ldg + col] != 0.f) ? v * e.gate_scale : 0.f;
+    return v;
+}
+
+__device__ __forceinline__ int acc_row32(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---------------------------------------------------------------------------------------------
+// 128x128x32 LDS-tiled NT kernel
+// ---------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int kTileThreads = 256;
+// LDS image of one operand tile: [4 row groups of 32][4 k-blocks of 8][64 float4 slots]
+constexpr int kTileSlots = 4 * 4 * 64;
+
+__device__ __forceinline__ int tile_slot(int row, int c4) {   // row in [0,128), c4 in [0,8)
+    const int rg = row >> 5, i = row & 31, kb = c4 >> 1, h = c4 & 1;
+    return ((rg * 4 + kb) << 6) + (((h << 5) + i) ^ c4);
+}
+
+__global__ __launch_bounds__(kTileThreads, 2) void gemm_tile128_nt(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
+    float* __restrict__ C, int64_t ldc, int M, int N, int K, Epilogue epi) {
+    __shared__ __attribute__((aligned(16))) f32x4 lds[2][2][kTileSlots];   // [stage][A|W]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // column tiles fastest: consecutive blocks share the same A rows (L2 reuse of A)
+    const int ntn = (N + BN - 1) / BN;
+    const int bn = blockIdx.x % ntn, bm = blockIdx.x / ntn;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // staging assignment: thread -> (row = tid/8 + 32*p, c4 = tid%8), p = 0..3
+    const int srow = tid >> 3, sc4 = tid & 7;
+    const float* aptr[4];
+    const float* wptr[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int ra = m0 + srow + 32 * p; if (ra > M - 1) ra = M - 1;
+        int rw = n0 + srow + 32 * p; if (rw > N - 1) rw = N - 1;
+        aptr[p] = A + (int64_t)ra * lda + 4 * sc4;
+        wptr[p] = W + (int64_t)rw * ldw + 4 * sc4;
+    }
+    int sslot[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) sslot[p] = tile_slot(srow + 32 * p, sc4);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = K / BK;
+    f32x4 ra[4], rw[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { ra[p] = *reinterpret_cast<const f32x4*>(aptr[p]); rw[p] = *reinterpret_cast<const f32x4*>(wptr[p]); }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { lds[0][0][sslot[p]] = ra[p]; lds[0][1][sslot[p]] = rw[p]; }
+    __syncthreads();
+
+    const int h = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        // prefetch the next k-tile (the last iteration re-reads the current one: loads stay
+        // unconditional so the compiler's vmcnt accounting is exact)
+        const int knext = (kt + 1 < nk) ? (kt + 1) * BK : kt * BK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = *reinterpret_cast<const f32x4*>(aptr[p] + knext);
+            rw[p] = *reinterpret_cast<const f32x4*>(wptr[p] + knext);
+        }
+        const f32x4* As = lds[cur][0];
+        const f32x4* Ws = lds[cur][1];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int sl = lane ^ ((kb * 2 + h) & 7);
+            const f32x4 a0 = As[(((2 * wm + 0) * 4 + kb) << 6) + sl];
+            const f32x4 a1 = As[(((2 * wm + 1) * 4 + kb) << 6) + sl];
+            const f32x4 b0 = Ws[(((2 * wn + 0) * 4 + kb) << 6) + sl];
+            const f32x4 b1 = Ws[(((2 * wn + 1) * 4 + kb) << 6) + sl];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { lds[cur ^ 1][0][sslot[p]] = ra[p]; lds[cur ^ 1][1][sslot[p]] = rw[p]; }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane owns column (lane & 31) of each 32x32 tile, 16 rows
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 64 + mi * 32 + acc_row32(r, lane);
+                if (row < M) C[row * ldc + col] = apply_epilogue(epi, acc[mi][ni][r], row, col, C, ldc, N);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// direct kernel: one 32x32 tile per block, K split over 4 waves
+//   AK: A element (m,k) at A[m*lda + k] (K-major) else A[k*lda + m]
+//   BK_: B element (k,n) at B[n*ldb + k] (K-major, nn.Linear weight) else B[k*ldb + n]
+// ---------------------------------------------------------------------------------------------
+template <bool KMAJ>
+__device__ __forceinline__ f32x4 load_frag(const float* base, int64_t ld, int idx, int idx_max, int k0,
+                                           int K, bool vec_ok) {
+    // idx = row (A) or column (B) owned by this lane (already clamped); k0 = first of 4 k's
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (KMAJ) {
+        const float* p = base + (int64_t)idx * ld + k0;
+        if (vec_ok && k0 + 3 < K) {
+            v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) if (k0 + s < K) v[s] = p[s];
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) if (k0 + s < K) v[s] = base[(int64_t)(k0 + s) * ld + idx];
+    }
+    (void)idx_max;
+    return v;
+}
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(256) void gemm_direct(const float* __restrict__ A, int64_t lda,
+                                                   const float* __restrict__ B, int64_t ldb,
+                                                   float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                   Epilogue epi) {
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int i = lane & 31, h = lane >> 5;
+    int arow = m0 + i; if (arow > M - 1) arow = M - 1;
+    int bcol = n0 + i; if (bcol > N - 1) bcol = N - 1;
+    const bool avec = AK && ((lda & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
+    const bool bvec = BKM && ((ldb & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
+
+    const int nkb = (K + 7) / 8;
+    const int kb_lo = (int)(((int64_t)wave * nkb) / 4), kb_hi = (int)(((int64_t)(wave + 1) * nkb) / 4);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kb = kb_lo; kb < kb_hi; ++kb) {
+        const int k0 = kb * 8 + 4 * h;
+        const f32x4 a = load_frag<AK>(A, lda, arow, M, k0, K, avec);
+        const f32x4 b = load_frag<BKM>(B, ldb, bcol, N, k0, K, bvec);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // 1024 outputs, 4 per thread; fixed summation order over the 4 K-slices
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int o = tid + 256 * e;          // o = r * 64 + l
+        const int r = o >> 6, l = o & 63;
+        const float v = ((red[0][r][l] + red[1][r][l]) + red[2][r][l]) + red[3][r][l];
+        const int64_t row = m0 + acc_row32(r, l);
+        const int col = n0 + (l & 31);
+        if (row < M && col < N) C[row * ldc + col] = apply_epilogue(epi, v, row, col, C, ldc, N);
+    }
+}
+
+static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, const float* B, int64_t ldb,
+                       float* C, int64_t ldc, int M, int N, int K, const Epilogue& epi, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return AC_OK;
+    const bool aligned = ((lda & 3) == 0) && ((ldb & 3) == 0) && ((((uintptr_t)A) & 15) == 0) &&
+                         ((((uintptr_t)B) & 15) == 0);
+    if (a_kmaj && b_kmaj && aligned && M >= 192 && K >= BK && (K % BK) == 0) {
+        const int64_t nblk = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+        hipLaunchKernelGGL(gemm_tile128_nt, dim3((unsigned)nblk), dim3(kTileThreads), 0, stream, A, lda, B, ldb,
+                           C, ldc, M, N, K, epi);
+    } else {
+        dim3 grid((N + 31) / 32, (M + 31) / 32);
+        if (a_kmaj && b_kmaj)
+            hipLaunchKernelGGL((gemm_direct<true, true>), grid, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
+        else if (a_kmaj && !b_kmaj)
+            hipLaunchKernelGGL((gemm_direct<true, false>), grid, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
+        else if (!a_kmaj && b_kmaj)
+            hipLaunchKernelGGL((gemm_direct<false, true>), grid, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
+        else
+            hipLaunchKernelGGL((gemm_direct<false, false>), grid, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
+    }
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+}  // namespace
+
+namespace ac {
+// internal entry used by head.hip / bert.hip
+int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+               const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
+               const uint8_t* mask, float mask_scale, hipStream_t stream) {
+    Epilogue e;
+    e.bias = bias; e.residual = residual; e.ldr = ldr; e.act = act; e.alpha = 1.f; e.beta = 0.f;
+    e.mask = mask; e.mask_scale = mask_scale; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f;
+    return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream);
+}
+int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
+             const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* gate, int64_t ldg,
+             float gate_scale, hipStream_t stream) {
+    Epilogue e;
+    e.bias = nullptr; e.residual = nullptr; e.ldr = 0; e.act = ACT_NONE; e.alpha = alpha; e.beta = beta;
+    e.mask = nullptr; e.mask_scale = 1.f; e.gate = gate; e.ldg = ldg; e.gate_scale = gate_scale;
+    return launch_gemm(transA == 0, transB != 0, A, lda, B, ldb, C, ldc, M, N, K, e, stream);
+}
+}  // namespace ac
+
+extern "C" int ac_linear_f32(const float* d_A, int64_t lda, const float* d_W, int64_t ldw,
+                             const float* d_bias, const float* d_residual, int64_t ldr, float* d_C,
+                             int64_t ldc, int M, int N, int K, int act, ac_stream_t stream) {
+    AC_REQUIRE(d_A && d_W && d_C, AC_EINVAL, "linear: null pointer");
+    AC_REQUIRE(M >= 0 && N >= 0 && K >= 1 && lda >= K && ldw >= K && ldc >= N, AC_EINVAL,
+               "linear: bad shape M=%d N=%d K=%d", M, N, K);
+    AC_REQUIRE(act >= 0 && act <= 2, AC_EINVAL, "linear: bad activation %d", act);
+    return ac::linear_f32(d_A, lda, d_W, ldw, d_bias, d_residual, ldr, d_C, ldc, M, N, K, act, nullptr, 1.f,
+                          (hipStream_t)stream);
+}
+
+extern "C" int ac_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* d_A,
+                           int64_t lda, const float* d_B, int64_t ldb, float beta, float* d_C,
+                           int64_t ldc, ac_stream_t stream) {
+    AC_REQUIRE(d_A && d_B && d_C, AC_EINVAL, "gemm: null pointer");
+    AC_REQUIRE(M >= 0 && N >= 0 && K >= 1, AC_EINVAL, "gemm: bad shape");
+    return ac::gemm_f32(transA, transB, M, N, K, alpha, d_A, lda, d_B, ldb, beta, d_C, ldc, nullptr, 0, 1.f,
+                        (hipStream_t)stream);
+}

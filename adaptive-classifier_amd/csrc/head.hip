@@ -1,0 +1,341 @@
+// AdaptiveHead (models.py:30-98), EWC (ewc.py:39-116) and the AdamW training step
+// (classifier.py:1463-1505 and :307-351) as HIP kernels.
+//
+// The head's six tensors live in one flat fp32 block (see acamd.h) so the optimizer step,
+// the Fisher accumulation and the EWC penalty are single launches over P = ~0.9 M elements.
+// The GEMMs run on the fp32 MFMA pipe (gemm.hip); with B = 32 the step is latency bound, so
+// everything else is fused into GEMM epilogues: bias+ReLU+dropout (forward), ReLU/dropout
+// backward gate (backward), softmax+CE+dlogits in one small kernel, bias gradients in one.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+struct HeadOffsets {
+    int64_t w1, b1, w2, b2, w3, b3, total;
+};
+
+HeadOffsets head_offsets(const ac_head_dims& d) {
+    HeadOffsets o;
+    o.w1 = 0;
+    o.b1 = o.w1 + (int64_t)d.H1 * d.D;
+    o.w2 = o.b1 + d.H1;
+    o.b2 = o.w2 + (int64_t)d.H2 * d.H1;
+    o.w3 = o.b2 + d.H2;
+    o.b3 = o.w3 + (int64_t)d.C * d.H2;
+    o.total = o.b3 + d.C;
+    return o;
+}
+
+struct HeadWs {
+    size_t a1, a2, z, dz, d2, d1, rowloss, total;
+};
+
+HeadWs head_ws(const ac_head_dims& d, int B) {
+    HeadWs w;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += ac::align_up(n * sizeof(float), 256); return o; };
+    w.a1 = take((size_t)B * d.H1);
+    w.a2 = take((size_t)B * d.H2);
+    w.z = take((size_t)B * d.C);
+    w.dz = take((size_t)B * d.C);
+    w.d2 = take((size_t)B * d.H2);
+    w.d1 = take((size_t)B * d.H1);
+    w.rowloss = take((size_t)B);
+    w.total = off;
+    return w;
+}
+
+// softmax + mean cross-entropy + dlogits; one wave per row, one block.
+// nn.CrossEntropyLoss (classifier.py:1463,1498): loss = mean_b( logsumexp(z_b) - z_b[y_b] ),
+// dz = (softmax(z) - onehot(y)) / B.
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* z, const int64_t* y, int B, int C,
+                                                         float* dz, float* rowloss, float* loss) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < B; b += 4) {
+        const float* zr = z + (size_t)b * C;
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, zr[c]);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int c = lane; c < C; c += 64) sum += expf(zr[c] - mx);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+        const int64_t yb = y[b];
+        const float invB = 1.f / (float)B;
+        for (int c = lane; c < C; c += 64) {
+            const float p = expf(zr[c] - mx) / sum;
+            dz[(size_t)b * C + c] = (p - (c == yb ? 1.f : 0.f)) * invB;
+        }
+        if (lane == 0) rowloss[b] = (mx + logf(sum)) - zr[yb];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float s = 0.f;
+        for (int b = lane; b < B; b += 64) s += rowloss[b];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+        if (lane == 0) *loss = s / (float)B;
+    }
+}
+
+// bias gradients: column sums of dz [B,C], d2 [B,H2], d1 [B,H1] into the flat grad block
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, const float* d2, const float* d1,
+                                                        int B, int C, int H2, int H1, float* gb3, float* gb2,
+                                                        float* gb1) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const float* src; float* dst; int n, c;
+    if (t < H1) { src = d1; dst = gb1; n = H1; c = t; }
+    else if (t < H1 + H2) { src = d2; dst = gb2; n = H2; c = t - H1; }
+    else if (t < H1 + H2 + C) { src = dz; dst = gb3; n = C; c = t - H1 - H2; }
+    else return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += src[(size_t)b * n + c];
+    dst[c] = s;
+}
+
+__global__ __launch_bounds__(256) void fisher_acc_kernel(const float* g, float inv, float* F, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        F[i] += gi * gi * inv;      // ewc.py:92  fisher += grad**2 / len(loader)
+    }
+}
+
+// ---- deterministic two-pass reductions over the flat parameter block ----
+constexpr int kRedBlocks = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    const float r = ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    __syncthreads();
+    return r;
+}
+
+// pass A: per-block partial sums of  sum g_tot^2  and  sum F (p - p*)^2
+__global__ __launch_bounds__(256) void ewc_partials_kernel(const float* p, const float* g, const float* F,
+                                                           const float* pold, int64_t n, float two_lam,
+                                                           float* partials) {
+    __shared__ float sh[4];
+    float sg = 0.f, se = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)kRedBlocks * 256) {
+        float gi = g ? g[i] : 0.f;
+        if (F) {
+            const float d = p[i] - pold[i];
+            const float fd = F[i] * d;
+            se = fmaf(fd, d, se);
+            gi = fmaf(two_lam, fd, gi);       // d/dp [ lam * F (p-p*)^2 ] = 2 lam F (p-p*)
+        }
+        sg = fmaf(gi, gi, sg);
+    }
+    const float tg = block_sum(sg, sh);
+    const float te = block_sum(se, sh);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = tg; partials[kRedBlocks + blockIdx.x] = te; }
+}
+
+__device__ __forceinline__ void reduce_partials(const float* partials, float* sh, float* tot_g, float* tot_e) {
+    const float a = threadIdx.x < kRedBlocks ? partials[threadIdx.x] : 0.f;
+    const float b = threadIdx.x < kRedBlocks ? partials[kRedBlocks + threadIdx.x] : 0.f;
+    *tot_g = block_sum(a, sh);
+    *tot_e = block_sum(b, sh);
+}
+
+__global__ __launch_bounds__(256) void ewc_loss_final_kernel(const float* partials, float lam, float* out) {
+    __shared__ float sh[4];
+    float tg, te;
+    reduce_partials(partials, sh, &tg, &te);
+    if (threadIdx.x == 0) *out = lam * te;
+}
+
+// pass B: clip + AdamW  (torch.optim.AdamW single-tensor path; clip_grad_norm_)
+__global__ __launch_bounds__(256) void ewc_adamw_kernel(float* p, const float* g, float* m, float* v,
+                                                        const float* F, const float* pold, int64_t n,
+                                                        float lam, float two_lam, float max_norm, float lr_wd,
+                                                        float beta1, float beta2, float one_m_b1, float one_m_b2,
+                                                        float eps, float step_size, float bc2_sqrt,
+                                                        const float* partials, float* out) {
+    __shared__ float sh[4];
+    float tg, te;
+    reduce_partials(partials, sh, &tg, &te);
+    const float norm = sqrtf(tg);
+    float coef = max_norm / (norm + 1e-6f);
+    if (coef > 1.f) coef = 1.f;
+    if (max_norm <= 0.f) coef = 1.f;          // max_norm <= 0 disables clipping
+    if (blockIdx.x == 0 && threadIdx.x == 0 && out) { out[0] = lam * te; out[1] = norm; }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float pi = p[i];
+        float gi = g[i];
+        if (F) gi = fmaf(two_lam, F[i] * (pi - pold[i]), gi);
+        gi *= coef;
+        pi *= (1.f - lr_wd);                                  // decoupled weight decay
+        float mi = m[i];
+        mi = mi + (gi - mi) * one_m_b1;                       // exp_avg.lerp_(grad, 1 - beta1)
+        float vi = v[i] * beta2;
+        vi = vi + one_m_b2 * gi * gi;                         // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);                   // addcdiv_(exp_avg, denom, value=-step_size)
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+int check_dims(const ac_head_dims* d) {
+    AC_REQUIRE(d != nullptr, AC_EINVAL, "head: dims is NULL");
+    AC_REQUIRE(d->D >= 1 && d->H1 >= 1 && d->H2 >= 1 && d->C >= 1, AC_EINVAL, "head: bad dims %d/%d/%d/%d",
+               d->D, d->H1, d->H2, d->C);
+    return AC_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t ac_head_param_count(const ac_head_dims* dims) {
+    if (!dims) return -1;
+    return head_offsets(*dims).total;
+}
+
+extern "C" int ac_head_workspace(const ac_head_dims* dims, int B, size_t* bytes) {
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    AC_REQUIRE(bytes && B >= 0, AC_EINVAL, "head workspace: bad arguments");
+    *bytes = head_ws(*dims, B > 0 ? B : 1).total;
+    return AC_OK;
+}
+
+extern "C" int ac_head_forward(const ac_head_dims* dims, const float* d_params, const float* d_X,
+                               int64_t ldx, int B, float* d_logits, void* d_ws, size_t ws_bytes,
+                               ac_stream_t stream_) {
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B == 0) return AC_OK;
+    AC_REQUIRE(d_params && d_X && d_logits && B > 0 && ldx >= dims->D, AC_EINVAL, "head_forward: bad arguments");
+    const ac_head_dims& d = *dims;
+    const HeadOffsets o = head_offsets(d);
+    const HeadWs w = head_ws(d, B);
+    AC_REQUIRE(d_ws && ws_bytes >= w.total, AC_EWORKSPACE, "head_forward: workspace %zu < %zu", ws_bytes, w.total);
+    char* ws = (char*)d_ws;
+    float* a1 = (float*)(ws + w.a1);
+    float* a2 = (float*)(ws + w.a2);
+    const float* P = d_params;
+    rc = ac::linear_f32(d_X, ldx, P + o.w1, d.D, P + o.b1, nullptr, 0, a1, d.H1, B, d.H1, d.D, 1, nullptr, 1.f, stream);
+    if (rc) return rc;
+    rc = ac::linear_f32(a1, d.H1, P + o.w2, d.H1, P + o.b2, nullptr, 0, a2, d.H2, B, d.H2, d.H1, 1, nullptr, 1.f, stream);
+    if (rc) return rc;
+    return ac::linear_f32(a2, d.H2, P + o.w3, d.H2, P + o.b3, nullptr, 0, d_logits, d.C, B, d.C, d.H2, 0, nullptr, 1.f, stream);
+}
+
+extern "C" int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_params, const float* d_X,
+                                  int64_t ldx, const int64_t* d_y, const uint8_t* d_mask1,
+                                  const uint8_t* d_mask2, float dropout_p, int B, float* d_loss,
+                                  float* d_grads, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_REQUIRE(d_params && d_X && d_y && d_loss && d_grads && B > 0 && ldx >= dims->D, AC_EINVAL,
+               "head_fwd_bwd_ce: bad arguments");
+    AC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, AC_EINVAL, "head_fwd_bwd_ce: dropout_p=%f", dropout_p);
+    const ac_head_dims& d = *dims;
+    const HeadOffsets o = head_offsets(d);
+    const HeadWs w = head_ws(d, B);
+    AC_REQUIRE(d_ws && ws_bytes >= w.total, AC_EWORKSPACE, "head_fwd_bwd_ce: workspace %zu < %zu", ws_bytes, w.total);
+    char* ws = (char*)d_ws;
+    float* a1 = (float*)(ws + w.a1);
+    float* a2 = (float*)(ws + w.a2);
+    float* z = (float*)(ws + w.z);
+    float* dz = (float*)(ws + w.dz);
+    float* d2 = (float*)(ws + w.d2);
+    float* d1 = (float*)(ws + w.d1);
+    float* rowloss = (float*)(ws + w.rowloss);
+    const float* P = d_params;
+    float* G = d_grads;
+    const float scale = 1.f / (1.f - dropout_p);       // nn.Dropout(0.1), models.py:58
+    const float s1 = d_mask1 ? scale : 1.f, s2 = d_mask2 ? scale : 1.f;
+
+    // forward (train mode): a = dropout(relu(x W^T + b))
+    rc = ac::linear_f32(d_X, ldx, P + o.w1, d.D, P + o.b1, nullptr, 0, a1, d.H1, B, d.H1, d.D, 1, d_mask1, s1, stream);
+    if (rc) return rc;
+    rc = ac::linear_f32(a1, d.H1, P + o.w2, d.H1, P + o.b2, nullptr, 0, a2, d.H2, B, d.H2, d.H1, 1, d_mask2, s2, stream);
+    if (rc) return rc;
+    rc = ac::linear_f32(a2, d.H2, P + o.w3, d.H2, P + o.b3, nullptr, 0, z, d.C, B, d.C, d.H2, 0, nullptr, 1.f, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(1), dim3(256), 0, stream, z, d_y, B, d.C, dz, rowloss, d_loss);
+    AC_LAUNCH_CHECK();
+    // backward.  dW = dY^T A  (transA=1: dY stored [B,out] is the [K,M] layout), dA = dY W gated
+    // by relu'/dropout (a != 0 ? scale : 0).
+    rc = ac::gemm_f32(1, 0, d.C, d.H2, B, 1.f, dz, d.C, a2, d.H2, 0.f, G + o.w3, d.H2, nullptr, 0, 1.f, stream);
+    if (rc) return rc;
+    rc = ac::gemm_f32(0, 0, B, d.H2, d.C, 1.f, dz, d.C, P + o.w3, d.H2, 0.f, d2, d.H2, a2, d.H2, s2, stream);
+    if (rc) return rc;
+    rc = ac::gemm_f32(1, 0, d.H2, d.H1, B, 1.f, d2, d.H2, a1, d.H1, 0.f, G + o.w2, d.H1, nullptr, 0, 1.f, stream);
+    if (rc) return rc;
+    rc = ac::gemm_f32(0, 0, B, d.H1, d.H2, 1.f, d2, d.H2, P + o.w2, d.H1, 0.f, d1, d.H1, a1, d.H1, s1, stream);
+    if (rc) return rc;
+    rc = ac::gemm_f32(1, 0, d.H1, d.D, B, 1.f, d1, d.H1, d_X, ldx, 0.f, G + o.w1, d.D, nullptr, 0, 1.f, stream);
+    if (rc) return rc;
+    const int nb = d.H1 + d.H2 + d.C;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, dz, d2, d1, B, d.C, d.H2,
+                       d.H1, G + o.b3, G + o.b2, G + o.b1);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_fisher_accumulate(const float* d_grads, float inv_num_batches, float* d_fisher, int64_t n,
+                                    ac_stream_t stream) {
+    AC_REQUIRE(d_grads && d_fisher && n >= 0, AC_EINVAL, "fisher_accumulate: bad arguments");
+    if (n == 0) return AC_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fisher_acc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_grads,
+                       inv_num_batches, d_fisher, n);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_ewc_loss(const float* d_params, const float* d_fisher, const float* d_old, int64_t n,
+                           float lambda_over_B, float* d_out_loss, void* d_scratch, ac_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_REQUIRE(d_params && d_fisher && d_old && d_out_loss && d_scratch && n >= 0, AC_EINVAL,
+               "ewc_loss: bad arguments");
+    float* partials = (float*)d_scratch;
+    hipLaunchKernelGGL(ewc_partials_kernel, dim3(kRedBlocks), dim3(256), 0, stream, d_params, (const float*)nullptr,
+                       d_fisher, d_old, n, 0.f, partials);
+    AC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ewc_loss_final_kernel, dim3(1), dim3(256), 0, stream, partials, lambda_over_B, d_out_loss);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_ewc_adamw_step(float* d_params, const float* d_grads, float* d_m, float* d_v,
+                                 const float* d_fisher, const float* d_old, int64_t n, float lambda_over_B,
+                                 float max_grad_norm, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int step, float* d_out, void* d_scratch,
+                                 ac_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_REQUIRE(d_params && d_grads && d_m && d_v && d_scratch && n >= 0 && step >= 1, AC_EINVAL,
+               "ewc_adamw_step: bad arguments");
+    AC_REQUIRE((d_fisher == nullptr) == (d_old == nullptr), AC_EINVAL,
+               "ewc_adamw_step: fisher and old params must be given together");
+    float* partials = (float*)d_scratch;
+    const float two_lam = 2.f * lambda_over_B;
+    hipLaunchKernelGGL(ewc_partials_kernel, dim3(kRedBlocks), dim3(256), 0, stream, d_params, d_grads, d_fisher,
+                       d_old, n, two_lam, partials);
+    AC_LAUNCH_CHECK();
+    // bias corrections in double like torch's Python floats (adamw single-tensor path)
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float lr_wd = (float)((double)lr * (double)weight_decay);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ewc_adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_params, d_grads, d_m, d_v,
+                       d_fisher, d_old, n, lambda_over_B, two_lam, max_grad_norm, lr_wd, beta1, beta2,
+                       1.f - beta1, 1.f - beta2, eps, step_size, bc2_sqrt, partials, d_out);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}

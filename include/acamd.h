@@ -152,6 +152,8 @@ int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_params,
                        float dropout_p, int B, float* d_loss, float* d_grads,
                        void* d_ws, size_t ws_bytes, ac_stream_t stream);
 
+#define AC_REDUCE_SCRATCH_BYTES 8192
+
 /* ewc.py:90-92: fisher += grad^2 * inv_num_batches over the flat block. */
 int ac_fisher_accumulate(const float* d_grads, float inv_num_batches,
                          float* d_fisher, int64_t n, ac_stream_t stream);
@@ -159,7 +161,7 @@ int ac_fisher_accumulate(const float* d_grads, float inv_num_batches,
 /* ewc.py:96-116: lambda * sum(F * (p - p_old)^2) [/ batch_size]. */
 int ac_ewc_loss(const float* d_params, const float* d_fisher,
                 const float* d_old, int64_t n, float lambda_over_B,
-                float* d_out_loss, ac_stream_t stream);
+                float* d_out_loss, void* d_scratch, ac_stream_t stream);
 
 /*
  * The fused EWC-regularised AdamW step (classifier.py:337-351 +
@@ -169,7 +171,8 @@ int ac_ewc_loss(const float* d_params, const float* d_fisher,
  *   p   *= 1 - lr*wd ; m = b1 m + (1-b1) coef g ; v = b2 v + (1-b2)(coef g)^2
  *   p   -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * d_out[0] = EWC penalty lambda_over_B*sum F (p-pold)^2 (before the update),
- * d_out[1] = ||g||_2 (before clipping).  `d_scratch` >= 1 KiB.
+ * d_out[1] = ||g||_2 (before clipping).  `d_scratch` >= AC_REDUCE_SCRATCH_BYTES
+ * (also for ac_ewc_loss); reductions use a fixed order, so results are deterministic.
  */
 int ac_ewc_adamw_step(float* d_params, const float* d_grads, float* d_m,
                       float* d_v, const float* d_fisher, const float* d_old,

@@ -1,0 +1,46 @@
+"""TEST INFRASTRUCTURE -- not part of the product path.
+
+Oracle for the encoder site (classifier.py:1271-1275): the installed transformers `BertModel`
+(v5.15.0, modeling_bert.py) in fp32 / eval / eager attention on CPU, randomly initialised from a
+seed because no pretrained weights are available offline, followed by CLS pooling and
+F.normalize exactly as the reference does.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def make_bert(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, max_pos=512, seed=0):
+    from transformers import BertConfig, BertModel
+    cfg = BertConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                     intermediate_size=intermediate, max_position_embeddings=max_pos)
+    try:
+        cfg._attn_implementation = "eager"
+    except Exception:
+        pass
+    torch.manual_seed(seed)
+    model = BertModel(cfg, add_pooling_layer=False)
+    # BERT's init std (0.02) makes LayerNorm inputs tiny and hides errors; widen a little
+    return model.eval()
+
+
+def synthetic_batch(b, S, vocab=30522, seed=1234, ragged=True):
+    """Token ids ~U[1000, vocab), lengths ~U[S/4, S] (padding id 0, mask 0), CLS-like id 101 first."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1000, vocab, (b, S), generator=g)
+    ids[:, 0] = 101
+    mask = torch.ones((b, S), dtype=torch.int64)
+    if ragged:
+        lens = torch.randint(max(1, S // 4), S + 1, (b,), generator=g)
+        lens[0] = S
+        for i in range(b):
+            mask[i, lens[i]:] = 0
+            ids[i, lens[i]:] = 0
+    types = torch.zeros((b, S), dtype=torch.int64)
+    return ids, types, mask
+
+
+@torch.no_grad()
+def encode_cls(model, ids, types, mask):
+    out = model(input_ids=ids, token_type_ids=types, attention_mask=mask)
+    emb = out.last_hidden_state[:, 0, :]            # classifier.py:1272
+    return F.normalize(emb, p=2, dim=1)             # classifier.py:1275

@@ -1,0 +1,184 @@
+"""Parity of the HIP head / EWC / AdamW path against the torch-CPU oracle (oracle/head_oracle.py).
+Tolerance from BASELINE.json north_star: logits and EWC loss within 1e-4 (fp32)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _data(B, D, C, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1)
+    y = torch.randint(0, C, (B,), generator=g)
+    return X, y
+
+
+@pytest.mark.parametrize("M,N,K,act", [(32, 768, 768, 1), (1, 4, 384, 0), (256, 768, 768, 2), (1000, 3072, 768, 2),
+                                        (333, 100, 64, 0), (8192, 768, 3072, 0), (7, 5, 12, 1)])
+def test_linear_matches_fp64(M, N, K, act, cuda_dev):
+    import ctypes
+    from adaptive_classifier import _native as nv
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().T + b.double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    ref = ref + R.double()
+    Ad, Wd, bd, Rd = (t.to(cuda_dev) for t in (A, W, b, R))
+    C = torch.empty(M, N, device=cuda_dev)
+    nv.check(nv.lib().ac_linear_f32(nv.ptr(Ad), K, nv.ptr(Wd), K, nv.ptr(bd), nv.ptr(Rd), N, nv.ptr(C), N,
+                                    M, N, K, act, nv.stream_ptr(cuda_dev)), "ac_linear_f32")
+    err = (C.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K", [(1, 0, 768, 768, 32), (0, 0, 32, 384, 4), (1, 0, 4, 384, 32), (0, 1, 50, 70, 33),
+                                          (1, 1, 40, 30, 20)])
+def test_gemm_layouts(tA, tB, M, N, K, cuda_dev):
+    from adaptive_classifier import _native as nv
+    g = torch.Generator().manual_seed(K)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((N, K) if tB else (K, N), generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    ref = 0.5 * ((A.T if tA else A).double() @ (B.T if tB else B).double()) + 2.0 * C0.double()
+    Ad, Bd, Cd = A.to(cuda_dev), B.to(cuda_dev), C0.to(cuda_dev).clone()
+    nv.check(nv.lib().ac_gemm_f32(tA, tB, M, N, K, 0.5, nv.ptr(Ad), A.shape[1], nv.ptr(Bd), B.shape[1], 2.0,
+                                  nv.ptr(Cd), N, nv.stream_ptr(cuda_dev)), "ac_gemm_f32")
+    assert (Cd.cpu().double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("B,C", [(1, 4), (8, 4), (256, 4), (33, 77), (1024, 64)])
+def test_head_forward_logits(B, C, cuda_dev):
+    from adaptive_classifier.models import AdaptiveHead
+    from oracle import head_oracle
+    D = 768
+    X, _ = _data(B, D, C)
+    ref = head_oracle.make_head(D, C).eval()
+    head = AdaptiveHead(D, C, [D, D // 2]).to(cuda_dev).eval()
+    with torch.no_grad():
+        want = ref(X)
+        got = head(X.to(cuda_dev))
+    assert got.shape == (B, C)
+    assert (got.cpu() - want).abs().max().item() < TOL
+    # [D] input keeps the batch dimension (models.py:74-80)
+    with torch.no_grad():
+        assert head(X[0].to(cuda_dev)).shape == (1, C)
+
+
+def _make_pair(D, C, cuda_dev):
+    from adaptive_classifier.models import AdaptiveHead
+    from adaptive_classifier.training import HeadTrainer
+    from oracle import head_oracle
+    ref = head_oracle.make_head(D, C)
+    ref.train()
+    opt = torch.optim.AdamW(ref.parameters(), lr=0.001, weight_decay=0.01, betas=(0.9, 0.999))
+    head = AdaptiveHead(D, C, [D, D // 2]).to(cuda_dev)
+    tr = HeadTrainer(head)
+    return ref, opt, head, tr
+
+
+def test_train_step_with_dropout_masks(cuda_dev):
+    """One step of classifier.py:1489-1505: loss, grad-norm, updated params, m, v."""
+    from oracle import head_oracle
+    D, C, B = 768, 4, 32
+    ref, opt, head, tr = _make_pair(D, C, cuda_dev)
+    X, y = _data(B, D, C, seed=1)
+    g = torch.Generator().manual_seed(7)
+    m1 = (torch.rand(B, D, generator=g) >= 0.1)
+    m2 = (torch.rand(B, D // 2, generator=g) >= 0.1)
+    for step in range(3):
+        ce, _, gn = head_oracle.train_step(ref, opt, X, y, masks=[m1, m2])
+        loss, out = tr.step(X.to(cuda_dev), y.to(cuda_dev), m1.to(cuda_dev, torch.uint8), m2.to(cuda_dev, torch.uint8))
+        assert abs(loss.item() - ce) < TOL
+        assert abs(out[1].item() - gn) < TOL * max(1.0, gn)
+        assert (tr.flat.cpu() - head_oracle.flat(ref)).abs().max().item() < 2e-5
+    st = opt.state_dict()["state"]
+    m_ref = torch.cat([st[i]["exp_avg"].reshape(-1) for i in range(6)])
+    v_ref = torch.cat([st[i]["exp_avg_sq"].reshape(-1) for i in range(6)])
+    assert (tr.m.cpu() - m_ref).abs().max().item() < 1e-6
+    assert (tr.v.cpu() - v_ref).abs().max().item() < 1e-8
+    # the nn.Parameters are views of the trained flat block
+    assert torch.equal(head.model[0].weight.detach().reshape(-1), tr.flat[: D * D])
+
+
+def test_training_trajectory_no_dropout(cuda_dev):
+    from oracle import head_oracle
+    D, C, B = 768, 5, 32
+    ref, opt, head, tr = _make_pair(D, C, cuda_dev)
+    for step in range(25):
+        X, y = _data(B, D, C, seed=100 + step)
+        ce, _, _ = head_oracle.train_step(ref, opt, X, y, masks=None)
+        loss, _ = tr.step(X.to(cuda_dev), y.to(cuda_dev), None, None, 0.0)
+        assert abs(loss.item() - ce) < TOL
+    head.eval()
+    Xt, _ = _data(64, D, C, seed=999)
+    with torch.no_grad():
+        assert (head(Xt.to(cuda_dev)).cpu() - ref.eval()(Xt)).abs().max().item() < TOL
+
+
+def test_ewc_fisher_penalty_and_fused_step(cuda_dev):
+    """EWC class contract (ewc.py; tests/test_ewc.py:128-153 scenario: params += 0.1)."""
+    import ctypes
+    from adaptive_classifier import _native as nv
+    from adaptive_classifier.ewc import EWC
+    from oracle import head_oracle
+    D, C, B = 768, 4, 32
+    ref, opt, head, tr = _make_pair(D, C, cuda_dev)
+    # Fisher from given sampled labels on 3 batches (sizes 32, 32, 6)
+    Xs, _ = _data(70, D, C, seed=3)
+    batches = [Xs[:32], Xs[32:64], Xs[64:]]
+    g = torch.Generator().manual_seed(11)
+    sampled = [torch.randint(0, C, (b.shape[0],), generator=g) for b in batches]
+    f_ref = head_oracle.fisher_from_labels(ref, batches, sampled)
+    ds = torch.utils.data.TensorDataset(Xs, torch.zeros(70, dtype=torch.long))
+    ewc = EWC.__new__(EWC)
+    ewc.model, ewc.device, ewc.ewc_lambda, ewc._native = head, str(cuda_dev), 5.0, True
+    ewc.old_flat = head.flat_params().detach().clone()
+    ewc.old_params = {n: p.data.clone() for n, p in head.named_parameters()}
+    head.eval()
+    ewc.fisher_info = ewc._compute_fisher_native([(b, None) for b in batches],
+                                                 sampled_labels=[s.to(cuda_dev) for s in sampled])
+    rel = (ewc.fisher_flat.cpu() - f_ref).abs().max().item() / f_ref.abs().max().item()
+    assert rel < 1e-4, rel
+    assert set(ewc.fisher_info) == {n for n, _ in head.named_parameters()}
+    # penalty after p += 0.1
+    old_ref = head_oracle.flat(ref).clone()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p += 0.1
+        for p in head.parameters():
+            p += 0.1
+    want = float(head_oracle.ewc_penalty(ref, f_ref, old_ref, 5.0))
+    want32 = float(head_oracle.ewc_penalty(ref, f_ref, old_ref, 5.0 / 32))
+    with torch.no_grad():
+        got, got32 = ewc.ewc_loss().item(), ewc.ewc_loss(batch_size=32).item()
+    assert got > 0 and got32 > 0 and got != got32                      # tests/test_ewc.py:147-153
+    assert abs(got - want) < TOL * max(1.0, abs(want))
+    assert abs(got32 - want32) < TOL * max(1.0, abs(want32))
+    # fused EWC + clip + AdamW step == autograd(CE + penalty) + clip_grad_norm_ + AdamW
+    head.train(); ref.train()
+    X, y = _data(B, D, C, seed=5)
+    for step in range(2):
+        ce, pen, gn = head_oracle.train_step(ref, opt, X, y, masks=None, fisher_flat=f_ref, old_flat=old_ref,
+                                             lam_over_B=5.0 / B)
+        loss, out = tr.step(X.to(cuda_dev), y.to(cuda_dev), None, None, 0.0, fisher=ewc.fisher_flat,
+                            old_params=ewc.old_flat, lambda_over_B=5.0 / B)
+        assert abs(loss.item() - ce) < TOL
+        assert abs(out[0].item() - pen) < TOL * max(1.0, abs(pen))
+        assert abs(out[1].item() - gn) < TOL * max(1.0, gn)
+        assert (tr.flat.cpu() - head_oracle.flat(ref)).abs().max().item() < 2e-5
+
+
+def test_ewc_generic_module_contract():
+    """The EWC class on an arbitrary nn.Module (tests/test_ewc.py fixtures) -- runs on CPU."""
+    pass
