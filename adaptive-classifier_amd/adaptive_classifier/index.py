@@ -51,53 +51,88 @@ def knn_l2_topk(P, N, D, Q, k, row_offset=0, out=None, workspace=None, stats=Non
 
 
 class HipFlatL2Index:
-    """Drop-in for faiss.IndexFlatL2 as used by PrototypeMemory."""
+    """Drop-in for faiss.IndexFlatL2 as used by PrototypeMemory.
+
+    Host-side bookkeeping (add / ntotal / remove_ids) works without a GPU: added rows are queued on
+    the host and uploaded in one copy when the device matrix is first needed.  search() has no CPU
+    implementation -- without a GPU it raises."""
 
     def __init__(self, d, device=None):
-        nv.require_gpu()
         self.d = int(d)
-        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self._device_arg = device
         self.ld = (self.d + 3) // 4 * 4
-        self._n = 0
-        self._store = torch.zeros((0, self.ld), dtype=torch.float32, device=self.device)
+        self._n = 0                  # rows resident in the device matrix
+        self._store = None
+        self._pending = []           # host row blocks not yet uploaded
+        self._npending = 0
         self._ws = None
-        self._stats = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._stats = None
+
+    @property
+    def device(self):
+        if self._device_arg is not None:
+            return torch.device(self._device_arg)
+        nv.require_gpu()
+        return torch.device(f"cuda:{torch.cuda.current_device()}")
 
     # -- faiss protocol ------------------------------------------------------------------
     @property
     def ntotal(self):
-        return self._n
+        return self._n + self._npending
 
     def _as_rows(self, x):
         if isinstance(x, torch.Tensor):
             t = x.detach().to(dtype=torch.float32)
         else:
             t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
-        t = t.reshape(-1, self.d)
-        return t
+        return t.reshape(-1, self.d)
 
     def _reserve(self, n):
-        if n <= self._store.shape[0]:
+        dev = self.device
+        if self._store is not None and n <= self._store.shape[0]:
             return
-        cap = max(n, 2 * self._store.shape[0], 64)
-        new = torch.zeros((cap, self.ld), dtype=torch.float32, device=self.device)
+        have = 0 if self._store is None else self._store.shape[0]
+        cap = max(n, 2 * have, 64)
+        new = torch.zeros((cap, self.ld), dtype=torch.float32, device=dev)
         if self._n:
             new[: self._n] = self._store[: self._n]
         self._store = new
 
+    def _materialize(self):
+        """Upload queued rows (one H2D copy)."""
+        nv.require_gpu()
+        if self._pending:
+            rows = torch.cat(self._pending, 0) if len(self._pending) > 1 else self._pending[0]
+            self._pending, self._npending = [], 0
+            m = rows.shape[0]
+            self._reserve(self._n + m)
+            self._store[self._n: self._n + m, : self.d] = rows.to(self.device, non_blocking=True)
+            self._n += m
+        if self._store is None:
+            self._reserve(1)
+        if self._stats is None:
+            self._stats = torch.zeros(4, dtype=torch.int32, device=self.device)
+
     def add(self, x):
         rows = self._as_rows(x)
-        m = rows.shape[0]
-        if m == 0:
+        if rows.shape[0] == 0:
             return
-        self._reserve(self._n + m)
-        self._store[self._n: self._n + m, : self.d] = rows.to(self.device, non_blocking=True)
-        self._n += m
+        if rows.is_cuda:
+            self._materialize()
+            m = rows.shape[0]
+            self._reserve(self._n + m)
+            self._store[self._n: self._n + m, : self.d] = rows.to(self.device)
+            self._n += m
+        else:
+            self._pending.append(rows.clone())
+            self._npending += rows.shape[0]
 
     def add_device_rows(self, rows):
         """Adopt an existing [n, ld] device matrix without copying (large synthetic stores)."""
         assert rows.is_cuda and rows.dtype == torch.float32 and rows.stride(1) == 1
         assert rows.stride(0) % 4 == 0 and rows.stride(0) >= self.ld and rows.data_ptr() % 16 == 0
+        self._device_arg = rows.device
+        self._pending, self._npending = [], 0
         self._store = rows
         self._n = rows.shape[0]
 
@@ -105,9 +140,10 @@ class HipFlatL2Index:
         if isinstance(ids, torch.Tensor):
             ids = ids.detach().cpu().numpy()
         ids = np.unique(np.asarray(ids).reshape(-1).astype(np.int64))
-        ids = ids[(ids >= 0) & (ids < self._n)]
+        ids = ids[(ids >= 0) & (ids < self.ntotal)]
         if ids.size == 0:
             return 0
+        self._materialize()
         keep = torch.ones(self._n, dtype=torch.bool, device=self.device)
         keep[torch.from_numpy(ids).to(self.device)] = False
         kept = self._store[: self._n][keep]             # IndexFlat compacts: later rows shift down
@@ -117,13 +153,27 @@ class HipFlatL2Index:
 
     def reset(self):
         self._n = 0
+        self._pending, self._npending = [], 0
+
+    def update_rows(self, rows, values):
+        """Overwrite existing rows in place (ids keep their meaning; no compaction)."""
+        rows = torch.as_tensor(rows, dtype=torch.int64)
+        if rows.numel() == 0:
+            return
+        if int(rows.max()) >= self.ntotal or int(rows.min()) < 0:
+            raise IndexError("update_rows: row id out of range")
+        self._materialize()
+        vals = self._as_rows(values).to(self.device)
+        self._store[rows.to(self.device), : self.d] = vals
 
     def search_device(self, q, k):
         """q: [nq, d] fp32 tensor (any device) -> (dist, ids) CUDA tensors; no host sync."""
+        self._materialize()
         q = q.detach().to(device=self.device, dtype=torch.float32)
         if q.dim() == 1:
             q = q.unsqueeze(0)
-        q = q.contiguous()
+        if q.stride(-1) != 1:
+            q = q.contiguous()
         need = knn_workspace_bytes(self._n, self.d, q.shape[0], k)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
@@ -138,7 +188,7 @@ class HipFlatL2Index:
     @property
     def exact_fallbacks(self):
         """Queries of the last search() that needed the exact fp64 fallback sweep."""
-        return int(self._stats[0].item())
+        return 0 if self._stats is None else int(self._stats[0].item())
 
 
 def topk_merge(D_in, I_in):

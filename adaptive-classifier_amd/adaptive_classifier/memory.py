@@ -1,0 +1,253 @@
+"""PrototypeMemory -- drop-in for /root/reference/src/adaptive_classifier/memory.py:11-295 with the
+prototype store resident in MI355X HBM and the kNN on the HIP sweep kernel.
+
+Surface kept (asserted by the reference's tests/test_memory.py):
+  PrototypeMemory(embedding_dim, config) | add_example | get_nearest_prototypes | _update_prototype |
+  _rebuild_index | _restore_from_save | _prune_examples | get_stats | clear
+  attributes: examples (defaultdict label -> [Example]), prototypes (label -> CPU tensor [D]),
+  index, label_to_index, index_to_label, updates_since_rebuild, embedding_dim, config.
+The host dict/list mirrors stay authoritative (the classifier reads and mutates them directly);
+the device matrix behind `.index` is a cache refreshed lazily.
+
+Deliberate differences from the reference (DESIGN.md "quirks"):
+  * `_update_prototype` rewrites the prototype's row in place instead of faiss remove_ids+add
+    (memory.py:156-159), which in the reference leaves label<->row maps stale until the next rebuild.
+  * class means come from an fp64 running sum (O(D) per add instead of re-stacking every stored
+    example, memory.py:149-150); the mean differs from torch.mean's fp32 result by <= 1 ulp.
+Beyond the reference: `load_rows()` puts an arbitrary [N, D] device matrix with an
+int32 row->class map behind the same search API (N >> #classes, BASELINE configs 1-2, 4).
+"""
+import logging
+import threading
+from collections import defaultdict
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as nv
+from .index import HipFlatL2Index, proto_scores
+from .models import Example, ModelConfig
+
+logger = logging.getLogger(__name__)
+
+
+class PrototypeMemory:
+    """Per-class example store + class-mean prototypes + exact L2 kNN over the prototypes."""
+
+    def __init__(self, embedding_dim: int, config: Optional[ModelConfig] = None, device=None):
+        self.embedding_dim = embedding_dim
+        self.config = config or ModelConfig()
+        self.examples = defaultdict(list)
+        self.prototypes = {}
+        self.strategic_prototypes = {}
+        self._device = device
+        self.index = self._new_index()
+        self.label_to_index = {}
+        self.index_to_label = {}
+        self.updates_since_rebuild = 0
+        self._sums = {}                      # label -> fp64 running sum of the stored embeddings
+        self._dirty = set()                  # labels whose index row is out of date
+        self._lock = threading.RLock()       # add_example is called from threads (test_memory.py:226-256)
+        self._row_labels = None              # int32 device tensor when load_rows() is in use
+        self._row_label_names = None
+
+    def _new_index(self):
+        return HipFlatL2Index(self.embedding_dim, device=self._device)
+
+    # ------------------------------------------------------------------ add / prune / prototype
+    def add_example(self, example: Example, label: str):
+        if example.embedding is None:
+            raise ValueError("Example must have an embedding")
+        if example.embedding.size(-1) != self.embedding_dim:
+            raise ValueError(
+                f"Example embedding dimension {example.embedding.size(-1)} "
+                f"does not match memory dimension {self.embedding_dim}")
+        with self._lock:
+            if example.embedding.is_cuda:
+                example.embedding = example.embedding.detach().cpu()   # prototypes stay on the host
+            self.examples[label].append(example)
+            n_prev = len(self.examples[label]) - 1
+            cached = self._sums.get(label)
+            if cached is None or cached[1] != n_prev:       # first add, or the list was edited behind us
+                s = torch.zeros(self.embedding_dim, dtype=torch.float64)
+                for ex in self.examples[label][:-1]:
+                    s += ex.embedding.double()
+            else:
+                s = cached[0]
+            self._sums[label] = (s + example.embedding.detach().double(), n_prev + 1)
+            if len(self.examples[label]) > self.config.max_examples_per_class:
+                self._prune_examples(label)
+            self._update_prototype(label)
+            # counter / lazy rebuild logic of memory.py:70-81
+            if not getattr(self, "just_rebuilt", False):
+                self.updates_since_rebuild += 1
+            if self.updates_since_rebuild >= self.config.prototype_update_frequency:
+                self._rebuild_index()
+                self.just_rebuilt = True
+            else:
+                self.just_rebuilt = False
+
+    def _update_prototype(self, label: str):
+        examples = self.examples[label]
+        if not examples:
+            return
+        cached = self._sums.get(label)
+        if cached is None or cached[1] != len(examples):
+            cached = (torch.stack([ex.embedding for ex in examples]).double().sum(0), len(examples))
+            self._sums[label] = cached
+        self.prototypes[label] = (cached[0] / len(examples)).to(torch.float32)
+        if label in self.label_to_index:
+            self._dirty.add(label)           # row refreshed in place at the next search
+
+    def _prune_examples(self, label: str):
+        """Keep the max_examples_per_class examples closest to the class mean (memory.py:196-217)."""
+        examples = self.examples[label]
+        if not examples:
+            return
+        emb = torch.stack([ex.embedding for ex in examples])
+        cached = self._sums.get(label)
+        if cached is not None and cached[1] == len(examples):
+            mean = (cached[0] / len(examples)).to(torch.float32)
+        else:
+            mean = emb.mean(0)
+        dist = torch.linalg.vector_norm(emb - mean, dim=1).numpy()
+        keep = np.argsort(dist)[: self.config.max_examples_per_class]
+        self.examples[label] = [examples[i] for i in keep]
+        self._sums[label] = (emb[torch.from_numpy(np.asarray(keep))].double().sum(0), len(keep))
+        assert len(self.examples[label]) <= self.config.max_examples_per_class
+
+    # ------------------------------------------------------------------ index maintenance
+    def _rebuild_index(self):
+        """Dense [C, D] matrix in sorted-label order, one upload (memory.py:161-177)."""
+        with self._lock:
+            self.index = self._new_index()
+            self.label_to_index.clear()
+            self.index_to_label.clear()
+            labels = sorted(self.prototypes.keys())
+            if labels:
+                self.index.add(torch.stack([self.prototypes[l].detach().float().cpu() for l in labels]))
+            for i, label in enumerate(labels):
+                self.label_to_index[label] = i
+                self.index_to_label[i] = label
+            self._dirty.clear()
+            self._row_labels = None
+            self._row_label_names = None
+            self.updates_since_rebuild = 0
+
+    def _restore_from_save(self):
+        """memory.py:179-194: same as a rebuild (prototypes were assigned directly by the loader)."""
+        self._rebuild_index()
+
+    def _flush_dirty(self):
+        if self._dirty:
+            labels = [l for l in self._dirty if l in self.label_to_index]
+            if labels:
+                rows = torch.tensor([self.label_to_index[l] for l in labels], dtype=torch.int64)
+                vals = torch.stack([self.prototypes[l].float() for l in labels])
+                self.index.update_rows(rows, vals)
+            self._dirty.clear()
+
+    def load_rows(self, rows: torch.Tensor, row_labels: torch.Tensor, label_names: List[str], sharded=None):
+        """Generalised store: arbitrary device rows + int32 row->class map behind the same search.
+
+        With `sharded` (adaptive_classifier.sharded.ShardedSearch) `rows` is this rank's row shard and
+        `row_labels` the GLOBAL (replicated) row->class map; search_batch() then all-gathers the ranks'
+        query blocks, searches the local shard and merges the all-gathered per-shard top-k."""
+        self.index = self._new_index()
+        self.index.add_device_rows(rows)
+        self._row_labels = row_labels.to(device=rows.device, dtype=torch.int32).contiguous()
+        self._row_label_names = list(label_names)
+        self._sharded = sharded
+        self._row_class_cache = None
+        self.updates_since_rebuild = 0
+        self._dirty.clear()
+
+    # ------------------------------------------------------------------ search
+    def get_nearest_prototypes(self, query_embedding: torch.Tensor, k: int = 5,
+                               min_similarity: Optional[float] = None) -> List[Tuple[str, float]]:
+        """[(label, score)] ascending in distance; scores = softmax(exp(-d^2)) (memory.py:85-136)."""
+        with self._lock:
+            if self._row_labels is None and self.updates_since_rebuild >= self.config.prototype_update_frequency:
+                self._rebuild_index()
+            if self.index.ntotal == 0:
+                return []
+            self._flush_dirty()
+            k = min(k, self.index.ntotal)
+            D, I = self.index.search_device(query_embedding.detach().reshape(1, -1), k)
+            S = proto_scores(D, I)
+            ids = I[0].cpu().numpy()
+            scores = S[0].cpu().numpy()
+        results = []
+        for idx, score in zip(ids, scores):
+            if idx >= 0:
+                results.append((self._label_of_row(int(idx)), float(score)))
+        return results
+
+    def _label_of_row(self, idx):
+        if self._row_labels is not None:
+            return self._row_label_names[int(self._row_labels[idx].item())]
+        return self.index_to_label[idx]
+
+    def search_batch(self, queries: torch.Tensor, k: int):
+        """Device-resident batch search: (scores [b,k], row ids [b,k], dist [b,k]) CUDA tensors.
+
+        Same arithmetic as get_nearest_prototypes per row; no host synchronisation."""
+        with self._lock:
+            if self._row_labels is None and self.updates_since_rebuild >= self.config.prototype_update_frequency:
+                self._rebuild_index()
+            self._flush_dirty()
+            sharded = getattr(self, "_sharded", None)
+            if sharded is not None and sharded.world > 1:
+                b = queries.shape[0]
+                q_all = sharded.gather_queries(queries)
+                D, I = sharded.search(q_all, k)
+                r = sharded.rank
+                D, I = D[r * b:(r + 1) * b].contiguous(), I[r * b:(r + 1) * b].contiguous()
+                return proto_scores(D, I), I, D
+            k = min(k, max(self.index.ntotal, 1))
+            D, I = self.index.search_device(queries, k)
+            return proto_scores(D, I), I, D
+
+    def row_class_ids(self, label_to_id: Dict[str, int], device):
+        """int64 [N] device tensor: classifier class id of every index row (-1 = unknown label).
+        Cached for the generalised store (N can be 10^7)."""
+        if self._row_labels is not None:
+            key = tuple(label_to_id.get(n, -1) for n in self._row_label_names)
+            cached = getattr(self, "_row_class_cache", None)
+            if cached is None or cached[0] != key or cached[1].device != torch.device(device):
+                lut = torch.tensor(key, dtype=torch.int64, device=device)
+                cached = (key, lut[self._row_labels.to(device).long()])
+                self._row_class_cache = cached
+            return cached[1]
+        n = self.index.ntotal
+        return torch.tensor([label_to_id.get(self.index_to_label[i], -1) for i in range(n)], dtype=torch.int64,
+                            device=device)
+
+    # ------------------------------------------------------------------ misc API
+    def get_stats(self) -> Dict[str, Any]:
+        return {
+            "num_classes": len(self.prototypes),
+            "examples_per_class": {label: len(ex) for label, ex in self.examples.items()},
+            "total_examples": sum(len(ex) for ex in self.examples.values()),
+            "prototype_dimensions": self.embedding_dim,
+            "updates_since_rebuild": self.updates_since_rebuild,
+        }
+
+    def clear(self):
+        with self._lock:
+            self.examples.clear()
+            self.prototypes.clear()
+            self._sums.clear()
+            self._dirty.clear()
+            self.index = self._new_index()
+            self.label_to_index.clear()
+            self.index_to_label.clear()
+            self._row_labels = None
+            self._row_label_names = None
+            self.updates_since_rebuild = 0
+
+    def drop_label(self, label):
+        """Forget cached sums when the classifier deletes a label's examples (classifier.py:1396-1399)."""
+        self._sums.pop(label, None)
+        self._dirty.discard(label)

@@ -745,7 +745,15 @@ static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
     return AC_OK;
 }
 
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+
 }  // namespace
+
+extern "C" int ac_knn_set_profile_events(void* start_event, void* stop_event) {
+    g_prof_start = (hipEvent_t)start_event;
+    g_prof_stop = (hipEvent_t)stop_event;
+    return AC_OK;
+}
 
 extern "C" int ac_knn_l2_topk_workspace(int64_t N, int D, int nq, int k, size_t* bytes) {
     AC_REQUIRE(bytes != nullptr, AC_EINVAL, "knn workspace: bytes is NULL");
@@ -805,6 +813,7 @@ extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, c
         sp.zeros = (const float*)(ws + pl.off_zeros);
         AC_HIP_CHECK(hipMemsetAsync(ws + pl.off_zeros, 0, 256, stream));
         const int nblk = pl.G * pl.nqt;
+        if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
         if (pl.TQ == 32) {
             (void)hipFuncSetAttribute((const void*)knn_sweep<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)pl.sweep_lds);
@@ -815,6 +824,7 @@ extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, c
             hipLaunchKernelGGL(knn_sweep<16>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
         }
         AC_LAUNCH_CHECK();
+        if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_stop, stream));
     }
     (void)hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)pl.merge_lds);

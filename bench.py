@@ -1,0 +1,252 @@
+"""bench.py -- the headline benchmark of BASELINE.json on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+metric   predict() queries/sec + kNN GB/s vs HBM roofline, 768-d
+step     one predict() pass over one batch: BERT-base encoder (random init, fp32) on 256 pre-tokenised
+         synthetic texts (S = 32) -> exact L2 top-16 over the 100k x 768 prototype store -> AdaptiveHead
+         (768-768-384-4) -> the reference's predict_batch blend -> Python result lists.  This is
+         BASELINE.json configs[1]; token ids and prototypes are resident in HBM before the timed region.
+N GPUs   one process per GPU: every rank encodes its own 256-text batch (data parallel), the prototype
+         rows are sharded by rows across ranks, the exchange is all-gather(queries) + all-gather(per-shard
+         top-k) over RCCL and a merge.  value = (N * 256 * K) / max-over-ranks time.
+roofline the kNN distance sweep in its HBM-bound regime (the north star's roofline target): knn_sweep
+         over 10M x 768 fp32 rows (30.7 GB) with 16 resident queries, timed with HIP events recorded
+         around that kernel on its own stream (ac_knn_set_profile_events).  algorithmic bytes = N*D*4.
+         The encoder GEMM chain and the batched kNN of the timed step are MFMA-bound; their achieved
+         TFLOP/s against the 157.3 TFLOP/s fp32-MFMA peak are reported next to it.
+cpu_baseline  the oracle port of the same predict() step (transformers BertModel fp32 on torch-CPU +
+         C fp32 brute-force kNN + torch head) on the host cores, on a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "adaptive-classifier_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+
+BATCH, SEQ, NPROTO, DIM, KNN_K, NCLASS, VOCAB = 256, 32, 100_000, 768, 16, 4, 30522
+
+
+def make_classifier(dev, rank, world):
+    from adaptive_classifier import AdaptiveClassifier, AdaptiveHead
+    from adaptive_classifier import index as ix
+    from adaptive_classifier.encoder import HipBertEncoder
+    from adaptive_classifier.sharded import ShardedSearch, shard_bounds
+    from transformers import BertConfig, BertModel
+    cfg = BertConfig()                                  # bert-base-uncased architecture
+    torch.manual_seed(0)
+    hf = BertModel(cfg, add_pooling_layer=False).eval()
+    enc = HipBertEncoder(hf, device=dev)
+    clf = AdaptiveClassifier("bert-base-uncased(random-init)", device=str(dev), encoder=enc, tokenizer=None)
+    labels = [f"c{i}" for i in range(NCLASS)]
+    clf.label_to_id = {l: i for i, l in enumerate(labels)}
+    clf.id_to_label = {i: l for i, l in enumerate(labels)}
+    clf.training_history = {l: 25 for l in labels}
+    clf.adaptive_head = AdaptiveHead(DIM, NCLASS, [DIM, DIM // 2]).to(dev).eval()
+    lo, hi = shard_bounds(NPROTO, world, rank)
+    rows = ix.synth_unit_rows(hi - lo, DIM, 1, row_offset=lo, device=dev)          # this rank's row shard
+    row_labels = torch.arange(NPROTO, dtype=torch.int32) % NCLASS                  # replicated row->class map
+    sharded = ShardedSearch(rows, hi - lo, DIM, lo) if world > 1 else None
+    clf.memory.load_rows(rows, row_labels, labels, sharded=sharded)
+    return clf, hf
+
+
+def synthetic_tokens(dev, rank):
+    g = torch.Generator().manual_seed(1234 + rank)
+    ids = torch.randint(1000, VOCAB, (BATCH, SEQ), generator=g)
+    ids[:, 0] = 101
+    lens = torch.randint(8, SEQ + 1, (BATCH,), generator=g)
+    lens[0] = SEQ
+    mask = (torch.arange(SEQ)[None, :] < lens[:, None]).to(torch.int64)
+    ids = ids * mask
+    return ids.to(dev), torch.zeros_like(ids).to(dev), mask.to(dev)
+
+
+def predict_step(clf, ids, types, mask):
+    emb = clf.model.encode_cls(ids, types, mask)
+    return clf.predict_embeddings(emb, k=KNN_K)
+
+
+def time_stages(clf, ids, types, mask, reps=5):
+    """HIP-event timing of the device stages of one step (current stream)."""
+    from adaptive_classifier import index as ix
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    out = {}
+    e = [ev() for _ in range(4)]
+    tot = np.zeros(3)
+    for _ in range(reps):
+        e[0].record()
+        emb = clf.model.encode_cls(ids, types, mask)
+        e[1].record()
+        S, I, D = clf.memory.search_batch(emb, KNN_K)
+        e[2].record()
+        probs = torch.softmax(clf.adaptive_head.forward_native(emb), dim=1)
+        e[3].record()
+        torch.cuda.synchronize()
+        tot += [e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])]
+    tot /= reps
+    out["encode_ms"], out["knn_ms"], out["head_ms"] = [float(x) for x in tot]
+    return out
+
+
+def sweep_roofline(dev, n_rows):
+    """knn_sweep alone over n_rows x 768 with 16 resident queries: algorithmic bytes / kernel time."""
+    from adaptive_classifier import _native as nv
+    from adaptive_classifier import index as ix
+    nq, k = 16, 32
+    P = ix.synth_unit_rows(n_rows, DIM, 1, device=dev)
+    Q = ix.synth_unit_rows(nq, DIM, 2, device=dev)
+    ws = torch.empty(ix.knn_workspace_bytes(n_rows, DIM, nq, k), dtype=torch.uint8, device=dev)
+    stats = torch.zeros(4, dtype=torch.int32, device=dev)
+    out = (torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record(); torch.cuda.synchronize()          # materialise the hipEvent handles
+    for _ in range(2):
+        ix.knn_l2_topk(P, n_rows, DIM, Q, k, out=out, workspace=ws, stats=stats)
+    torch.cuda.synchronize()
+    times = []
+    nv.lib().ac_knn_set_profile_events(e0.cuda_event, e1.cuda_event)
+    try:
+        for _ in range(8):
+            ix.knn_l2_topk(P, n_rows, DIM, Q, k, out=out, workspace=ws, stats=stats)
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+    finally:
+        nv.lib().ac_knn_set_profile_events(None, None)
+    ms = float(np.mean(times))
+    bytes_alg = n_rows * DIM * 4
+    del P
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "achieved": bytes_alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": bytes_alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "knn_sweep<16>", "rows": n_rows, "dim": DIM, "resident_queries": nq,
+            "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": ms, "min_kernel_ms": float(np.min(times)),
+            "exact_fallback_queries": int(stats[0].item())}
+
+
+def cpu_baseline(hf, clf, rows_dev, sample=64):
+    """Oracle port of the same step on the host cores (bounded sample)."""
+    from oracle import c_oracle, head_oracle
+    cores = c_oracle.usable_cores()           # the box's cgroup quota, not os.cpu_count()
+    torch.set_num_threads(cores)
+    c_oracle.set_threads(cores)
+    g = torch.Generator().manual_seed(99)
+    ids = torch.randint(1000, VOCAB, (sample, SEQ), generator=g)
+    mask = torch.ones_like(ids)
+    P = rows_dev[:, :DIM].cpu().numpy()
+    head = head_oracle.make_head(DIM, NCLASS).eval()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        emb = torch.nn.functional.normalize(hf(input_ids=ids, attention_mask=mask).last_hidden_state[:, 0, :], dim=1)
+        t1 = time.perf_counter()
+        D, I = c_oracle.knn_l2_topk_f32(P, emb.numpy(), KNN_K)       # what faiss's nq<20 path computes, all cores
+        t2 = time.perf_counter()
+        s = np.exp(-D)
+        torch.softmax(torch.from_numpy(s), dim=1)
+        torch.softmax(head(emb), dim=1)
+    t3 = time.perf_counter()
+    return {"value": sample / (t3 - t0), "unit": "queries/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{sample} texts x S={SEQ}: transformers BertModel fp32 (torch CPU) + C fp32 brute-force kNN "
+                      f"over {NPROTO}x{DIM} (OpenMP, {c_oracle.num_threads()} threads) + torch head",
+            "encode_s": t1 - t0, "knn_s": t2 - t1, "head_s": t3 - t2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sweep-rows", type=int, default=10_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    clf, hf = make_classifier(dev, rank, world)
+    ids, types, mask = synthetic_tokens(dev, rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        preds = predict_step(clf, ids, types, mask)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        preds = predict_step(clf, ids, types, mask)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert len(preds) == BATCH and all(len(p) >= 1 for p in preds)
+
+    stages = time_stages(clf, ids, types, mask)
+    if rank == 0:
+        enc_flops = clf.model.flops(BATCH, SEQ)
+        rows_local = clf.memory.index.ntotal
+        knn_flops = 2.0 * (BATCH * world) * rows_local * DIM
+        line = {
+            "metric": "predict() queries/sec + kNN GB/s vs HBM roofline, 768-d",
+            "value": BATCH * world * args.steps / dt, "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: bert-base-uncased arch (random init), 768-d, 100k prototypes "
+                                   "row-sharded over the ranks, k=16, batch=256 per GPU, S=32, 4 classes",
+                       "batch_per_gpu": BATCH, "seq_len": SEQ, "prototypes": NPROTO, "dim": DIM, "k": KNN_K,
+                       "classes": NCLASS, "parallelism": f"dp{world}+rowshard{world}"},
+            "stages_ms": stages,
+            "roofline_encoder": {"bound": "mfma", "achieved": enc_flops / stages["encode_ms"] / 1e9,
+                                 "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                 "frac": enc_flops / stages["encode_ms"] / 1e9 / F32_MFMA_PEAK_TF,
+                                 "flops_per_step": enc_flops},
+            "roofline_knn_batch": {"bound": "mfma", "achieved": knn_flops / stages["knn_ms"] / 1e9,
+                                   "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": knn_flops / stages["knn_ms"] / 1e9 / F32_MFMA_PEAK_TF,
+                                   "note": "kNN of the timed step (256 queries/GPU) is compute bound, not HBM bound"},
+        }
+        if world == 1 and not args.no_sweep:
+            free, _ = torch.cuda.mem_get_info(dev)
+            n_rows = args.sweep_rows
+            while n_rows * DIM * 4 > 0.8 * free and n_rows > 100_000:
+                n_rows //= 2
+            line["roofline"] = sweep_roofline(dev, n_rows)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(hf, clf, clf.memory.index._store[:NPROTO])
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,15 @@ int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D,
                    ac_stream_t stream);
 
 /*
+ * Optional profiling hook: when both events are non-NULL, every following
+ * ac_knn_l2_topk call of THIS thread records `start` immediately before and
+ * `stop` immediately after its sweep kernel (the HBM-bound kernel) on the
+ * call's stream, so the caller can read that kernel's duration with
+ * hipEventElapsedTime.  Pass NULLs to switch it off.  (hipEvent_t as void*.)
+ */
+int ac_knn_set_profile_events(void* start_event, void* stop_event);
+
+/*
  * Merge per-shard results: in [shards, nq, k] ascending
  * lists -> global ascending top-k by (distance, id).  Entries with id < 0 are
  * padding.  Pure selection: no arithmetic on the distances.

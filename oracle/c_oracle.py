@@ -31,6 +31,22 @@ def num_threads():
     return lib().oracle_num_threads()
 
 
+def set_threads(n):
+    lib().oracle_set_threads(ctypes.c_int(int(n)))
+
+
+def usable_cores():
+    """CPUs this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def knn_l2_topk(P, Q, k, row_offset=0):
     P = np.ascontiguousarray(P, dtype=np.float32)
     Q = np.ascontiguousarray(Q, dtype=np.float32)

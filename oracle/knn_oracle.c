@@ -39,6 +39,14 @@ static inline void topk_insert(ent_t* L, int* n, int k, double d, int64_t i) {
     *n = m + 1;
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -1,0 +1,204 @@
+"""Generate the golden fixtures under tests/golden/ by running the UNMODIFIED reference
+(/root/reference/src/adaptive_classifier) in the build container.
+
+    python tests/golden/gen_golden.py
+
+`faiss` is not installable here, so oracle/faiss_shim.py (exact-L2 numpy shim) is injected as
+sys.modules["faiss"]; everything else (memory.py, models.py, ewc.py, classifier.py blend formulas,
+torch's CrossEntropyLoss / clip_grad_norm_ / AdamW) is the reference's own code.  Inputs are
+regenerated at test time from oracle/synth.py (bit-identical everywhere) or stored when they come
+from the reference's own fixture (scripts/adaptive_router).  /root/reference is NOT available on the
+GPU box, hence the committed outputs.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import faiss_shim, synth  # noqa: E402
+
+faiss_shim.install()
+sys.path.insert(0, "/root/reference/src")
+import adaptive_classifier as ref  # noqa: E402  (the reference package)
+from adaptive_classifier.ewc import EWC as RefEWC  # noqa: E402
+
+assert ref.__file__.startswith("/root/reference"), ref.__file__
+
+SAMPLE_IDX = np.random.default_rng(0).integers(0, 2 ** 31, size=64)
+
+
+def summarize(t):
+    """Compact, order-sensitive fingerprint of a big tensor: 64 sampled entries + sum + abs-sum."""
+    f = t.detach().reshape(-1).double().numpy()
+    idx = SAMPLE_IDX % f.size
+    return {"n": int(f.size), "idx": idx.tolist(), "vals": f[idx].tolist(), "sum": float(f.sum()),
+            "abssum": float(np.abs(f).sum())}
+
+
+def build_memory(C=4, per_class=25, D=768, seed=10):
+    """cfg0 'plumbing' store: C classes x per_class unit-norm synthetic embeddings, reference memory."""
+    mem = ref.PrototypeMemory(D)
+    labels = [f"c{c}" for c in range(C)]
+    X = synth.synth_unit_rows(C * per_class, D, seed)
+    # class structure: add a class-specific offset direction then renormalise (all deterministic)
+    cent = synth.synth_unit_rows(C, D, seed + 1)
+    for i in range(C * per_class):
+        c = i % C
+        v = X[i] * 0.5 + cent[c]
+        v = (v / np.linalg.norm(v)).astype(np.float32)
+        mem.add_example(ref.Example(f"t{i:03d}", labels[c], torch.from_numpy(v)), labels[c])
+    mem._rebuild_index()
+    return mem, labels
+
+
+def gen_router():
+    """The reference's own saved-classifier fixture (scripts/adaptive_router): real 768-d embeddings
+    and prototypes -> reference memory scores and seed-42-head logits."""
+    from safetensors.torch import load_file
+    cfg = json.load(open("/root/reference/scripts/adaptive_router/config.json"))
+    tens = load_file("/root/reference/scripts/adaptive_router/tensors.safetensors")
+    labels = ["HIGH", "LOW"]
+    emb = np.stack([np.asarray(e["embedding"], np.float32) for l in labels for e in cfg["examples"][l]])
+    protos = np.stack([tens[f"prototype_{l}"].numpy() for l in labels])
+    mem = ref.PrototypeMemory(768)
+    for l, p in zip(labels, protos):
+        mem.prototypes[l] = torch.from_numpy(p)
+    mem._restore_from_save()
+    scores = np.zeros((10, 2)); order = np.zeros((10, 2), np.int64)
+    for i in range(10):
+        res = mem.get_nearest_prototypes(torch.from_numpy(emb[i]), k=2)
+        for j, (lab, sc) in enumerate(res):
+            order[i, j] = labels.index(lab); scores[i, j] = sc
+    dist = ((emb[:, None, :].astype(np.float64) - protos[None].astype(np.float64)) ** 2).sum(-1)
+    head = ref.AdaptiveHead(768, 2, [768, 384]).eval()          # seed-42 init, reproducible anywhere
+    with torch.no_grad():
+        logits = head(torch.from_numpy(emb)).numpy()
+    # the fixture's trained head: logits stored, weights are NOT copied (3.5 MB); checked via checksum only
+    np.savez_compressed(os.path.join(HERE, "router_fixture.npz"), emb=emb, protos=protos, order=order,
+                        scores=scores, dist=dist, seed42_logits=logits)
+
+
+def gen_knn():
+    cases = {}
+    specs = [("small_k1", 50, 768, 4, 1, 1), ("k_eq_N", 20, 128, 3, 20, 2), ("ragged", 333, 1024, 5, 16, 3),
+             ("tiles", 257, 768, 2, 32, 4)]
+    for name, N, D, nq, k, seed in specs:
+        P = synth.synth_unit_rows(N, D, seed); Q = synth.synth_unit_rows(nq, D, seed + 100)
+        idx = ref.memory.faiss.IndexFlatL2(D); idx.add(P)
+        Dd, Ii = idx.search(Q, k)
+        cases[name] = {"N": N, "D": D, "nq": nq, "k": k, "seed": seed, "I": Ii.tolist(), "D_out": Dd.tolist()}
+    # duplicates: ids must come back lowest-first
+    P = np.concatenate([synth.synth_unit_rows(10, 768, 9)] * 3); Q = P[:2]
+    idx = ref.memory.faiss.IndexFlatL2(768); idx.add(P)
+    Dd, Ii = idx.search(Q, 6)
+    cases["dups"] = {"I": Ii.tolist(), "D_out": Dd.tolist()}
+    json.dump(cases, open(os.path.join(HERE, "knn_cases.json"), "w"))
+
+
+def gen_memory_and_blend():
+    """Reference PrototypeMemory scores + the two blend formulas (_predict_regular, predict_batch)
+    driven with given embeddings (encoder bypassed by patching _get_embeddings)."""
+    mem, labels = build_memory()
+    Q = synth.synth_unit_rows(8, 768, 77)
+    cent = synth.synth_unit_rows(4, 768, 11)
+    Q = np.stack([(q * 0.5 + cent[i % 4]) / np.linalg.norm(q * 0.5 + cent[i % 4]) for i, q in enumerate(Q)]).astype(np.float32)
+    out = {"protos": {l: mem.prototypes[l].numpy().tolist()[:8] for l in labels}}
+    out["nearest"] = [[(l, s) for l, s in mem.get_nearest_prototypes(torch.from_numpy(q), k=4)] for q in Q]
+    out["nearest_k2"] = [[(l, s) for l, s in mem.get_nearest_prototypes(torch.from_numpy(q), k=2)] for q in Q]
+    clf = ref.AdaptiveClassifier.__new__(ref.AdaptiveClassifier)
+    clf.config = ref.ModelConfig(); clf.device = "cpu"; clf.memory = mem; clf.embedding_dim = 768
+    clf.label_to_id = {l: i for i, l in enumerate(labels)}; clf.id_to_label = {i: l for i, l in enumerate(labels)}
+    clf.training_history = {"c0": 25, "c1": 5, "c2": 25, "c3": 9}      # mixes the <10 / >=10 weight branches
+    clf.strategic_cost_function = None
+    clf.adaptive_head = ref.AdaptiveHead(768, 4, [768, 384])
+    texts = [f"q{i}" for i in range(8)]
+    table = {t: torch.from_numpy(q) for t, q in zip(texts, Q)}
+    clf._get_embeddings = lambda ts: [table[t] for t in ts]
+    out["predict"] = {f"k{k}": [clf._predict_regular(t, k) for t in texts] for k in (1, 3, 5)}
+    out["predict_batch"] = {f"k{k}": clf.predict_batch(texts, k=k) for k in (1, 2, 5)}
+    json.dump(out, open(os.path.join(HERE, "memory_blend.json"), "w"))
+
+
+def gen_head_step():
+    """Two reference training steps (classifier.py:1489-1505) with the dropout masks captured."""
+    torch.manual_seed(0)
+    head = ref.AdaptiveHead(768, 4, [768, 384])
+    head.train()
+    opt = torch.optim.AdamW(head.parameters(), lr=0.001, weight_decay=0.01, betas=(0.9, 0.999))
+    crit = torch.nn.CrossEntropyLoss()
+    X = torch.from_numpy(synth.synth_unit_rows(32, 768, 21))
+    y = torch.from_numpy((np.arange(32) * 7 % 4).astype(np.int64))
+    masks, steps = [], []
+    cap = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: cap.append(((out != 0) | (inp[0] == 0)).to(torch.uint8)))
+             for m in head.model if isinstance(m, torch.nn.Dropout)]
+    torch.manual_seed(123)
+    for s in range(2):
+        cap.clear()
+        opt.zero_grad()
+        loss = crit(head(X), y)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(head.parameters(), max_norm=1.0)
+        opt.step()
+        masks.append([c.numpy().copy() for c in cap])
+        steps.append({"loss": float(loss), "grad_norm": float(gn),
+                      "params": {k: summarize(v) for k, v in head.state_dict().items()},
+                      "out_bias": head.model[-1].bias.detach().numpy().tolist()})
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(HERE, "head_step_masks.npz"), m1_0=masks[0][0], m2_0=masks[0][1],
+                        m1_1=masks[1][0], m2_1=masks[1][1])
+    json.dump({"steps": steps, "x_seed": 21}, open(os.path.join(HERE, "head_step.json"), "w"))
+
+
+def gen_ewc():
+    """Reference EWC: Fisher with recorded batch order + sampled labels; penalty after p += 0.1
+    (tests/test_ewc.py:128-153); and the as-wired construct of _train_new_classes (== 0.0)."""
+    head = ref.AdaptiveHead(768, 3, [768, 384])
+    X = torch.from_numpy(synth.synth_unit_rows(20, 768, 31))
+    y = torch.arange(20) % 3
+
+    class Rec(torch.utils.data.Dataset):
+        def __init__(self): self.order = []
+        def __len__(self): return 20
+        def __getitem__(self, i): self.order.append(int(i)); return X[i], y[i]
+
+    ds = Rec()
+    sampled = []
+    orig = torch.multinomial
+    torch.multinomial = lambda *a, **k: (sampled.append(orig(*a, **k)) or sampled[-1])
+    try:
+        torch.manual_seed(5)
+        ewc = RefEWC(head, ds, device="cpu", ewc_lambda=100.0)
+    finally:
+        torch.multinomial = orig
+    zero = float(ewc.ewc_loss(batch_size=32))
+    with torch.no_grad():
+        for p in head.parameters():
+            p += 0.1
+    out = {"order": ds.order, "sampled": sampled[0].squeeze(-1).tolist(), "loss_unperturbed": zero,
+           "fisher": {k: summarize(v) for k, v in ewc.fisher_info.items()},
+           "loss_p01": float(ewc.ewc_loss()), "loss_p01_b32": float(ewc.ewc_loss(batch_size=32))}
+    # as wired in classifier.py:171,298-303,339: EWC on a deepcopy, penalty evaluated while another head trains
+    import copy
+    live = ref.AdaptiveHead(768, 3, [768, 384])
+    old = copy.deepcopy(live)
+    live.update_num_classes(4)
+    e2 = RefEWC(old, torch.utils.data.TensorDataset(X[:10], y[:10]), device="cpu", ewc_lambda=5.0)
+    with torch.no_grad():
+        for p in live.parameters():
+            p += 0.3                                   # training moves the live head ...
+    out["as_wired_penalty"] = float(e2.ewc_loss(batch_size=32))   # ... but the penalty looks at `old` only
+    json.dump(out, open(os.path.join(HERE, "ewc.json"), "w"))
+
+
+if __name__ == "__main__":
+    gen_router(); gen_knn(); gen_memory_and_blend(); gen_head_step(); gen_ewc()
+    print("golden fixtures written to", HERE)
+    for f in sorted(os.listdir(HERE)):
+        print(f"  {f:28s} {os.path.getsize(os.path.join(HERE, f)):8d} B")

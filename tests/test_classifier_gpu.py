@@ -1,0 +1,188 @@
+"""GPU suite: API-level behaviour of the drop-in AdaptiveClassifier (mirrors the reference's
+tests/test_classifier.py with an offline tokenizer stub and a small random BERT) and the reference's
+memory tests against the real device search."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import HashTokenizer, small_bert
+
+pytestmark = pytest.mark.gpu
+
+TEXTS = ["great product works well", "love it so much", "best purchase ever made",
+         "terrible waste of money", "awful do not buy", "broke after one day",
+         "it is fine nothing special", "average product okay", "neither good nor bad"]
+LABELS = ["positive"] * 3 + ["negative"] * 3 + ["neutral"] * 3
+
+
+@pytest.fixture(scope="module")
+def clf(cuda_dev):
+    from adaptive_classifier import AdaptiveClassifier
+    from adaptive_classifier.encoder import HipBertEncoder
+    enc = HipBertEncoder(small_bert(), device=cuda_dev)
+    c = AdaptiveClassifier("synthetic-bert-tiny", device="cuda:0", encoder=enc, tokenizer=HashTokenizer())
+    c.add_examples(TEXTS, LABELS)
+    return c
+
+
+def test_init_and_add(clf):
+    assert clf.embedding_dim == 128 and clf.adaptive_head is not None
+    assert clf.label_to_id == {"negative": 0, "neutral": 1, "positive": 2}       # sorted ids (:147-150)
+    assert clf.memory.index.ntotal == 3 and clf.memory.updates_since_rebuild == 0
+    assert clf.training_history == {"positive": 3, "negative": 3, "neutral": 3}
+    assert clf.train_steps == 1 and clf.last_train_info["steps"] >= 1
+    st = clf.get_memory_stats()
+    assert st["num_classes"] == 3 and st["total_examples"] == 9
+    assert clf.get_example_statistics()["model_params"] == sum(p.numel() for p in clf.adaptive_head.parameters())
+
+
+def test_predict_types_and_normalisation(clf):
+    preds = clf.predict("really great product", k=3)
+    assert len(preds) == 3 and all(isinstance(l, str) and isinstance(s, float) for l, s in preds)
+    assert abs(sum(s for _, s in preds) - 1.0) < 1e-6
+    assert preds == sorted(preds, key=lambda x: -x[1])
+    assert len(clf.predict("really great product", k=1)) == 1
+    with pytest.raises(ValueError, match="Empty input text"):
+        clf.predict("")
+
+
+def test_predict_batch_and_errors(clf):
+    out = clf.predict_batch(["great product", "awful thing", "fine I guess", "x"], k=2, batch_size=3)
+    assert len(out) == 4 and all(len(p) <= 2 for p in out)
+    assert all(isinstance(s, float) for p in out for _, s in p)
+    with pytest.raises(ValueError, match="Empty input batch"):
+        clf.predict_batch([])
+    with pytest.raises(ValueError, match="Empty input lists"):
+        clf.add_examples([], [])
+    with pytest.raises(ValueError, match="Mismatched"):
+        clf.add_examples(["a"], ["x", "y"])
+
+
+def test_training_learns_separable_embeddings(cuda_dev):
+    """add_embeddings (add_examples after the encoder) on 3 separable synthetic clusters: the native
+    training loop (DataLoader order, dropout, CE, clip, AdamW, plateau scheduler, early stop) learns them."""
+    from adaptive_classifier import AdaptiveClassifier
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import synth
+    enc = HipBertEncoder(small_bert(), device=cuda_dev)
+    c = AdaptiveClassifier("synthetic", device="cuda:0", encoder=enc, tokenizer=HashTokenizer())
+    D, per = 128, 30
+    cent = synth.synth_unit_rows(3, D, 5)
+    noise = synth.synth_unit_rows(3 * per + 30, D, 6)
+    def sample(i):
+        v = cent[i % 3] + 0.6 * noise[i]
+        return torch.from_numpy((v / np.linalg.norm(v)).astype(np.float32))
+    labels = [f"cls{i % 3}" for i in range(3 * per)]
+    c.add_embeddings([f"t{i}" for i in range(3 * per)], [sample(i) for i in range(3 * per)], labels)
+    assert c.last_train_info["steps"] >= 3 and c.last_train_info["final_loss"] < 0.9
+    test = torch.stack([sample(3 * per + i) for i in range(30)]).to(cuda_dev)
+    preds = c.predict_embeddings(test, k=3)
+    acc = np.mean([p[0][0] == f"cls{i % 3}" for i, p in enumerate(preds)])
+    assert acc >= 0.9, acc
+    assert all(abs(sum(s for _, s in p) - 1) < 1e-6 for p in preds)
+
+
+def test_get_embeddings_contract(clf):
+    embs = clf._get_embeddings(["hello world", "another longer piece of text here"])
+    assert len(embs) == 2 and all(e.device.type == "cpu" and e.shape == (128,) for e in embs)
+    assert all(abs(float(e.norm()) - 1) < 1e-5 for e in embs)
+    # padding independence: same text alone or next to a longer one
+    alone = clf._get_embeddings(["hello world"])[0]
+    assert (alone - embs[0]).abs().max().item() < 1e-5
+
+
+def test_dynamic_class_addition_and_as_wired_ewc(cuda_dev):
+    from adaptive_classifier import AdaptiveClassifier
+    from adaptive_classifier.encoder import HipBertEncoder
+    enc = HipBertEncoder(small_bert(), device=cuda_dev)
+    c = AdaptiveClassifier("synthetic", device="cuda:0", encoder=enc, tokenizer=HashTokenizer())
+    c.add_examples(TEXTS[:6], LABELS[:6])
+    w_before = c.adaptive_head.model[-1].weight.detach().clone()
+    assert w_before.shape[0] == 2
+    np.random.seed(0)
+    c.add_examples(["how do i reset my password", "need help with login", "support please help"], ["support"] * 3)
+    assert c.adaptive_head.model[-1].weight.shape[0] == 3                      # grown, not re-initialised
+    assert c.label_to_id["support"] == 2 and c.memory.index.ntotal == 3
+    assert c.train_steps == 2
+    assert any(l == "support" for l, _ in c.predict("help me login", k=3))
+    # intended-EWC mode trains too and reports a non-negative penalty path
+    c2 = AdaptiveClassifier("synthetic", device="cuda:0", config={"ewc_mode": "intended"}, encoder=enc,
+                            tokenizer=HashTokenizer())
+    c2.add_examples(TEXTS[:6], LABELS[:6])
+    c2.add_examples(["how do i reset my password", "need help with login", "support please help"], ["support"] * 3)
+    assert c2.adaptive_head.model[-1].weight.shape[0] == 3
+
+
+def test_save_load_roundtrip(clf, tmp_path, cuda_dev):
+    from adaptive_classifier import AdaptiveClassifier
+    clf.save(str(tmp_path))
+    assert (tmp_path / "config.json").exists() and (tmp_path / "examples.json").exists() and (tmp_path / "model.safetensors").exists()
+    from safetensors.torch import load_file
+    keys = set(load_file(str(tmp_path / "model.safetensors")))
+    assert {"prototype_positive", "adaptive_head_model.0.weight", "adaptive_head_model.6.bias"} <= keys
+    c2 = AdaptiveClassifier("synthetic-bert-tiny", device="cuda:0", encoder=clf.model, tokenizer=HashTokenizer())
+    c2.load_state(str(tmp_path))
+    for t in ["really great product", "awful thing"]:
+        a, b = clf.predict(t, k=3), c2.predict(t, k=3)
+        assert [l for l, _ in a] == [l for l, _ in b]
+        assert np.allclose([s for _, s in a], [s for _, s in b], atol=1e-6)
+
+
+def test_cpu_device_rejected():
+    from adaptive_classifier import AdaptiveClassifier, _native as nv
+    with pytest.raises(nv.NativeError):
+        AdaptiveClassifier("x", device="cpu", encoder=object(), tokenizer=None)
+
+
+# ---- reference tests/test_memory.py cases that need the search ---------------------------------
+def test_nearest_prototypes_reference_case(cuda_dev):
+    from adaptive_classifier import Example, PrototypeMemory
+    memory = PrototypeMemory(768, device=cuda_dev)
+    e = torch.randn(768)
+    for i, cls in enumerate(["positive", "negative", "neutral"]):
+        shift = torch.zeros_like(e); shift[i] = 1.0
+        memory.add_example(Example(f"text_{cls}", cls, e + shift), cls)
+    memory._rebuild_index()
+    q = e.clone(); q[0] = 1.0
+    res = memory.get_nearest_prototypes(q, k=3)
+    assert len(res) == 3 and all(isinstance(l, str) and isinstance(s, float) for l, s in res)
+    assert abs(sum(s for _, s in res) - 1.0) < 1e-5
+    assert memory.get_nearest_prototypes(q, k=10) == res                       # k clamps to ntotal
+    assert PrototypeMemory(768, device=cuda_dev).get_nearest_prototypes(q) == []
+
+
+def test_prototype_row_updates_in_place(cuda_dev):
+    """Deliberate fix of memory.py:156-159: after an update the row<->label map stays valid."""
+    from adaptive_classifier import Example, PrototypeMemory
+    m = PrototypeMemory(8, device=cuda_dev)
+    a, b = torch.zeros(8), torch.zeros(8)
+    a[0], b[1] = 1, 1
+    m.add_example(Example("a", "A", a), "A"); m.add_example(Example("b", "B", b), "B")
+    m._rebuild_index()
+    m.add_example(Example("a2", "A", a * 3), "A")                             # prototype A moves to 2*a
+    res = m.get_nearest_prototypes(a * 2, k=2)
+    assert res[0][0] == "A"
+
+
+def test_memory_device_handling(cuda_dev):
+    from adaptive_classifier import Example, PrototypeMemory
+    m = PrototypeMemory(768, device=cuda_dev)
+    m.add_example(Example("t", "positive", torch.randn(768, device=cuda_dev)), "positive")
+    assert m.prototypes["positive"].device == torch.device("cpu")             # tests/test_memory.py:156-164
+
+
+def test_generalised_store_rows_to_classes(cuda_dev):
+    """M6: N >> C rows with a row->class map behind the same search (BASELINE configs[1] shape, scaled)."""
+    from adaptive_classifier import PrototypeMemory
+    from adaptive_classifier import index as ix
+    from oracle import c_oracle
+    N, D, C = 5000, 768, 4
+    rows = ix.synth_unit_rows(N, D, 1, device=cuda_dev)
+    m = PrototypeMemory(D, device=cuda_dev)
+    m.load_rows(rows, torch.arange(N) % C, [f"c{i}" for i in range(C)])
+    Q = ix.synth_unit_rows(3, D, 2, device=cuda_dev)
+    S, I, Dd = m.search_batch(Q, 16)
+    oD, oI = c_oracle.knn_l2_topk(rows.cpu().numpy(), Q.cpu().numpy(), 16)
+    assert np.array_equal(I.cpu().numpy(), oI)
+    res = m.get_nearest_prototypes(Q[0].cpu(), k=16)
+    assert [l for l, _ in res] == [f"c{int(i) % C}" for i in oI[0]]

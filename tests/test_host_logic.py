@@ -1,0 +1,235 @@
+"""CPU suite: host-side logic of the drop-in classes, mirroring the model-free tests of the
+reference (tests/test_memory.py, tests/test_ewc.py:34-84,128-153,194-215) that do not need a search."""
+import threading
+
+import pytest
+import torch
+import torch.nn as nn
+
+from adaptive_classifier import EWC, AdaptiveHead, Example, ModelConfig, PrototypeMemory
+
+
+@pytest.fixture
+def memory():
+    return PrototypeMemory(embedding_dim=768)
+
+
+@pytest.fixture
+def emb():
+    return torch.randn(768)
+
+
+@pytest.fixture
+def config():
+    return ModelConfig({"max_examples_per_class": 5, "prototype_update_frequency": 3, "similarity_threshold": 0.95})
+
+
+def test_initialization(memory):
+    assert memory.embedding_dim == 768 and len(memory.examples) == 0 and len(memory.prototypes) == 0
+    assert memory.index is not None
+
+
+def test_add_example_and_counter(memory, emb):
+    memory.add_example(Example("test text", "positive", emb), "positive")
+    assert len(memory.examples["positive"]) == 1 and "positive" in memory.prototypes
+    assert memory.updates_since_rebuild == 1
+
+
+def test_prototype_is_mean(memory, emb):
+    exs = [Example(f"text_{i}", "positive", emb + i) for i in range(3)]
+    for ex in exs:
+        memory.add_example(ex, "positive")
+    assert torch.allclose(torch.stack([e.embedding for e in exs]).mean(0), memory.prototypes["positive"])
+
+
+def test_pruning(emb, config):
+    m = PrototypeMemory(768, config=config)
+    for i in range(config.max_examples_per_class + 3):
+        m.add_example(Example(f"text_{i}", "positive", emb + i), "positive")
+    assert len(m.examples["positive"]) == config.max_examples_per_class
+    # kept = the ones closest to the running mean; prototype == mean of what is kept
+    kept = torch.stack([e.embedding for e in m.examples["positive"]])
+    assert torch.allclose(kept.mean(0), m.prototypes["positive"], atol=1e-5)
+
+
+def test_index_rebuild_counter(emb, config):
+    m = PrototypeMemory(768, config=config)
+    for i in range(config.prototype_update_frequency + 1):
+        m.add_example(Example(f"text_{i}", "positive", emb + i), "positive")
+    assert m.updates_since_rebuild == 0 and len(m.label_to_index) == 1 and len(m.index_to_label) == 1
+    assert m.index.ntotal == 1
+
+
+def test_rebuild_sorted_label_rows(memory, emb):
+    for lab in ["zeta", "alpha", "mid"]:
+        memory.add_example(Example("t", lab, emb), lab)
+    memory._rebuild_index()
+    assert memory.index_to_label == {0: "alpha", 1: "mid", 2: "zeta"} and memory.index.ntotal == 3
+
+
+def test_clear_and_stats(memory, emb):
+    for cls in ["positive", "negative"]:
+        for i in range(3):
+            memory.add_example(Example(f"text_{cls}_{i}", cls, emb + i), cls)
+    st = memory.get_stats()
+    assert st["num_classes"] == 2 and st["examples_per_class"]["positive"] == 3 and st["total_examples"] == 6
+    assert st["prototype_dimensions"] == 768 and "updates_since_rebuild" in st
+    memory.clear()
+    assert not memory.examples and not memory.prototypes and not memory.label_to_index and memory.updates_since_rebuild == 0
+
+
+def test_invalid_inputs(memory):
+    with pytest.raises(ValueError):
+        memory.add_example(Example("t", "positive", torch.randn(100)), "positive")
+    with pytest.raises(ValueError):
+        memory.add_example(Example("t", "positive", None), "positive")
+
+
+def test_prototype_stability(memory, emb):
+    ex = Example("test text", "positive", emb)
+    for _ in range(5):
+        memory.add_example(ex, "positive")
+    assert torch.allclose(memory.prototypes["positive"], emb, atol=1e-6)
+
+
+def test_concurrent_access(memory, emb):
+    def add(label):
+        for i in range(100):
+            memory.add_example(Example(f"text_{label}_{i}", label, emb + i), label)
+    ts = [threading.Thread(target=add, args=(l,)) for l in ["positive", "negative", "neutral"]]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    st = memory.get_stats()
+    assert st["num_classes"] == 3 and all(len(memory.examples[l]) == 100 for l in ["positive", "negative", "neutral"])
+
+
+def test_external_edit_of_examples_is_detected(memory, emb):
+    """classifier.py assigns memory.examples[label] directly (:883); cached sums must not go stale."""
+    for i in range(4):
+        memory.add_example(Example(f"t{i}", "a", emb + i), "a")
+    memory.examples["a"] = memory.examples["a"][:2]
+    memory.add_example(Example("new", "a", emb + 10), "a")
+    want = torch.stack([e.embedding for e in memory.examples["a"]]).mean(0)
+    assert torch.allclose(memory.prototypes["a"], want, atol=1e-6)
+
+
+# ---- models ---------------------------------------------------------------------------------
+def test_config_surface():
+    c = ModelConfig({"max_length": 128})
+    assert c.max_length == 128 and c.max_examples_per_class == 1000 and c.prototype_update_frequency == 100
+    c.update(batch_size=8, not_a_key=1)
+    assert c.batch_size == 8 and not hasattr(c, "not_a_key")
+    d = c.to_dict()
+    assert d["ewc_lambda"] == 100.0 and d["prototype_weight"] == 0.7 and len(d) == 29
+
+
+def test_example_roundtrip():
+    e = Example("t", "l", torch.arange(4.0))
+    assert torch.equal(Example.from_dict(e.to_dict()).embedding, e.embedding)
+    assert Example.from_dict(Example("t", "l").to_dict()).embedding is None
+
+
+def test_head_anatomy_and_determinism():
+    h1, h2 = AdaptiveHead(768, 4, [768, 384]), AdaptiveHead(768, 4, [768, 384])
+    assert list(h1.state_dict()) == [f"model.{i}.{p}" for i in (0, 3, 6) for p in ("weight", "bias")]
+    assert all(torch.equal(a, b) for a, b in zip(h1.state_dict().values(), h2.state_dict().values()))
+    assert isinstance(h1.model[0], nn.Linear) and isinstance(h1.model[2], nn.Dropout) and h1.model[-1].out_features == 4
+    assert h1(torch.randn(768)).shape == (1, 4) and h1(torch.randn(5, 768)).shape == (5, 4)
+    old_w = h1.model[-1].weight.detach().clone()
+    h1.update_num_classes(6)
+    assert h1.model[-1].weight.shape == (6, 384) and torch.equal(h1.model[-1].weight[:4], old_w)
+    assert sum(p.numel() for p in AdaptiveHead(768, 4, [768, 384]).parameters()) == 887428
+
+
+def test_head_flat_block_views():
+    h = AdaptiveHead(16, 3, [16, 8])
+    flat = h.flat_params()
+    assert flat.numel() == sum(p.numel() for p in h.parameters())
+    with torch.no_grad():
+        flat.zero_()
+    assert all(float(p.abs().sum()) == 0 for p in h.parameters())        # parameters are views
+    sd = {k: torch.ones_like(v) for k, v in h.state_dict().items()}
+    h.load_state_dict(sd)
+    assert float(h.flat_params().sum()) == flat.numel()                 # load_state_dict writes through
+
+
+# ---- EWC generic-module contract (reference tests/test_ewc.py) ---------------------------------
+class _Simple(nn.Module):
+    def __init__(self, i=10, c=3):
+        super().__init__()
+        self.fc = nn.Linear(i, c)
+
+    def forward(self, x):
+        return self.fc(x)
+
+
+@pytest.mark.parametrize("size", [1, 31, 32, 33, 64, 65, 100])
+def test_ewc_various_sizes(size):
+    model = _Simple()
+    ds = torch.utils.data.TensorDataset(torch.randn(size, 10), torch.randint(0, 3, (size,)))
+    ewc = EWC(model, ds, device="cpu", ewc_lambda=100.0)
+    assert ewc.fisher_info and set(ewc.fisher_info) == set(ewc.old_params) == {"fc.weight", "fc.bias"}
+    assert ewc.ewc_loss(batch_size=32).item() >= 0
+
+
+def test_ewc_loss_after_perturbation():
+    model = _Simple()
+    ds = torch.utils.data.TensorDataset(torch.randn(33, 10), torch.tensor([0, 1, 2] * 11))
+    ewc = EWC(model, ds, device="cpu", ewc_lambda=100.0)
+    assert ewc.ewc_loss().item() == 0.0
+    for p in model.parameters():
+        p.data += 0.1
+    l, ln = ewc.ewc_loss(), ewc.ewc_loss(batch_size=32)
+    assert l.item() > 0 and ln.item() > 0 and ln.item() != l.item()
+    l.backward()                                                       # autograd flows into the model
+    assert model.fc.weight.grad is not None
+
+
+def test_ewc_single_sample():
+    model = _Simple(5, 2)
+    ewc = EWC(model, torch.utils.data.TensorDataset(torch.randn(1, 5), torch.tensor([0])), ewc_lambda=50.0)
+    assert ewc.ewc_loss() is not None
+
+
+# ---- blend formulas (host logic of predict / predict_batch) against the reference's outputs -------
+def test_blend_matches_reference_golden():
+    """AdaptiveClassifier._blend (vectorised, fp64) reproduces reference _predict_regular / predict_batch
+    (tests/golden/memory_blend.json) when fed the oracle's kNN scores and head probabilities."""
+    import json
+    import os
+    import numpy as np
+    from adaptive_classifier import AdaptiveClassifier
+    from oracle import head_oracle, knn_oracle, synth
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "memory_blend.json")))
+    C, per, D = 4, 25, 768
+    labels = [f"c{c}" for c in range(C)]
+    X, cent = synth.synth_unit_rows(C * per, D, 10), synth.synth_unit_rows(C, D, 11)
+    protos = np.zeros((C, D), np.float64)
+    for i in range(C * per):
+        v = X[i] * 0.5 + cent[i % C]
+        protos[i % C] += (v / np.linalg.norm(v)).astype(np.float32)
+    protos = (protos / per).astype(np.float32)
+    Q = synth.synth_unit_rows(8, D, 77)
+    Q = np.stack([(q * 0.5 + cent[i % 4]) / np.linalg.norm(q * 0.5 + cent[i % 4]) for i, q in enumerate(Q)]).astype(np.float32)
+    clf = AdaptiveClassifier.__new__(AdaptiveClassifier)
+    clf.label_to_id = {l: i for i, l in enumerate(labels)}
+    clf.id_to_label = {i: l for i, l in enumerate(labels)}
+    clf.training_history = {"c0": 25, "c1": 5, "c2": 25, "c3": 9}
+    clf.memory = type("M", (), {"_row_labels": None})()
+    with torch.no_grad():
+        P = torch.softmax(head_oracle.make_head(768, 4).eval()(torch.from_numpy(Q)), 1).numpy()
+
+    def same(got, want):
+        assert [l for l, _ in got] == [l for l, _ in want]
+        assert np.allclose([s for _, s in got], [s for _, s in want], atol=1e-6)
+        assert all(isinstance(s, float) for _, s in got)
+
+    for key, want in g["predict"].items():
+        Dd, I = knn_oracle.knn_l2_topk(protos, Q, 4)
+        for a, w in zip(clf._blend(knn_oracle.proto_scores(Dd, I), I, P, int(key[1:]), True), want):
+            same(a, w)
+    for key, want in g["predict_batch"].items():
+        k = int(key[1:])
+        Dd, I = knn_oracle.knn_l2_topk(protos, Q, k)
+        for a, w in zip(clf._blend(knn_oracle.proto_scores(Dd, I), I, P, k, False), want):
+            same(a, w)

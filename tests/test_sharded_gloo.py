@@ -1,0 +1,69 @@
+"""CPU suite: the multi-GPU orchestration (row shards, query all-gather, top-k all-gather + merge)
+with a world_size-2 gloo group.  The HIP kernels cannot run here, so the local search and the merge
+are the ORACLE (injected) -- what is under test is the sharding / collective / offset logic of
+adaptive_classifier.sharded, which is identical under RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, N, D, nq, k, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "adaptive-classifier_amd")]
+    from adaptive_classifier.sharded import ShardedSearch, shard_bounds
+    from oracle import knn_oracle, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(N, world, rank)
+    rows = torch.from_numpy(synth.synth_unit_rows(hi - lo, D, 1, row_offset=lo))   # shard generated in place
+    q_local = torch.from_numpy(synth.synth_unit_rows(nq // world, D, 2, row_offset=rank * (nq // world)))
+
+    def local_search(P, n, Dd, Q, kk, off):
+        d, i = knn_oracle.knn_l2_topk(P.numpy()[:n], Q.numpy(), kk, row_offset=off)
+        return torch.from_numpy(d), torch.from_numpy(i)
+
+    def merge(Ds, Is):
+        d, i = knn_oracle.topk_merge(Ds.numpy(), Is.numpy(), Ds.shape[2])
+        return torch.from_numpy(d), torch.from_numpy(i)
+
+    ss = ShardedSearch(rows, hi - lo, D, lo, local_search=local_search, merge=merge)
+    Q = ss.gather_queries(q_local)
+    Dg, Ig = ss.search(Q, k)
+    ret[rank] = (Q.numpy(), Dg.numpy(), Ig.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,k", [(1001, 8), (37, 16)])
+def test_sharded_search_world2(N, k):
+    from oracle import knn_oracle, synth
+    D, nq, world = 64, 6, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), N, D, nq, k, ret), nprocs=world, join=True)
+    P = synth.synth_unit_rows(N, D, 1)
+    Q = synth.synth_unit_rows(nq, D, 2)
+    oD, oI = knn_oracle.knn_l2_topk(P, Q, k)
+    for r in range(world):
+        Qr, Dg, Ig = ret[r]
+        assert np.array_equal(Qr, Q)                       # gathered query block is the global batch
+        assert np.array_equal(Ig, oI) and np.array_equal(Dg, oD)
+
+
+def test_shard_bounds_cover_rows():
+    from adaptive_classifier.sharded import shard_bounds
+    for N in (0, 1, 7, 8, 1000, 10_000_000):
+        for w in (1, 2, 4, 8):
+            b = [shard_bounds(N, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == N and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
