@@ -127,10 +127,19 @@ def sweep_roofline(dev, n_rows):
         nv.lib().ac_knn_set_profile_events(None, None)
     ms = float(np.mean(times))
     bytes_alg = n_rows * DIM * 4
+    # HBM traffic per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 gfx950 correction,
+    # profiles/<round>/knn_sweep_pmc.json); null when no pass exists for this problem size.
+    traffic, traffic_src = None, None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "knn_sweep_pmc.json"))):
+        pj = json.load(open(f))
+        if pj.get("rows") == n_rows and pj.get("dim") == DIM:
+            traffic = pj["hbm_read_bytes_per_launch_corrected"] + pj["hbm_write_bytes_per_launch"]
+            traffic_src = os.path.relpath(f, ROOT)
     del P
     torch.cuda.empty_cache()
     return {"bound": "hbm", "achieved": bytes_alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": bytes_alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+            "frac": bytes_alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "knn_sweep<16>", "rows": n_rows, "dim": DIM, "resident_queries": nq,
             "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": ms, "min_kernel_ms": float(np.min(times)),
             "exact_fallback_queries": int(stats[0].item())}
