@@ -28,6 +28,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -38,7 +39,7 @@ constexpr int kWaves = 8;               // waves per sweep block (2 per SIMD)
 constexpr int kThreads = kWaves * 64;
 constexpr int kGroup = 8;               // float4 loads in flight per lane per buffer
 constexpr int kPad = 8;                 // extra candidates kept beyond k
-constexpr int kMergeMaxCand = 16384;    // G * k' limit (merge kernel keeps them in LDS)
+constexpr int kMergeMaxCand = 32768;    // G * k' limit (merge kernel keeps 32-bit keys in LDS)
 constexpr int kLdsLimit = 160 * 1024;
 
 template <int TQ> struct Shape;
@@ -387,6 +388,38 @@ struct MergeParams {
 
 constexpr int kMergeThreads = 256;
 
+// Block-wide radix select (8 bits per round) over 32-bit keys held in LDS: returns the `want`-th
+// smallest (1-based) among the entries with active(t) != 0.  On return *rank_in_ties is how many of
+// the entries equal to the result are needed to reach `want`, *n_ties how many such entries exist.
+template <typename KeyFn, typename ActiveFn>
+__device__ __forceinline__ uint32_t block_radix_select(int n, int want, KeyFn key_of, ActiveFn active,
+                                                       int* hist, int* bcast, int* rank_in_ties, int* n_ties) {
+    const int tid = threadIdx.x;
+    uint32_t prefix = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;                       // kMergeThreads == 256 bins
+        __syncthreads();
+        const uint32_t himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+        for (int t = tid; t < n; t += kMergeThreads) {
+            if (!active(t)) continue;
+            const uint32_t key = key_of(t);
+            if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        int c = 0;                            // exclusive prefix of bin `tid`
+        for (int bb = 0; bb < tid; ++bb) c += hist[bb];
+        const int mine = hist[tid];
+        if (c < want && want <= c + mine) { bcast[0] = tid; bcast[1] = want - c; bcast[2] = mine; }
+        __syncthreads();
+        prefix |= (uint32_t)bcast[0] << shift;
+        want = bcast[1];
+        *n_ties = bcast[2];
+        __syncthreads();
+    }
+    *rank_in_ties = want;
+    return prefix;
+}
+
 __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int q = blockIdx.x;
@@ -396,78 +429,66 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
     const int n = prm.G * prm.kp;
     const int kp = prm.kp;
 
-    // LDS: keys[n] u64 | qrow[Dp] f32 | sel_key[kp] u64 | exact[kp] f64 | misc
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-    size_t off = ac::align_up((size_t)n * 8, 16);
+    // LDS: keys[n] u32 | qrow[Dp] f32 | sel[kp] u64 | exact[kp] f64 | hist[256] | misc
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
+    size_t off = ac::align_up((size_t)n * 4, 16);
     float* qrow = reinterpret_cast<float*>(smem + off);
     off += ac::align_up((size_t)prm.Dp * 4, 16);
     unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem + off);
     off += (size_t)kp * 8;
     double* exact = reinterpret_cast<double*>(smem + off);
     off += (size_t)kp * 8;
-    int* misc = reinterpret_cast<int*>(smem + off);   // [0] count, [1] nsel, [2] nreal
-    double* dmisc = reinterpret_cast<double*>(misc + 4);  // [0] qnorm2, [1] exact k-th
+    int* hist = reinterpret_cast<int*>(smem + off);
+    off += 256 * 4;
+    int* misc = reinterpret_cast<int*>(smem + off);       // [0..2] radix broadcast, [4] nsel counter, [5] nreal
+    double* dmisc = reinterpret_cast<double*>(misc + 8);  // [0] qnorm2, [1] exact k-th
 
-    // composite key = fkey(d) << 32 | (uint32) id ; padding (id < 0) sorts last
+    // monotone 32-bit key of the sweep value; padding (id < 0) sorts last
     const float* pd = prm.part_d + (size_t)q * n;
     const int32_t* pi = prm.part_i + (size_t)q * n;
     int nreal_local = 0;
     for (int t = tid; t < n; t += kMergeThreads) {
-        const int32_t id = pi[t];
-        unsigned long long key = ~0ull;
-        if (id >= 0) {
-            key = ((unsigned long long)fkey(pd[t]) << 32) | (uint32_t)id;
-            ++nreal_local;
-        }
-        keys[t] = key;
+        const bool real = pi[t] >= 0;
+        keys[t] = real ? fkey(pd[t]) : 0xffffffffu;
+        nreal_local += real ? 1 : 0;
     }
     for (int c = tid; c < prm.Dp; c += kMergeThreads)
         qrow[c] = c < prm.D ? prm.Q[(size_t)q * prm.ldQ + c] : 0.f;
-    if (tid < 4) misc[tid] = 0;
+    if (tid < 8) misc[tid] = 0;
     __syncthreads();
-    atomicAdd(&misc[2], nreal_local);
+    atomicAdd(&misc[5], nreal_local);
     __syncthreads();
-    const int nreal = misc[2];
+    const int nreal = misc[5];
     const int nsel = nreal < kp ? nreal : kp;     // how many candidates we re-rank
 
-    // ---- MSB-first binary radix select of the nsel-th smallest composite key ----
-    unsigned long long prefix = 0, T64 = ~0ull;
+    // ---- the nsel-th smallest sweep value T; ties at T are resolved by the lowest ids ----
+    uint32_t T = 0xffffffffu;
+    int32_t tie_id_max = 0x7fffffff;
     if (nsel > 0) {
-        int want = nsel;   // rank (1-based) still to locate inside the current prefix class
-        for (int bit = 63; bit >= 0; --bit) {
-            const unsigned long long himask = (bit == 63) ? 0ull : (~0ull << (bit + 1));
-            int c0 = 0;
-            for (int t = tid; t < n; t += kMergeThreads) {
-                const unsigned long long key = keys[t];
-                c0 += ((key & himask) == prefix && !((key >> bit) & 1ull)) ? 1 : 0;
-            }
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) c0 += __shfl_xor(c0, o);
-            if (lane == 0 && c0) atomicAdd(&misc[0], c0);
-            __syncthreads();
-            const int tot0 = misc[0];
-            __syncthreads();
-            if (tid == 0) misc[0] = 0;
-            if (tot0 >= want) {
-                // the wanted key has this bit = 0
-            } else {
-                want -= tot0;
-                prefix |= (1ull << bit);
-            }
-            __syncthreads();
+        int r = 0, c_eq = 0;
+        T = block_radix_select(n, nsel, [&](int t) { return keys[t]; },
+                               [&](int t) { return keys[t] != 0xffffffffu; }, hist, misc, &r, &c_eq);
+        if (c_eq != r) {     // rare: several candidates share the boundary value -> r lowest ids of them
+            int r2 = 0, c2 = 0;
+            tie_id_max = (int32_t)block_radix_select(
+                n, r, [&](int t) { return (uint32_t)pi[t]; },
+                [&](int t) { return pi[t] >= 0 && keys[t] == T; }, hist, misc, &r2, &c2);
         }
-        T64 = prefix;
     }
-    // ---- compact the selected candidates (key <= T64) ----
+    // ---- compact the selected candidates ----
     for (int t = tid; t < n; t += kMergeThreads) {
-        const unsigned long long key = keys[t];
-        if (nsel > 0 && key <= T64 && key != ~0ull) {
-            const int s = atomicAdd(&misc[1], 1);
-            if (s < kp) sel[s] = key;
+        const int32_t id = pi[t];
+        if (nsel > 0 && id >= 0) {
+            const uint32_t key = keys[t];
+            if (key < T || (key == T && id <= tie_id_max)) {
+                const int s = atomicAdd(&misc[4], 1);
+                if (s < kp) sel[s] = ((unsigned long long)key << 32) | (uint32_t)id;
+            }
         }
     }
     __syncthreads();
-    const int ns = misc[1] < kp ? misc[1] : kp;    // == nsel (composite keys of real rows are unique)
+    const int ns = misc[4] < kp ? misc[4] : kp;
+    const unsigned long long T64 = (unsigned long long)T << 32;
 
     // ---- exact fp64 distances of the selected rows; |q|^2 ----
     const int nc4 = prm.Dp >> 2;
@@ -721,11 +742,23 @@ static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
     const int rows_per_tile = kWaves * TQ;
     pl->ntiles = (N + rows_per_tile - 1) / rows_per_tile;
     const ac::DevInfo& di = ac::dev_info();
-    int per_cu = (int)(kLdsLimit / pl->sweep_lds);
+    // blocks that are actually co-resident on a CU (VGPR/LDS limited); the grid is sized to exactly
+    // one residency round so that no CU idles in a second, partial round
+    int per_cu = 0;
+    hipError_t oe = (TQ == 32)
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_sweep<32>, kThreads, pl->sweep_lds)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_sweep<16>, kThreads, pl->sweep_lds);
+    if (oe != hipSuccess) { (void)hipGetLastError(); per_cu = 1; }
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
     int64_t G = ((int64_t)di.cus * per_cu) / pl->nqt;
     if (G < 1) G = 1;
+    if (G > pl->ntiles) G = pl->ntiles;
+    if (G > kMergeMaxCand / pl->kp) {
+        G = kMergeMaxCand / pl->kp;
+        if (pl->nqt == 1 && G > di.cus) G = G / di.cus * di.cus;
+    }
+    if (const char* e = getenv("AC_KNN_G")) { int64_t v = atoll(e); if (v >= 1) G = v; }   // tuning experiments
     if (G > pl->ntiles) G = pl->ntiles;
     if (G > kMergeMaxCand / pl->kp) G = kMergeMaxCand / pl->kp;
     if (G < 1) G = 1;
@@ -739,8 +772,8 @@ static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
     pl->off_flags = off; off += ac::align_up((size_t)(nq > 0 ? nq : 1) * 4, 256);
     pl->off_zeros = off; off += 256;
     pl->total = off;
-    pl->merge_lds = ac::align_up((size_t)pl->G * pl->kp * 8, 16) + ac::align_up((size_t)pl->Dp * 4, 16) +
-                    (size_t)pl->kp * 16 + 64;
+    pl->merge_lds = ac::align_up((size_t)pl->G * pl->kp * 4, 16) + ac::align_up((size_t)pl->Dp * 4, 16) +
+                    (size_t)pl->kp * 16 + 256 * 4 + 64;
     pl->fb_lds = (size_t)kFbCap * 12 + ac::align_up((size_t)pl->Dp, 4) * 4 + 64;
     return AC_OK;
 }
