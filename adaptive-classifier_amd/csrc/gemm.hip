@@ -15,6 +15,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -52,25 +53,41 @@ __device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, in
     return v;
 }
 
+// compile-time epilogue classes for the hot encoder/head shapes; EPI_GENERIC keeps the runtime flags
+enum { EPI_GENERIC = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RES = 3, EPI_BIAS_RELU = 4 };
+
+template <int EPI>
+__device__ __forceinline__ float fast_epilogue(float acc, float bias, float res) {
+    float v = acc + bias;
+    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+    if (EPI == EPI_BIAS_RES) v += res;
+    return v;
+}
+
 __device__ __forceinline__ int acc_row32(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // ---------------------------------------------------------------------------------------------
-// 128x128x32 LDS-tiled NT kernel
+// LDS-tiled NT kernel: (64*TM) x 128 x 32 block tile, 4 waves as 2(M) x 2(N), wave tile (32*TM) x 64.
+//   TM = 2: 128x128 tile, 64 KB LDS, 2 blocks/CU        TM = 1: 64x128 tile, 48 KB LDS, 3 blocks/CU
 // ---------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BN = 128, BK = 32;
 constexpr int kTileThreads = 256;
-// LDS image of one operand tile: [4 row groups of 32][4 k-blocks of 8][64 float4 slots]
-constexpr int kTileSlots = 4 * 4 * 64;
 
-__device__ __forceinline__ int tile_slot(int row, int c4) {   // row in [0,128), c4 in [0,8)
+// slot of (row, c4) inside an operand image laid out [row groups of 32][4 k-blocks of 8][64 float4]
+__device__ __forceinline__ int tile_slot(int row, int c4) {   // c4 in [0,8)
     const int rg = row >> 5, i = row & 31, kb = c4 >> 1, h = c4 & 1;
     return ((rg * 4 + kb) << 6) + (((h << 5) + i) ^ c4);
 }
 
-__global__ __launch_bounds__(kTileThreads, 2) void gemm_tile128_nt(
+template <int EPI, int TM>
+__global__ __launch_bounds__(kTileThreads, TM == 2 ? 2 : 3) void gemm_tile_nt(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
     float* __restrict__ C, int64_t ldc, int M, int N, int K, Epilogue epi) {
-    __shared__ __attribute__((aligned(16))) f32x4 lds[2][2][kTileSlots];   // [stage][A|W]
+    constexpr int BM = 64 * TM;
+    constexpr int A_SLOTS = (BM / 32) * 4 * 64, W_SLOTS = (BN / 32) * 4 * 64;
+    constexpr int PA = BM / 32, PW = BN / 32;                // staging passes (32 rows each)
+    __shared__ __attribute__((aligned(16))) f32x4 lds[2][A_SLOTS + W_SLOTS];   // [stage][A | W]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -79,35 +96,42 @@ __global__ __launch_bounds__(kTileThreads, 2) void gemm_tile128_nt(
     const int bn = blockIdx.x % ntn, bm = blockIdx.x / ntn;
     const int m0 = bm * BM, n0 = bn * BN;
 
-    // staging assignment: thread -> (row = tid/8 + 32*p, c4 = tid%8), p = 0..3
+    // staging assignment: thread -> (row = tid/8 + 32*p, c4 = tid%8)
     const int srow = tid >> 3, sc4 = tid & 7;
-    const float* aptr[4];
-    const float* wptr[4];
+    const float* aptr[PA];
+    const float* wptr[PW];
+    int aslot[PA], wslot[PW];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < PA; ++p) {
         int ra = m0 + srow + 32 * p; if (ra > M - 1) ra = M - 1;
-        int rw = n0 + srow + 32 * p; if (rw > N - 1) rw = N - 1;
         aptr[p] = A + (int64_t)ra * lda + 4 * sc4;
-        wptr[p] = W + (int64_t)rw * ldw + 4 * sc4;
+        aslot[p] = tile_slot(srow + 32 * p, sc4);
     }
-    int sslot[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) sslot[p] = tile_slot(srow + 32 * p, sc4);
+    for (int p = 0; p < PW; ++p) {
+        int rw = n0 + srow + 32 * p; if (rw > N - 1) rw = N - 1;
+        wptr[p] = W + (int64_t)rw * ldw + 4 * sc4;
+        wslot[p] = A_SLOTS + tile_slot(srow + 32 * p, sc4);
+    }
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = K / BK;
-    f32x4 ra[4], rw[4];
+    f32x4 ra[PA], rw[PW];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { ra[p] = *reinterpret_cast<const f32x4*>(aptr[p]); rw[p] = *reinterpret_cast<const f32x4*>(wptr[p]); }
+    for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(aptr[p]);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { lds[0][0][sslot[p]] = ra[p]; lds[0][1][sslot[p]] = rw[p]; }
+    for (int p = 0; p < PW; ++p) rw[p] = *reinterpret_cast<const f32x4*>(wptr[p]);
+#pragma unroll
+    for (int p = 0; p < PA; ++p) lds[0][aslot[p]] = ra[p];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) lds[0][wslot[p]] = rw[p];
     __syncthreads();
 
     const int h = lane >> 5;
@@ -117,45 +141,78 @@ __global__ __launch_bounds__(kTileThreads, 2) void gemm_tile128_nt(
         // unconditional so the compiler's vmcnt accounting is exact)
         const int knext = (kt + 1 < nk) ? (kt + 1) * BK : kt * BK;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            ra[p] = *reinterpret_cast<const f32x4*>(aptr[p] + knext);
-            rw[p] = *reinterpret_cast<const f32x4*>(wptr[p] + knext);
-        }
-        const f32x4* As = lds[cur][0];
-        const f32x4* Ws = lds[cur][1];
+        for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(aptr[p] + knext);
+#pragma unroll
+        for (int p = 0; p < PW; ++p) rw[p] = *reinterpret_cast<const f32x4*>(wptr[p] + knext);
+        // keep the loads above the MFMA section: hipcc otherwise sinks them to their first use
+        // (the ds_write after the k-tile) and their HBM/L2 latency is exposed every k-tile
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4* As = lds[cur];
+        const f32x4* Ws = lds[cur] + A_SLOTS;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             const int sl = lane ^ ((kb * 2 + h) & 7);
-            const f32x4 a0 = As[(((2 * wm + 0) * 4 + kb) << 6) + sl];
-            const f32x4 a1 = As[(((2 * wm + 1) * 4 + kb) << 6) + sl];
-            const f32x4 b0 = Ws[(((2 * wn + 0) * 4 + kb) << 6) + sl];
-            const f32x4 b1 = Ws[(((2 * wn + 1) * 4 + kb) << 6) + sl];
+            f32x4 af[TM], bf[2];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
-            }
-        }
-        if (kt + 1 < nk) {
+            for (int a = 0; a < TM; ++a) af[a] = As[(((TM * wm + a) * 4 + kb) << 6) + sl];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) { lds[cur ^ 1][0][sslot[p]] = ra[p]; lds[cur ^ 1][1][sslot[p]] = rw[p]; }
+            for (int b = 0; b < 2; ++b) bf[b] = Ws[(((2 * wn + b) * 4 + kb) << 6) + sl];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // unconditional (the last k-tile stores a duplicate nobody reads): a conditional store lets
+        // hipcc sink the loads into the branch, i.e. below the MFMA section again
+#pragma unroll
+        for (int p = 0; p < PA; ++p) lds[cur ^ 1][aslot[p]] = ra[p];
+#pragma unroll
+        for (int p = 0; p < PW; ++p) lds[cur ^ 1][wslot[p]] = rw[p];
         __syncthreads();
     }
 
     // epilogue: lane owns column (lane & 31) of each 32x32 tile, 16 rows
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
             if (col >= N) continue;
+            const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
+            if (EPI == EPI_GENERIC) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * 64 + mi * 32 + acc_row32(r, lane);
-                if (row < M) C[row * ldc + col] = apply_epilogue(epi, acc[mi][ni][r], row, col, C, ldc, N);
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = rbase + acc_row32(r, lane);
+                    if (row < M) C[row * ldc + col] = apply_epilogue(epi, acc[mi][ni][r], row, col, C, ldc, N);
+                }
+            } else {
+                const float bias = epi.bias[col];
+                float res[16];
+                if (EPI == EPI_BIAS_RES) {   // issue all residual loads first, then compute + store
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int64_t row = rbase + acc_row32(r, lane);
+                        if (row > M - 1) row = M - 1;
+                        res[r] = epi.residual[row * epi.ldr + col];
+                    }
+                }
+                if (m0 + BM <= M) {          // block-uniform: interior tile, branch-free stores
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        C[(rbase + acc_row32(r, lane)) * ldc + col] =
+                            fast_epilogue<EPI>(acc[mi][ni][r], bias, EPI == EPI_BIAS_RES ? res[r] : 0.f);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = rbase + acc_row32(r, lane);
+                        const float v = fast_epilogue<EPI>(acc[mi][ni][r], bias, EPI == EPI_BIAS_RES ? res[r] : 0.f);
+                        if (row < M) C[row * ldc + col] = v;
+                    }
+                }
             }
         }
 }
@@ -233,9 +290,35 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
     const bool aligned = ((lda & 3) == 0) && ((ldb & 3) == 0) && ((((uintptr_t)A) & 15) == 0) &&
                          ((((uintptr_t)B) & 15) == 0);
     if (a_kmaj && b_kmaj && aligned && M >= 192 && K >= BK && (K % BK) == 0) {
-        const int64_t nblk = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-        hipLaunchKernelGGL(gemm_tile128_nt, dim3((unsigned)nblk), dim3(kTileThreads), 0, stream, A, lda, B, ldb,
-                           C, ldc, M, N, K, epi);
+        // pick the M-tile that wastes fewer CU-rounds: cost = rounds * (tile rows) * (resident blocks)
+        const int cus = ac::dev_info().cus;
+        const int64_t ntn = (N + BN - 1) / BN;
+        const int64_t b128 = (int64_t)((M + 127) / 128) * ntn, b64 = (int64_t)((M + 63) / 64) * ntn;
+        const int64_t cost128 = ((b128 + 2 * cus - 1) / (2 * cus)) * 128 * 2;
+        const int64_t cost64 = ((b64 + 3 * cus - 1) / (3 * cus)) * 64 * 3;
+        int tm = cost64 < cost128 ? 1 : 2;
+        if (const char* e = getenv("AC_GEMM_TM")) { int v = atoi(e); if (v == 1 || v == 2) tm = v; }
+        const int64_t nblk = tm == 2 ? b128 : b64;
+        const bool plain = epi.alpha == 1.f && epi.beta == 0.f && epi.bias && !epi.mask && !epi.gate;
+        int cls = EPI_GENERIC;
+        if (plain && !epi.residual && epi.act == ACT_NONE) cls = EPI_BIAS;
+        else if (plain && !epi.residual && epi.act == ACT_GELU) cls = EPI_BIAS_GELU;
+        else if (plain && !epi.residual && epi.act == ACT_RELU) cls = EPI_BIAS_RELU;
+        else if (plain && epi.residual && epi.act == ACT_NONE) cls = EPI_BIAS_RES;
+        const dim3 grid((unsigned)nblk), block(kTileThreads);
+#define AC_LAUNCH_TILE(E)                                                                                     \
+    do {                                                                                                      \
+        if (tm == 2) hipLaunchKernelGGL((gemm_tile_nt<E, 2>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi); \
+        else hipLaunchKernelGGL((gemm_tile_nt<E, 1>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);         \
+    } while (0)
+        switch (cls) {
+            case EPI_BIAS: AC_LAUNCH_TILE(EPI_BIAS); break;
+            case EPI_BIAS_GELU: AC_LAUNCH_TILE(EPI_BIAS_GELU); break;
+            case EPI_BIAS_RELU: AC_LAUNCH_TILE(EPI_BIAS_RELU); break;
+            case EPI_BIAS_RES: AC_LAUNCH_TILE(EPI_BIAS_RES); break;
+            default: AC_LAUNCH_TILE(EPI_GENERIC); break;
+        }
+#undef AC_LAUNCH_TILE
     } else {
         dim3 grid((N + 31) / 32, (M + 31) / 32);
         if (a_kmaj && b_kmaj)
