@@ -124,11 +124,16 @@ class HipBertEncoder:
                 "ac_bert_encode_cls")
         return out
 
-    def flops(self, b, S):
-        """Algorithmic FLOPs of one forward (dense projections + attention), for roofline reports."""
+    def flops(self, b, S, executed=True):
+        """FLOPs of one forward (dense projections + attention), for roofline reports.
+        executed=True counts what the kernels run (the last layer's output projection / FFN and its
+        attention only touch the b CLS rows); executed=False is the full BertModel.forward count."""
         c = self.ccfg
         H, I, L = c.hidden, c.intermediate, c.layers
         T = b * S
-        dense = 2.0 * T * (4.0 * H * H + 2.0 * H * I) * L
-        attn = 4.0 * b * c.heads * S * S * (H // c.heads) * L
-        return dense + attn
+        per_tok = 2.0 * (4.0 * H * H + 2.0 * H * I)
+        attn_layer = 4.0 * b * c.heads * S * S * (H // c.heads)
+        if not executed:
+            return per_tok * T * L + attn_layer * L
+        last = 2.0 * T * 3.0 * H * H + 2.0 * b * (H * H + 2.0 * H * I) + attn_layer / S
+        return per_tok * T * (L - 1) + attn_layer * (L - 1) + last

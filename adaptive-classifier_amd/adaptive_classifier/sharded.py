@@ -43,21 +43,29 @@ class ShardedSearch:
     def world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    def _all_gather(self, t):
+        """all_gather along a new leading dim -> [world, ...].  RCCL gathers device tensors directly; the
+        gloo path (CPU tests, single-GPU dry runs) stages through the host."""
+        t = t.contiguous()
+        if t.is_cuda and dist.get_backend(self.group) != "nccl":
+            parts = [torch.empty_like(t, device="cpu") for _ in range(self.world)]
+            dist.all_gather(parts, t.cpu(), group=self.group)
+            return torch.stack(parts).to(t.device)
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group) if t.is_cuda else \
+            dist.all_gather(list(out.unbind(0)), t, group=self.group)
+        return out
+
     def gather_queries(self, q_local):
         """Data-parallel query blocks -> the full [b, D] block on every rank (equal block sizes)."""
         if self.world == 1:
             return q_local
-        parts = [torch.empty_like(q_local) for _ in range(self.world)]
-        dist.all_gather(parts, q_local.contiguous(), group=self.group)
-        return torch.cat(parts, 0)
+        g = self._all_gather(q_local)
+        return g.reshape(-1, q_local.shape[-1])
 
     def search(self, queries, k):
         """queries [b, D] (identical on all ranks) -> global (dist [b,k], ids [b,k]) on every rank."""
         D_loc, I_loc = self._search(self.rows, self.n_local, self.dim, queries, k, self.row_offset)
         if self.world == 1:
             return D_loc, I_loc
-        Ds = [torch.empty_like(D_loc) for _ in range(self.world)]
-        Is = [torch.empty_like(I_loc) for _ in range(self.world)]
-        dist.all_gather(Ds, D_loc.contiguous(), group=self.group)
-        dist.all_gather(Is, I_loc.contiguous(), group=self.group)
-        return self._merge(torch.stack(Ds), torch.stack(Is))
+        return self._merge(self._all_gather(D_loc), self._all_gather(I_loc))

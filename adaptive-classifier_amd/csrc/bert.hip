@@ -206,6 +206,61 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* qkv, const i
     }
 }
 
+// Last layer: only the CLS query of every sequence feeds the output (classifier.py:1272), so its
+// attention is a single-query problem.  One wave per (sequence, head): lane = key for the scores,
+// lane = output dim for the P.V reduction; K tile rows padded to 65 floats (conflict-free column reads).
+__global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, const int64_t* mask, int S, int H,
+                                                           float scale, float* ctx_cls) {
+    __shared__ float Ks[KT][DH + 1];
+    __shared__ __attribute__((aligned(16))) float Vs[KT][DH];
+    __shared__ float qs[DH];
+    __shared__ float ps[KT];
+    const int lane = threadIdx.x;
+    const int head = blockIdx.x, bi = blockIdx.y;
+    const int64_t ld = 3 * (int64_t)H;
+    const float* base = qkv + (int64_t)bi * S * ld + head * DH;
+    qs[lane] = base[lane] * scale;              // CLS token = row 0 of the sequence
+    float m = -INFINITY, l = 0.f, o = 0.f;      // o: output dim `lane`
+    for (int k0 = 0; k0 < S; k0 += KT) {
+        const int nk = (S - k0) < KT ? (S - k0) : KT;
+        __syncthreads();
+        for (int r = lane >> 4; r < KT; r += 4) {
+            const int c = (lane & 15) * 4;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (r < nk) {
+                const float* kp = base + (int64_t)(k0 + r) * ld + H;
+                kv = *reinterpret_cast<const f32x4*>(kp + c);
+                vv = *reinterpret_cast<const f32x4*>(kp + H + c);
+            }
+            Ks[r][c] = kv.x; Ks[r][c + 1] = kv.y; Ks[r][c + 2] = kv.z; Ks[r][c + 3] = kv.w;
+            *reinterpret_cast<f32x4*>(&Vs[r][c]) = vv;
+        }
+        __syncthreads();
+        const bool valid = lane < nk && (!mask || mask[(int64_t)bi * S + k0 + lane] != 0);
+        float sc = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < DH; ++d) sc = fmaf(qs[d], Ks[lane][d], sc);
+        sc = valid ? sc : -INFINITY;
+        float cmax = sc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, off));
+        const float m_new = fmaxf(m, cmax);
+        if (m_new == -INFINITY) continue;        // wave-uniform
+        const float corr = expf(m - m_new);
+        const float p = expf(sc - m_new);        // masked -> 0
+        ps[lane] = p;
+        float psum = p;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) psum += __shfl_xor(psum, off);
+        l = l * corr + psum;
+        o *= corr;
+        __syncthreads();
+        for (int j = 0; j < nk; ++j) o = fmaf(ps[j], Vs[j][lane], o);
+        m = m_new;
+    }
+    ctx_cls[(int64_t)bi * H + head * DH + lane] = l > 0.f ? o / l : 0.f;
+}
+
 struct BertWs {
     size_t x, qkv, ctx, y, ffn, total;
 };
@@ -272,23 +327,37 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
     for (int l = 0; l < c.layers; ++l) {
         rc = ac::linear_f32(x, H, w->qkv_w[l], H, w->qkv_b[l], nullptr, 0, qkv, 3 * H, T, 3 * H, H, 0, nullptr, 1.f, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(attention_kernel, dim3((S + 63) / 64, c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H,
-                           scale, ctx);
+        const bool last = (l == c.layers - 1);
+        // After the last layer's attention only the CLS row of each sequence is consumed, so the
+        // output projection, both LayerNorms and the FFN run on b rows instead of b*S.
+        const int Ml = last ? b : T;
+        const float* resid = x;                        // residual = layer input
+        const int64_t ldres = last ? (int64_t)S * H : H;   // CLS rows of x are S*H apart
+        if (last) {
+            hipLaunchKernelGGL(attention_cls_kernel, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale, ctx);
+        } else {
+            hipLaunchKernelGGL(attention_kernel, dim3((S + 63) / 64, c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H,
+                               scale, ctx);
+        }
         AC_LAUNCH_CHECK();
-        rc = ac::linear_f32(ctx, H, w->ao_w[l], H, w->ao_b[l], x, H, y, H, T, H, H, 0, nullptr, 1.f, stream);
+        const int lblocks = (Ml + 3) / 4;
+        rc = ac::linear_f32(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, y, T, H, w->ln1_g[l], w->ln1_b[l],
-                           c.ln_eps, x);
+        // (last layer: x is overwritten with b compact rows; its old contents are no longer needed)
+        hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln1_g[l], w->ln1_b[l],
+                           c.ln_eps, last ? ctx : x);
         AC_LAUNCH_CHECK();
-        rc = ac::linear_f32(x, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, T, I, H, 2, nullptr, 1.f, stream);
+        float* x1 = last ? ctx : x;                    // ctx is free again after the AO projection
+        rc = ac::linear_f32(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, nullptr, 1.f, stream);
         if (rc) return rc;
-        rc = ac::linear_f32(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x, H, y, H, T, H, I, 0, nullptr, 1.f, stream);
+        rc = ac::linear_f32(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, nullptr, 1.f, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, y, T, H, w->ln2_g[l], w->ln2_b[l],
+        hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln2_g[l], w->ln2_b[l],
                            c.ln_eps, x);
         AC_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(cls_normalize_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, b, S, H, d_out, ldo);
+    // after the CLS-only last layer x holds b compact rows (sequence stride 1)
+    hipLaunchKernelGGL(cls_normalize_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, b, 1, H, d_out, ldo);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

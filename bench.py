@@ -191,11 +191,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    dev = torch.device(f"cuda:{local_rank}")
+    dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" is RCCL on ROCm.  AC_BENCH_BACKEND=gloo exists only to exercise the N>1 code path with
+        # several ranks on ONE GPU (RCCL refuses duplicate devices); it is never used for reported numbers.
+        backend = os.environ.get("AC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     clf, hf = make_classifier(dev, rank, world)
     ids, types, mask = synthetic_tokens(dev, rank)
@@ -215,7 +221,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert len(preds) == BATCH and all(len(p) >= 1 for p in preds)
@@ -239,7 +245,9 @@ def main():
             "roofline_encoder": {"bound": "mfma", "achieved": enc_flops / stages["encode_ms"] / 1e9,
                                  "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": enc_flops / stages["encode_ms"] / 1e9 / F32_MFMA_PEAK_TF,
-                                 "flops_per_step": enc_flops},
+                                 "flops_per_step": enc_flops,
+                                 "note": "executed FLOPs (last layer runs its post-attention part on the CLS rows only); "
+                                         "full BertModel.forward would be %.4g" % clf.model.flops(BATCH, SEQ, executed=False)},
             "roofline_knn_batch": {"bound": "mfma", "achieved": knn_flops / stages["knn_ms"] / 1e9,
                                    "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                    "frac": knn_flops / stages["knn_ms"] / 1e9 / F32_MFMA_PEAK_TF,
