@@ -42,28 +42,18 @@ constexpr int kPad = 8;                 // extra candidates kept beyond k
 constexpr int kMergeMaxCand = 32768;    // G * k' limit (merge kernel keeps 32-bit keys in LDS)
 constexpr int kLdsLimit = 160 * 1024;
 
-template <int TQ> struct Shape;
-template <> struct Shape<32> {
-    static constexpr int ROWS = 32, KSPLIT = 2, NACC = 16, KCOLS = 8;
-    typedef f32x16 acc_t;
-    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-    }
-    // C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    static __device__ __forceinline__ int acc_row(int r, int lane) {
-        return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    }
-};
-template <> struct Shape<16> {
+// One MFMA shape for every query-tile width: v_mfma_f32_16x16x4_f32.  A lane (row i = lane & 15,
+// k-slice h = lane >> 4) loads float4 P[row0 + i][16*kb + 4*h ..]: 16 rows x 64 contiguous bytes per
+// wave load (two instructions per 128-B line; the 32x32x2 shape would touch 32 rows x 32 B).  A query
+// tile is J sub-tiles of 16 queries; the A fragment is reused for the J B-fragments.
+struct Shape {
     static constexpr int ROWS = 16, KSPLIT = 4, NACC = 4, KCOLS = 16;
     typedef f32x4 acc_t;
     static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
     // C/D layout: col = lane & 15, row = 4 * (lane >> 4) + r
-    static __device__ __forceinline__ int acc_row(int r, int lane) {
-        return 4 * (lane >> 4) + r;
-    }
+    static __device__ __forceinline__ int acc_row(int r, int lane) { return 4 * (lane >> 4) + r; }
 };
 
 struct SweepParams {
@@ -154,10 +144,11 @@ __device__ __forceinline__ void prune_dispatch(float* ld, int32_t* li, int* cnt_
     else prune_list<8>(ld, li, cnt_p, tau_p, cap, kp, lane);
 }
 
-template <int TQ>
+template <int J>
 __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
-    typedef Shape<TQ> S;
-    typedef typename S::acc_t acc_t;
+    typedef Shape S;
+    typedef S::acc_t acc_t;
+    constexpr int TQ = 16 * J;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -169,7 +160,7 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
     const int g = v / prm.nqt;
 
     // ---- LDS carve-up (all offsets multiples of 16) ----
-    const int nslots = prm.ng * kGroup * 64;          // float4 slots of the query tile
+    const int nslots = J * prm.ng * kGroup * 64;      // float4 slots of the query tile
     f32x4* Qs = reinterpret_cast<f32x4*>(smem);
     float* list_d = reinterpret_cast<float*>(smem + (size_t)nslots * 16);
     int32_t* list_i = reinterpret_cast<int32_t*>(list_d + (size_t)TQ * prm.cap);
@@ -177,7 +168,7 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
     float* tau_s = reinterpret_cast<float*>(cnt + TQ);
     float* wmax_s = tau_s + TQ;                       // [kWaves]
 
-    // ---- stage the query tile: slot (kb, ksub, j) = -2 * Q[qt*TQ + j][KCOLS*kb + 4*ksub ..+3] ----
+    // ---- stage the query tile: slot (jj, kb, ksub, j) = -2 * Q[qt*TQ + 16*jj + j][16*kb + 4*ksub ..+3] ----
     {
         const int c4_per_q = prm.ng * kGroup * S::KSPLIT;   // float4 columns per query (padded)
         const int total = TQ * c4_per_q;
@@ -195,7 +186,7 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
                 if (col + 2 < prm.D) val.z = -2.f * src[2];
                 if (col + 3 < prm.D) val.w = -2.f * src[3];
             }
-            Qs[kb * 64 + ksub * TQ + j] = val;
+            Qs[((j >> 4) * (prm.ng * kGroup) + kb) * 64 + ksub * 16 + (j & 15)] = val;
         }
         for (int t = tid; t < TQ; t += kThreads) {
             cnt[t] = 0;
@@ -204,10 +195,12 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
     }
     __syncthreads();
 
-    const int j = lane % TQ;            // query column this lane owns in the C/D layout
+    const int j = lane & 15;            // query column (within each sub-tile) this lane owns in C/D
     const int ksub = lane / S::ROWS;    // k sub-slice this lane feeds in the A/B layout
     const int arow = lane % S::ROWS;    // tile row this lane feeds in the A layout
-    float tau = tau_s[j];
+    float tau[J];
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) tau[jj] = tau_s[16 * jj + j];
     float wave_maxnorm = 0.f;
 
     // tiles of this block: T = it * G + g
@@ -243,14 +236,15 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
         if (++pf_grp == ng) { pf_grp = 0; ++pf_tile; pf_ptr = tile_rowptr(pf_tile); }    \
     } while (0)
 
-    acc_t acc;
+    acc_t acc[J];
     float nsq = 0.f;
     int64_t cur_tile = 0;
     int cur_grp = 0;
 
     auto epilogue = [&]() {
         // fold |p|^2 in: A = this lane's partial sum of squares, B = 1
-        acc = S::mfma(nsq, 1.0f, acc);
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) acc[jj] = S::mfma(nsq, 1.0f, acc[jj]);
         // row norm for the error-bound certificate
         float rn = nsq;
 #pragma unroll
@@ -260,24 +254,31 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
         const int64_t row_base = (cur_tile * prm.G + g) * (int64_t)(kWaves * S::ROWS) + wave * S::ROWS;
         bool maybe = false;
 #pragma unroll
-        for (int r = 0; r < S::NACC; ++r) maybe |= (acc[r] < tau);
+        for (int jj = 0; jj < J; ++jj)
+#pragma unroll
+            for (int r = 0; r < S::NACC; ++r) maybe |= (acc[jj][r] < tau[jj]);
         unsigned done = 0;
         bool pend = __any(maybe) != 0;
         for (;;) {
             bool lane_pend = false;
             if (pend) {
 #pragma unroll
-                for (int r = 0; r < S::NACC; ++r) {
-                    const int64_t row = row_base + S::acc_row(r, lane);
-                    const float d = acc[r];
-                    if (!((done >> r) & 1u) && d < tau && row < prm.N) {
-                        const int slot = atomicAdd(&cnt[j], 1);
-                        if (slot < prm.cap) {
-                            list_d[j * prm.cap + slot] = d;
-                            list_i[j * prm.cap + slot] = (int32_t)row;
-                            done |= 1u << r;
-                        } else {
-                            lane_pend = true;
+                for (int jj = 0; jj < J; ++jj) {
+                    const int q = 16 * jj + j;
+#pragma unroll
+                    for (int r = 0; r < S::NACC; ++r) {
+                        const int64_t row = row_base + S::acc_row(r, lane);
+                        const float d = acc[jj][r];
+                        const unsigned bit = 1u << (jj * S::NACC + r);
+                        if (!(done & bit) && d < tau[jj] && row < prm.N) {
+                            const int slot = atomicAdd(&cnt[q], 1);
+                            if (slot < prm.cap) {
+                                list_d[q * prm.cap + slot] = d;
+                                list_i[q * prm.cap + slot] = (int32_t)row;
+                                done |= bit;
+                            } else {
+                                lane_pend = true;
+                            }
                         }
                     }
                 }
@@ -293,7 +294,8 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
                                    prm.cap, prm.kp, lane);
             }
             __syncthreads();
-            tau = tau_s[j];
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) tau[jj] = tau_s[16 * jj + j];
             pend = true;   // re-test un-pushed entries against the tightened tau
         }
         nsq = 0.f;
@@ -302,20 +304,26 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
 #define AC_COMPUTE(B)                                                                    \
     do {                                                                                 \
         if (cur_grp == 0) {                                                              \
-            _Pragma("unroll") for (int r = 0; r < S::NACC; ++r) acc[r] = 0.f;            \
+            _Pragma("unroll") for (int jj = 0; jj < J; ++jj)                             \
+                _Pragma("unroll") for (int r = 0; r < S::NACC; ++r) acc[jj][r] = 0.f;    \
         }                                                                                \
         const f32x4* qsrc = Qs + (size_t)cur_grp * kGroup * 64 + lane;                   \
-        f32x4 bq = qsrc[0];                                                              \
+        const size_t jstride = (size_t)ng * kGroup * 64;                                 \
+        f32x4 bq[J];                                                                     \
+        _Pragma("unroll") for (int jj = 0; jj < J; ++jj) bq[jj] = qsrc[jj * jstride];    \
         _Pragma("unroll") for (int u = 0; u < kGroup; ++u) {                             \
             const f32x4 a = buf[B][u];                                                   \
-            const f32x4 b = bq;                                                          \
-            if (u + 1 < kGroup) bq = qsrc[(u + 1) * 64]; /* LDS read one step ahead */   \
-            acc = S::mfma(a.x, b.x, acc);                                                \
+            f32x4 b[J];                                                                  \
+            _Pragma("unroll") for (int jj = 0; jj < J; ++jj) b[jj] = bq[jj];             \
+            if (u + 1 < kGroup) { /* LDS reads one step ahead */                         \
+                _Pragma("unroll") for (int jj = 0; jj < J; ++jj) bq[jj] = qsrc[jj * jstride + (u + 1) * 64]; \
+            }                                                                            \
+            _Pragma("unroll") for (int jj = 0; jj < J; ++jj) acc[jj] = S::mfma(a.x, b[jj].x, acc[jj]); \
             nsq = fmaf(a.x, a.x, nsq); nsq = fmaf(a.y, a.y, nsq);                        \
-            acc = S::mfma(a.y, b.y, acc);                                                \
+            _Pragma("unroll") for (int jj = 0; jj < J; ++jj) acc[jj] = S::mfma(a.y, b[jj].y, acc[jj]); \
             nsq = fmaf(a.z, a.z, nsq); nsq = fmaf(a.w, a.w, nsq);                        \
-            acc = S::mfma(a.z, b.z, acc);                                                \
-            acc = S::mfma(a.w, b.w, acc);                                                \
+            _Pragma("unroll") for (int jj = 0; jj < J; ++jj) acc[jj] = S::mfma(a.z, b[jj].z, acc[jj]); \
+            _Pragma("unroll") for (int jj = 0; jj < J; ++jj) acc[jj] = S::mfma(a.w, b[jj].w, acc[jj]); \
             __builtin_amdgcn_sched_barrier(0); /* keep the per-load consume order */     \
         }                                                                                \
         if (++cur_grp == ng) { epilogue(); cur_grp = 0; ++cur_tile; }                    \
@@ -729,9 +737,10 @@ static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
     pl->Dp = (D + 3) / 4 * 4;
     int TQ = nq > 16 ? 32 : 16;
     for (;;) {
-        const int kcols = TQ == 32 ? 8 : 16;
+        const int kcols = 16;
         pl->ng = (pl->Dp + kcols * kGroup - 1) / (kcols * kGroup);
-        pl->sweep_lds = (size_t)pl->ng * kGroup * 64 * 16 + (size_t)TQ * pl->cap * 8 + TQ * 8 + kWaves * 4 + 64;
+        pl->sweep_lds = (size_t)(TQ / 16) * pl->ng * kGroup * 64 * 16 + (size_t)TQ * pl->cap * 8 + TQ * 8 +
+                        kWaves * 4 + 64;
         if (pl->sweep_lds <= (size_t)kLdsLimit) break;
         AC_REQUIRE(TQ == 32, AC_EUNSUPPORTED,
                    "knn: D=%d with k=%d needs %zu B of LDS (> %d); unsupported", D, k, pl->sweep_lds, kLdsLimit);
@@ -739,15 +748,15 @@ static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
     }
     pl->TQ = TQ;
     pl->nqt = nq > 0 ? (nq + TQ - 1) / TQ : 1;
-    const int rows_per_tile = kWaves * TQ;
+    const int rows_per_tile = kWaves * 16;
     pl->ntiles = (N + rows_per_tile - 1) / rows_per_tile;
     const ac::DevInfo& di = ac::dev_info();
     // blocks that are actually co-resident on a CU (VGPR/LDS limited); the grid is sized to exactly
     // one residency round so that no CU idles in a second, partial round
     int per_cu = 0;
     hipError_t oe = (TQ == 32)
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_sweep<32>, kThreads, pl->sweep_lds)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_sweep<16>, kThreads, pl->sweep_lds);
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_sweep<2>, kThreads, pl->sweep_lds)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_sweep<1>, kThreads, pl->sweep_lds);
     if (oe != hipSuccess) { (void)hipGetLastError(); per_cu = 1; }
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
@@ -822,7 +831,7 @@ extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, c
     MergeParams mp;
     mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = pl.Dp;
     mp.k = k; mp.kp = pl.kp; mp.G = pl.G; mp.nblk = pl.G * pl.nqt;
-    mp.nterms = pl.ng * kGroup * (pl.TQ == 32 ? 8 : 16) + 16;
+    mp.nterms = pl.ng * kGroup * 16 + 16;
     mp.row_offset = row_offset;
     mp.part_d = (const float*)(ws + pl.off_part_d);
     mp.part_i = (const int32_t*)(ws + pl.off_part_i);
@@ -848,13 +857,13 @@ extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, c
         const int nblk = pl.G * pl.nqt;
         if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
         if (pl.TQ == 32) {
-            (void)hipFuncSetAttribute((const void*)knn_sweep<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute((const void*)knn_sweep<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)pl.sweep_lds);
-            hipLaunchKernelGGL(knn_sweep<32>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
+            hipLaunchKernelGGL(knn_sweep<2>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
         } else {
-            (void)hipFuncSetAttribute((const void*)knn_sweep<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute((const void*)knn_sweep<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)pl.sweep_lds);
-            hipLaunchKernelGGL(knn_sweep<16>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
+            hipLaunchKernelGGL(knn_sweep<1>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
         }
         AC_LAUNCH_CHECK();
         if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_stop, stream));

@@ -140,7 +140,7 @@ def sweep_roofline(dev, n_rows):
     torch.cuda.empty_cache()
     return {"bound": "hbm", "achieved": bytes_alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "knn_sweep<16>", "rows": n_rows, "dim": DIM, "resident_queries": nq,
+            "kernel": "knn_sweep<1> (16-query tile)", "rows": n_rows, "dim": DIM, "resident_queries": nq,
             "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": ms, "min_kernel_ms": float(np.min(times)),
             "exact_fallback_queries": int(stats[0].item())}
 
