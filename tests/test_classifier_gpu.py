@@ -186,3 +186,78 @@ def test_generalised_store_rows_to_classes(cuda_dev):
     assert np.array_equal(I.cpu().numpy(), oI)
     res = m.get_nearest_prototypes(Q[0].cpu(), k=16)
     assert [l for l, _ in res] == [f"c{int(i) % C}" for i in oI[0]]
+
+
+# ---- reference tests/test_order_independence.py + tests/test_ewc.py:156-191 analogues -------------
+def _fresh(cuda_dev, cfg=None):
+    from adaptive_classifier import AdaptiveClassifier
+    from adaptive_classifier.encoder import HipBertEncoder
+    enc = HipBertEncoder(small_bert(), device=cuda_dev)
+    return AdaptiveClassifier("synthetic", device="cuda:0", config=cfg, encoder=enc, tokenizer=HashTokenizer())
+
+
+def test_label_ids_are_order_independent(cuda_dev):
+    """New classes get ids in sorted order regardless of the order examples arrive in (:147-150)."""
+    a, b = _fresh(cuda_dev), _fresh(cuda_dev)
+    a.add_examples(TEXTS, LABELS)
+    perm = [8, 2, 5, 0, 7, 3, 1, 6, 4]
+    b.add_examples([TEXTS[i] for i in perm], [LABELS[i] for i in perm])
+    assert a.label_to_id == b.label_to_id == {"negative": 0, "neutral": 1, "positive": 2}
+    assert a.memory.index_to_label == b.memory.index_to_label
+    for l in a.memory.prototypes:
+        assert torch.allclose(a.memory.prototypes[l], b.memory.prototypes[l], atol=1e-6)
+
+
+def test_progressive_class_addition(cuda_dev):
+    """tests/test_ewc.py:156-191: four phases, new classes twice; every label stays addressable."""
+    c = _fresh(cuda_dev)
+    c.add_examples(["Good product", "Bad service", "Average quality"], ["positive", "negative", "neutral"])
+    c.add_examples(["Need help", "Bug report", "Feature request"], ["support", "bug", "feature"])
+    c.add_examples(["Excellent!", "Terrible!", "It's okay"], ["positive", "negative", "neutral"])
+    c.add_examples(["Urgent issue", "Question about pricing"], ["urgent", "inquiry"])
+    expected = {"positive", "negative", "neutral", "support", "bug", "feature", "urgent", "inquiry"}
+    assert set(c.label_to_id) == expected and c.adaptive_head.model[-1].out_features == 8
+    assert c.memory.index.ntotal == 8 and c.train_steps == 4
+    preds = c.predict("This is wonderful!", k=3)
+    assert len(preds) == 3 and all(l in expected for l, _ in preds)
+    many = c.predict("This is wonderful!", k=20)
+    assert len(many) == 8 and abs(sum(s for _, s in many) - 1) < 1e-6
+
+
+def test_many_classes_path(cuda_dev):
+    """> 20 classes takes the stratified-sampling branch of _train_new_classes (:224-246)."""
+    c = _fresh(cuda_dev)
+    np.random.seed(42)
+    base_t = [f"class {i} example {j} word{i}" for i in range(22) for j in range(3)]
+    base_l = [f"class_{i:02d}" for i in range(22) for j in range(3)]
+    c.add_examples(base_t, base_l)
+    c.add_examples([f"brand new thing {j}" for j in range(3)], ["class_99"] * 3)
+    assert len(c.label_to_id) == 23 and c.adaptive_head.model[-1].out_features == 23
+    assert len(c.predict("brand new thing", k=5)) == 5
+
+
+def test_continuous_learning_loop_scaled(cuda_dev):
+    """BASELINE configs[3] at reduced scale: a stream of pre-computed embeddings in chunks of 32 with
+    max_examples_per_class capping the store, then a 5th class (EWC path, both modes)."""
+    from oracle import synth
+    D, C, n = 128, 4, 640
+    cent = synth.synth_unit_rows(C + 1, D, 3)
+    noise = synth.synth_unit_rows(n + 64, D, 4)
+    def emb(i, c):
+        v = cent[c] + 0.5 * noise[i]
+        return torch.from_numpy((v / np.linalg.norm(v)).astype(np.float32))
+    for mode in ("as_wired", "intended"):
+        c = _fresh(cuda_dev, {"max_examples_per_class": 50, "ewc_mode": mode})
+        for s in range(0, n, 32):
+            idx = list(range(s, s + 32))
+            c.add_embeddings([f"t{i}" for i in idx], [emb(i, i % C) for i in idx], [f"c{i % C}" for i in idx])
+        st = c.get_memory_stats()
+        assert all(v == 50 for v in st["examples_per_class"].values()) and st["total_examples"] == 200
+        assert c.training_history == {f"c{k}": n // C for k in range(C)}
+        np.random.seed(1)
+        c.add_embeddings([f"n{i}" for i in range(32)], [emb(n + i, C) for i in range(32)], ["zzz_new"] * 32)
+        assert c.adaptive_head.model[-1].out_features == 5
+        test = torch.stack([emb(n + 32 + i, i % (C + 1)) for i in range(30)]).to(cuda_dev)
+        want = [f"c{i % (C + 1)}" if i % (C + 1) < C else "zzz_new" for i in range(30)]
+        acc = np.mean([p[0][0] == w for p, w in zip(c.predict_embeddings(test, k=2), want)])
+        assert acc >= 0.8, (mode, acc)
