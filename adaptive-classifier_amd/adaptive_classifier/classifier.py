@@ -33,6 +33,7 @@ from . import _native as nv
 from .ewc import EWC
 from .memory import PrototypeMemory
 from .models import AdaptiveHead, Example, ModelConfig
+from .ops import l2_normalize_rows, softmax_rows
 from .training import HeadTrainer
 
 logger = logging.getLogger(__name__)
@@ -171,20 +172,28 @@ class AdaptiveClassifier:
         loader = self._index_loader(X.shape[0], batch_size)
         best_loss, patience, patience_counter = float("inf"), 3, 0
         steps = 0
+        X = X.contiguous()
+        y = y.contiguous()
+        # dropout masks are generated in-kernel from (seed, step): counter-based, reproducible per
+        # classifier seed; the reference draws them from torch's global generator (not replayable)
+        base_seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self.train_steps * 1000003) & 0x7FFFFFFFFFFFFFFF
         for epoch in range(epochs):
-            total = torch.zeros((), dtype=torch.float32, device=X.device)
-            for (idx,) in loader:
-                idx = idx.to(X.device)
-                xb, yb = X.index_select(0, idx), y.index_select(0, idx)
-                m1, m2 = trainer.dropout_masks(xb.shape[0], AdaptiveHead.DROPOUT_P)
+            trainer.loss_accum.zero_()
+            # one H2D of the epoch's batch order (same order as the reference's seeded DataLoader)
+            batches = [idx for (idx,) in loader]
+            order = torch.cat(batches).to(X.device)
+            off = 0
+            for idx in batches:
+                nb = idx.numel()
+                index = order[off: off + nb]
+                off += nb
                 if ewc is not None:
-                    loss, out = trainer.step(xb, yb, m1, m2, AdaptiveHead.DROPOUT_P, fisher=ewc.fisher_flat,
-                                             old_params=ewc.old_flat, lambda_over_B=lambda_B / xb.shape[0])
-                    total += loss[0] + out[0]
+                    trainer.fused_step(X, y, index, AdaptiveHead.DROPOUT_P, base_seed + steps, fisher=ewc.fisher_flat,
+                                       old_params=ewc.old_flat, lambda_over_B=lambda_B / nb)
                 else:
-                    loss, _ = trainer.step(xb, yb, m1, m2, AdaptiveHead.DROPOUT_P)
-                    total += loss[0]
+                    trainer.fused_step(X, y, index, AdaptiveHead.DROPOUT_P, base_seed + steps)
                 steps += 1
+            total = trainer.loss_accum
             avg_loss = float(total.item()) / len(loader)         # the only host sync of the epoch
             if sched is not None:
                 sched.step(avg_loss)
@@ -208,7 +217,7 @@ class AdaptiveClassifier:
             for example in sorted(self.memory.examples[label], key=lambda x: x.text):
                 embs.append(example.embedding)
                 labs.append(self.label_to_id[example.label])
-        X = F.normalize(torch.stack(embs).to(self.device), p=2, dim=1)       # :1450
+        X = l2_normalize_rows(torch.stack(embs).to(self.device))               # :1450
         y = torch.tensor(labs, dtype=torch.long, device=self.device)
         self._run_epochs(X, y, batch_size=min(32, X.shape[0]), epochs=epochs, use_scheduler=True)
 
@@ -291,7 +300,7 @@ class AdaptiveClassifier:
                     Cid = torch.where(I >= 0, lut[I.clamp(min=0) % lut.numel()], torch.full_like(I, -1))
             if self.adaptive_head is not None:
                 self.adaptive_head.eval()
-                probs = torch.softmax(self.adaptive_head.forward_native(emb), dim=1)
+                probs = softmax_rows(self.adaptive_head.forward_native(emb))
             out = (None if S is None else S.cpu().numpy(), None if S is None else Cid.cpu().numpy(),
                    None if probs is None else probs.cpu().numpy())
         return out

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from . import _native as nv
 from .models import AdaptiveHead
+from .ops import softmax_rows
 
 
 class EWC:
@@ -67,7 +68,7 @@ class EWC:
         for bi, (batch_embeddings, _) in enumerate(loader):
             X = batch_embeddings.to(flat.device)
             if sampled_labels is None:
-                probs = torch.softmax(head.forward_native(X), dim=1)
+                probs = softmax_rows(head.forward_native(X))
                 y = torch.multinomial(probs, 1).squeeze(-1)     # ewc.py:81
             else:
                 y = sampled_labels[bi]

@@ -35,6 +35,8 @@ class HeadTrainer:
         self.scratch = torch.zeros(REDUCE_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.out = torch.zeros(2, dtype=torch.float32, device=dev)      # [ewc penalty, grad norm]
+        self.out3 = torch.zeros(3, dtype=torch.float32, device=dev)     # fused step: [ce, ewc penalty, grad norm]
+        self.loss_accum = torch.zeros(1, dtype=torch.float32, device=dev)   # epoch running sum (device)
         self._ws = None
 
     def _workspace(self, B):
@@ -80,3 +82,20 @@ class HeadTrainer:
         self.forward_backward(X, y, mask1, mask2, dropout_p)
         self.optimizer_step(fisher, old_params, lambda_over_B)
         return self.loss, self.out
+
+    def fused_step(self, X_all, y_all, index=None, dropout_p=0.1, seed=0, fisher=None, old_params=None,
+                   lambda_over_B=0.0):
+        """One call = gather batch (rows `index` of X_all / y_all) + train-mode forward with in-kernel
+        counter-based dropout + CE + backward + EWC/clip/AdamW (`ac_head_train_step`).  No torch kernels,
+        no host sync; the step's CE + penalty is added to self.loss_accum on device."""
+        B = int(index.numel()) if index is not None else X_all.shape[0]
+        ws = self._workspace(B)
+        self.t += 1
+        with torch.cuda.device(self.device):
+            nv.check(nv.lib().ac_head_train_step(
+                ctypes.byref(self.dims), nv.ptr(self.flat), nv.ptr(self.m), nv.ptr(self.v), nv.ptr(self.grads),
+                nv.ptr(X_all), X_all.stride(0), nv.ptr(y_all), nv.ptr(index), B, dropout_p, seed,
+                nv.ptr(fisher), nv.ptr(old_params), lambda_over_B, self.max_grad_norm, self.lr, self.betas[0],
+                self.betas[1], self.eps, self.weight_decay, self.t, nv.ptr(self.out3), nv.ptr(self.loss_accum),
+                nv.ptr(ws), ws.numel(), nv.stream_ptr(self.device)), "ac_head_train_step")
+        return self.out3

@@ -53,7 +53,17 @@ __host__ __device__ static inline size_t align_up(size_t x, size_t a) { return (
 //   dropout mask (uint8 [M,N], kept values * mask_scale), optional residual added last.
 int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
-               const uint8_t* mask, float mask_scale, hipStream_t stream);
+               const uint8_t* mask, float mask_scale, hipStream_t stream, float drop_p = 0.f,
+               uint64_t drop_seed = 0);
+
+// counter-based Bernoulli(1-p) keep decision for in-kernel dropout (stateless: seed + element index)
+__host__ __device__ static inline bool dropout_keep(uint64_t seed, uint64_t idx, float p) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;
+}
 //   C = alpha * op(A) op(B) + beta * C; if gate != null: C = gate[m,n] != 0 ? C * gate_scale : 0
 int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
              const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* gate,

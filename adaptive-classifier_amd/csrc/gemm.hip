@@ -34,6 +34,10 @@ struct Epilogue {
     // inverted-dropout mask applied after the activation (train-mode head): 1 = keep
     const uint8_t* mask;    // [M, N] or null
     float mask_scale;
+    // ... or generated in-kernel from a counter-based hash (no mask tensor, no torch RNG launch):
+    // keep element (row, col) iff u(drop_seed, row * N + col) >= drop_p
+    uint64_t drop_seed;
+    float drop_p;
     // relu/dropout backward gate: out = gate[row,col] != 0 ? out * gate_scale : 0
     const float* gate;      // [M, ldg] or null
     int64_t ldg;
@@ -48,6 +52,7 @@ __device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, in
     if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
     else if (e.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     if (e.mask) v = e.mask[row * (int64_t)N + col] ? v * e.mask_scale : 0.f;
+    else if (e.drop_p > 0.f) v = ac::dropout_keep(e.drop_seed, (uint64_t)(row * (int64_t)N + col), e.drop_p) ? v * e.mask_scale : 0.f;
     if (e.residual) v += e.residual[row * e.ldr + col];
     if (e.gate) v = (e.gate[row * e.ldg + col] != 0.f) ? v * e.gate_scale : 0.f;
     return v;
@@ -299,7 +304,8 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         int tm = cost64 < cost128 ? 1 : 2;
         if (const char* e = getenv("AC_GEMM_TM")) { int v = atoi(e); if (v == 1 || v == 2) tm = v; }
         const int64_t nblk = tm == 2 ? b128 : b64;
-        const bool plain = epi.alpha == 1.f && epi.beta == 0.f && epi.bias && !epi.mask && !epi.gate;
+        const bool plain = epi.alpha == 1.f && epi.beta == 0.f && epi.bias && !epi.mask && !epi.gate &&
+                           epi.drop_p == 0.f;
         int cls = EPI_GENERIC;
         if (plain && !epi.residual && epi.act == ACT_NONE) cls = EPI_BIAS;
         else if (plain && !epi.residual && epi.act == ACT_GELU) cls = EPI_BIAS_GELU;
@@ -340,10 +346,11 @@ namespace ac {
 // internal entry used by head.hip / bert.hip
 int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
-               const uint8_t* mask, float mask_scale, hipStream_t stream) {
+               const uint8_t* mask, float mask_scale, hipStream_t stream, float drop_p, uint64_t drop_seed) {
     Epilogue e;
     e.bias = bias; e.residual = residual; e.ldr = ldr; e.act = act; e.alpha = 1.f; e.beta = 0.f;
     e.mask = mask; e.mask_scale = mask_scale; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f;
+    e.drop_p = mask ? 0.f : drop_p; e.drop_seed = drop_seed;
     return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream);
 }
 int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
@@ -352,6 +359,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const flo
     Epilogue e;
     e.bias = nullptr; e.residual = nullptr; e.ldr = 0; e.act = ACT_NONE; e.alpha = alpha; e.beta = beta;
     e.mask = nullptr; e.mask_scale = 1.f; e.gate = gate; e.ldg = ldg; e.gate_scale = gate_scale;
+    e.drop_p = 0.f; e.drop_seed = 0;
     return launch_gemm(transA == 0, transB != 0, A, lda, B, ldb, C, ldc, M, N, K, e, stream);
 }
 }  // namespace ac

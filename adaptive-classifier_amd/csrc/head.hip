@@ -29,7 +29,7 @@ HeadOffsets head_offsets(const ac_head_dims& d) {
 }
 
 struct HeadWs {
-    size_t a1, a2, z, dz, d2, d1, rowloss, total;
+    size_t a1, a2, z, dz, d2, d1, rowloss, xg, yg, scratch, total;
 };
 
 HeadWs head_ws(const ac_head_dims& d, int B) {
@@ -43,6 +43,9 @@ HeadWs head_ws(const ac_head_dims& d, int B) {
     w.d2 = take((size_t)B * d.H2);
     w.d1 = take((size_t)B * d.H1);
     w.rowloss = take((size_t)B);
+    w.xg = take((size_t)B * d.D);          // gathered batch (ac_head_train_step with an index)
+    w.yg = take((size_t)B * 2);            // int64 labels
+    w.scratch = take(AC_REDUCE_SCRATCH_BYTES / sizeof(float));
     w.total = off;
     return w;
 }
@@ -103,6 +106,47 @@ __global__ __launch_bounds__(256) void fisher_acc_kernel(const float* g, float i
     }
 }
 
+// batch gather: xg[b,:] = X[idx[b],:], yg[b] = y[idx[b]]  (DataLoader batch assembly, classifier.py:1485-1487)
+__global__ __launch_bounds__(256) void gather_batch_kernel(const float* X, int64_t ldx, const int64_t* y,
+                                                           const int64_t* idx, int B, int D, float* xg, int64_t* yg) {
+    const int b = blockIdx.x;
+    const int64_t r = idx[b];
+    for (int c = threadIdx.x; c < D; c += 256) xg[(size_t)b * D + c] = X[r * ldx + c];
+    if (threadIdx.x == 0) yg[b] = y[r];
+}
+
+// F.softmax(logits, dim=1) (classifier.py:435,1345), one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, int B, int C, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* zr = in + (size_t)b * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, zr[c]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += expf(zr[c] - mx);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+    for (int c = lane; c < C; c += 64) out[(size_t)b * C + c] = expf(zr[c] - mx) / sum;
+}
+
+// F.normalize(x, p=2, dim=1) with eps 1e-12 (classifier.py:1450), one wave per row
+__global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* in, int64_t ldi, int B, int D, float* out,
+                                                                int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* src = in + (size_t)b * ldi;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s = fmaf(src[c], src[c], s);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    const float nrm = fmaxf(sqrtf(s), 1e-12f);
+    for (int c = lane; c < D; c += 64) out[(size_t)b * ldo + c] = src[c] / nrm;
+}
+
 // ---- deterministic two-pass reductions over the flat parameter block ----
 constexpr int kRedBlocks = 256;
 
@@ -158,7 +202,8 @@ __global__ __launch_bounds__(256) void ewc_adamw_kernel(float* p, const float* g
                                                         float lam, float two_lam, float max_norm, float lr_wd,
                                                         float beta1, float beta2, float one_m_b1, float one_m_b2,
                                                         float eps, float step_size, float bc2_sqrt,
-                                                        const float* partials, float* out) {
+                                                        const float* partials, float* out, const float* ce_loss,
+                                                        float* loss_accum) {
     __shared__ float sh[4];
     float tg, te;
     reduce_partials(partials, sh, &tg, &te);
@@ -166,7 +211,10 @@ __global__ __launch_bounds__(256) void ewc_adamw_kernel(float* p, const float* g
     float coef = max_norm / (norm + 1e-6f);
     if (coef > 1.f) coef = 1.f;
     if (max_norm <= 0.f) coef = 1.f;          // max_norm <= 0 disables clipping
-    if (blockIdx.x == 0 && threadIdx.x == 0 && out) { out[0] = lam * te; out[1] = norm; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (out) { out[0] = lam * te; out[1] = norm; }
+        if (loss_accum) *loss_accum += (ce_loss ? *ce_loss : 0.f) + lam * te;   // total_loss += loss.item()
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float pi = p[i];
         float gi = g[i];
@@ -228,21 +276,14 @@ extern "C" int ac_head_forward(const ac_head_dims* dims, const float* d_params, 
     return ac::linear_f32(a2, d.H2, P + o.w3, d.H2, P + o.b3, nullptr, 0, d_logits, d.C, B, d.C, d.H2, 0, nullptr, 1.f, stream);
 }
 
-extern "C" int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_params, const float* d_X,
-                                  int64_t ldx, const int64_t* d_y, const uint8_t* d_mask1,
-                                  const uint8_t* d_mask2, float dropout_p, int B, float* d_loss,
-                                  float* d_grads, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
-    int rc = check_dims(dims);
-    if (rc) return rc;
-    hipStream_t stream = (hipStream_t)stream_;
-    AC_REQUIRE(d_params && d_X && d_y && d_loss && d_grads && B > 0 && ldx >= dims->D, AC_EINVAL,
-               "head_fwd_bwd_ce: bad arguments");
-    AC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, AC_EINVAL, "head_fwd_bwd_ce: dropout_p=%f", dropout_p);
-    const ac_head_dims& d = *dims;
+namespace {
+
+// forward (train mode) + CE + backward into G; masks either explicit (uint8, 1 = keep) or generated
+// in-kernel from `seed` when dropout_p > 0 and no mask is given with use_seed.
+int head_fwd_bwd(const ac_head_dims& d, const float* P, const float* X, int64_t ldx, const int64_t* y,
+                 const uint8_t* mask1, const uint8_t* mask2, float dropout_p, bool use_seed, uint64_t seed, int B,
+                 float* d_loss, float* G, char* ws, const HeadWs& w, hipStream_t stream) {
     const HeadOffsets o = head_offsets(d);
-    const HeadWs w = head_ws(d, B);
-    AC_REQUIRE(d_ws && ws_bytes >= w.total, AC_EWORKSPACE, "head_fwd_bwd_ce: workspace %zu < %zu", ws_bytes, w.total);
-    char* ws = (char*)d_ws;
     float* a1 = (float*)(ws + w.a1);
     float* a2 = (float*)(ws + w.a2);
     float* z = (float*)(ws + w.z);
@@ -250,19 +291,21 @@ extern "C" int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_param
     float* d2 = (float*)(ws + w.d2);
     float* d1 = (float*)(ws + w.d1);
     float* rowloss = (float*)(ws + w.rowloss);
-    const float* P = d_params;
-    float* G = d_grads;
+    const bool drop = dropout_p > 0.f && (use_seed || mask1 || mask2);
     const float scale = 1.f / (1.f - dropout_p);       // nn.Dropout(0.1), models.py:58
-    const float s1 = d_mask1 ? scale : 1.f, s2 = d_mask2 ? scale : 1.f;
-
+    const float s1 = (drop && (use_seed || mask1)) ? scale : 1.f;
+    const float s2 = (drop && (use_seed || mask2)) ? scale : 1.f;
+    const float p1 = (use_seed && !mask1) ? dropout_p : 0.f, p2 = (use_seed && !mask2) ? dropout_p : 0.f;
+    int rc;
     // forward (train mode): a = dropout(relu(x W^T + b))
-    rc = ac::linear_f32(d_X, ldx, P + o.w1, d.D, P + o.b1, nullptr, 0, a1, d.H1, B, d.H1, d.D, 1, d_mask1, s1, stream);
+    rc = ac::linear_f32(X, ldx, P + o.w1, d.D, P + o.b1, nullptr, 0, a1, d.H1, B, d.H1, d.D, 1, mask1, s1, stream, p1, seed);
     if (rc) return rc;
-    rc = ac::linear_f32(a1, d.H1, P + o.w2, d.H1, P + o.b2, nullptr, 0, a2, d.H2, B, d.H2, d.H1, 1, d_mask2, s2, stream);
+    rc = ac::linear_f32(a1, d.H1, P + o.w2, d.H1, P + o.b2, nullptr, 0, a2, d.H2, B, d.H2, d.H1, 1, mask2, s2, stream, p2,
+                        seed ^ 0xA5A5A5A5A5A5A5A5ull);
     if (rc) return rc;
     rc = ac::linear_f32(a2, d.H2, P + o.w3, d.H2, P + o.b3, nullptr, 0, z, d.C, B, d.C, d.H2, 0, nullptr, 1.f, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(1), dim3(256), 0, stream, z, d_y, B, d.C, dz, rowloss, d_loss);
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(1), dim3(256), 0, stream, z, y, B, d.C, dz, rowloss, d_loss);
     AC_LAUNCH_CHECK();
     // backward.  dW = dY^T A  (transA=1: dY stored [B,out] is the [K,M] layout), dA = dY W gated
     // by relu'/dropout (a != 0 ? scale : 0).
@@ -274,11 +317,106 @@ extern "C" int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_param
     if (rc) return rc;
     rc = ac::gemm_f32(0, 0, B, d.H1, d.H2, 1.f, d2, d.H2, P + o.w2, d.H1, 0.f, d1, d.H1, a1, d.H1, s1, stream);
     if (rc) return rc;
-    rc = ac::gemm_f32(1, 0, d.H1, d.D, B, 1.f, d1, d.H1, d_X, ldx, 0.f, G + o.w1, d.D, nullptr, 0, 1.f, stream);
+    rc = ac::gemm_f32(1, 0, d.H1, d.D, B, 1.f, d1, d.H1, X, ldx, 0.f, G + o.w1, d.D, nullptr, 0, 1.f, stream);
     if (rc) return rc;
     const int nb = d.H1 + d.H2 + d.C;
     hipLaunchKernelGGL(bias_grad_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, dz, d2, d1, B, d.C, d.H2,
                        d.H1, G + o.b3, G + o.b2, G + o.b1);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+int adamw_launch(float* p, const float* g, float* m, float* v, const float* F, const float* pold, int64_t n,
+                 float lam, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
+                 float* d_out, float* partials, const float* ce_loss, float* loss_accum, hipStream_t stream) {
+    const float two_lam = 2.f * lam;
+    hipLaunchKernelGGL(ewc_partials_kernel, dim3(kRedBlocks), dim3(256), 0, stream, p, g, F, pold, n, two_lam, partials);
+    AC_LAUNCH_CHECK();
+    // bias corrections in double like torch's Python floats (adamw single-tensor path)
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float lr_wd = (float)((double)lr * (double)wd);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ewc_adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, F, pold, n, lam,
+                       two_lam, max_norm, lr_wd, beta1, beta2, 1.f - beta1, 1.f - beta2, eps, step_size, bc2_sqrt,
+                       partials, d_out, ce_loss, loss_accum);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+}  // namespace
+
+extern "C" int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_params, const float* d_X,
+                                  int64_t ldx, const int64_t* d_y, const uint8_t* d_mask1,
+                                  const uint8_t* d_mask2, float dropout_p, int B, float* d_loss,
+                                  float* d_grads, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_REQUIRE(d_params && d_X && d_y && d_loss && d_grads && B > 0 && ldx >= dims->D, AC_EINVAL,
+               "head_fwd_bwd_ce: bad arguments");
+    AC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, AC_EINVAL, "head_fwd_bwd_ce: dropout_p=%f", dropout_p);
+    const HeadWs w = head_ws(*dims, B);
+    AC_REQUIRE(d_ws && ws_bytes >= w.total, AC_EWORKSPACE, "head_fwd_bwd_ce: workspace %zu < %zu", ws_bytes, w.total);
+    return head_fwd_bwd(*dims, d_params, d_X, ldx, d_y, d_mask1, d_mask2, dropout_p, false, 0, B, d_loss, d_grads,
+                        (char*)d_ws, w, stream);
+}
+
+extern "C" int ac_head_train_step(const ac_head_dims* dims, float* d_params, float* d_m, float* d_v, float* d_grads,
+                                  const float* d_X, int64_t ldx, const int64_t* d_y, const int64_t* d_index, int B,
+                                  float dropout_p, uint64_t dropout_seed, const float* d_fisher, const float* d_old,
+                                  float lambda_over_B, float max_grad_norm, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, int step, float* d_out, float* d_loss_accum,
+                                  void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_REQUIRE(d_params && d_m && d_v && d_grads && d_X && d_y && d_out && B > 0 && ldx >= dims->D && step >= 1,
+               AC_EINVAL, "head_train_step: bad arguments");
+    AC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, AC_EINVAL, "head_train_step: dropout_p=%f", dropout_p);
+    AC_REQUIRE((d_fisher == nullptr) == (d_old == nullptr), AC_EINVAL,
+               "head_train_step: fisher and old params must be given together");
+    const ac_head_dims& d = *dims;
+    const HeadWs w = head_ws(d, B);
+    AC_REQUIRE(d_ws && ws_bytes >= w.total, AC_EWORKSPACE, "head_train_step: workspace %zu < %zu", ws_bytes, w.total);
+    char* ws = (char*)d_ws;
+    const float* X = d_X;
+    const int64_t* y = d_y;
+    int64_t ld = ldx;
+    if (d_index) {       // assemble the batch on device: rows d_index[0..B) of the stored examples
+        float* xg = (float*)(ws + w.xg);
+        int64_t* yg = (int64_t*)(ws + w.yg);
+        hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, stream, d_X, ldx, d_y, d_index, B, d.D, xg, yg);
+        AC_LAUNCH_CHECK();
+        X = xg; y = yg; ld = d.D;
+    }
+    rc = head_fwd_bwd(d, d_params, X, ld, y, nullptr, nullptr, dropout_p, dropout_p > 0.f, dropout_seed, B, d_out, d_grads,
+                      ws, w, stream);
+    if (rc) return rc;
+    // d_out[0] = CE loss (written above); [1] = EWC penalty, [2] = grad norm
+    return adamw_launch(d_params, d_grads, d_m, d_v, d_fisher, d_old, head_offsets(d).total, lambda_over_B,
+                        max_grad_norm, lr, beta1, beta2, eps, weight_decay, step, d_out + 1, (float*)(ws + w.scratch),
+                        d_out, d_loss_accum, stream);
+}
+
+extern "C" int ac_softmax_rows(const float* d_in, int B, int C, float* d_out, ac_stream_t stream) {
+    AC_REQUIRE(d_in && d_out && B >= 0 && C >= 1, AC_EINVAL, "softmax_rows: bad arguments");
+    if (B == 0) return AC_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_in, B, C, d_out);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_l2_normalize_rows(const float* d_in, int64_t ldi, int B, int D, float* d_out, int64_t ldo,
+                                    ac_stream_t stream) {
+    AC_REQUIRE(d_in && d_out && B >= 0 && D >= 1 && ldi >= D && ldo >= D, AC_EINVAL, "l2_normalize_rows: bad arguments");
+    if (B == 0) return AC_OK;
+    hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_in, ldi, B, D,
+                       d_out, ldo);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
@@ -314,28 +452,10 @@ extern "C" int ac_ewc_adamw_step(float* d_params, const float* d_grads, float* d
                                  float max_grad_norm, float lr, float beta1, float beta2, float eps,
                                  float weight_decay, int step, float* d_out, void* d_scratch,
                                  ac_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     AC_REQUIRE(d_params && d_grads && d_m && d_v && d_scratch && n >= 0 && step >= 1, AC_EINVAL,
                "ewc_adamw_step: bad arguments");
     AC_REQUIRE((d_fisher == nullptr) == (d_old == nullptr), AC_EINVAL,
                "ewc_adamw_step: fisher and old params must be given together");
-    float* partials = (float*)d_scratch;
-    const float two_lam = 2.f * lambda_over_B;
-    hipLaunchKernelGGL(ewc_partials_kernel, dim3(kRedBlocks), dim3(256), 0, stream, d_params, d_grads, d_fisher,
-                       d_old, n, two_lam, partials);
-    AC_LAUNCH_CHECK();
-    // bias corrections in double like torch's Python floats (adamw single-tensor path)
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    const float lr_wd = (float)((double)lr * (double)weight_decay);
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(ewc_adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_params, d_grads, d_m, d_v,
-                       d_fisher, d_old, n, lambda_over_B, two_lam, max_grad_norm, lr_wd, beta1, beta2,
-                       1.f - beta1, 1.f - beta2, eps, step_size, bc2_sqrt, partials, d_out);
-    AC_LAUNCH_CHECK();
-    return AC_OK;
+    return adamw_launch(d_params, d_grads, d_m, d_v, d_fisher, d_old, n, lambda_over_B, max_grad_norm, lr, beta1, beta2,
+                        eps, weight_decay, step, d_out, (float*)d_scratch, nullptr, nullptr, (hipStream_t)stream_);
 }

@@ -163,6 +163,33 @@ int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_params,
 
 #define AC_REDUCE_SCRATCH_BYTES 8192
 
+/*
+ * One whole training step of classifier.py:1485-1507 / :329-353 in a single call:
+ * (optional) batch gather X[index], y[index] -> train-mode forward with in-kernel
+ * counter-based dropout (seed; no mask tensors) -> CE -> backward -> EWC gradient
+ * + clip_grad_norm_ + AdamW.  d_out[0] = CE loss, [1] = EWC penalty, [2] = grad
+ * norm; if d_loss_accum != NULL, *d_loss_accum += CE + penalty (the epoch's
+ * `total_loss += loss.item()` without a host sync).  d_grads: flat scratch for
+ * the gradients.  Workspace size: ac_head_workspace(dims, B).
+ */
+int ac_head_train_step(const ac_head_dims* dims, float* d_params, float* d_m,
+                       float* d_v, float* d_grads, const float* d_X, int64_t ldx,
+                       const int64_t* d_y, const int64_t* d_index, int B,
+                       float dropout_p, uint64_t dropout_seed,
+                       const float* d_fisher, const float* d_old,
+                       float lambda_over_B, float max_grad_norm, float lr,
+                       float beta1, float beta2, float eps, float weight_decay,
+                       int step, float* d_out, float* d_loss_accum,
+                       void* d_ws, size_t ws_bytes, ac_stream_t stream);
+
+/* F.softmax(logits, dim=1) over [B, C] rows (classifier.py:435,1345). */
+int ac_softmax_rows(const float* d_in, int B, int C, float* d_out,
+                    ac_stream_t stream);
+
+/* F.normalize(x, p=2, dim=1, eps=1e-12) over [B, D] rows (classifier.py:1450). */
+int ac_l2_normalize_rows(const float* d_in, int64_t ldi, int B, int D,
+                         float* d_out, int64_t ldo, ac_stream_t stream);
+
 /* ewc.py:90-92: fisher += grad^2 * inv_num_batches over the flat block. */
 int ac_fisher_accumulate(const float* d_grads, float inv_num_batches,
                          float* d_fisher, int64_t n, ac_stream_t stream);

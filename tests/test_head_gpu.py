@@ -182,3 +182,54 @@ def test_ewc_fisher_penalty_and_fused_step(cuda_dev):
 def test_ewc_generic_module_contract():
     """The EWC class on an arbitrary nn.Module (tests/test_ewc.py fixtures) -- runs on CPU."""
     pass
+
+
+def _dropout_keep_np(seed, n_rows, n_cols, p):
+    """numpy port of ac::dropout_keep (csrc/common.h): keep iff u(seed, row*N+col) >= p."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        idx = np.arange(n_rows * n_cols, dtype=np.uint64)
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u >= np.float32(p)).reshape(n_rows, n_cols)
+
+
+def test_softmax_and_normalize_rows(cuda_dev):
+    from adaptive_classifier.ops import l2_normalize_rows, softmax_rows
+    g = torch.Generator().manual_seed(0)
+    for B, C in [(1, 4), (37, 77), (256, 1000)]:
+        z = torch.randn(B, C, generator=g) * 3
+        assert (softmax_rows(z.to(cuda_dev)).cpu() - torch.softmax(z, 1)).abs().max().item() < 1e-6
+    x = torch.randn(33, 768, generator=g) * 5
+    x[3] = 0                                               # zero row: eps clamp, stays zero
+    got = l2_normalize_rows(x.to(cuda_dev)).cpu()
+    assert (got - torch.nn.functional.normalize(x, p=2, dim=1)).abs().max().item() < 1e-6
+
+
+def test_fused_train_step_with_in_kernel_dropout_and_gather(cuda_dev):
+    """ac_head_train_step: batch gather + counter-based dropout + CE + backward + clip + AdamW in one call
+    equals the oracle step fed with the same (reconstructed) masks and batch."""
+    from oracle import head_oracle
+    D, C, B, n = 768, 4, 32, 100
+    ref, opt, head, tr = _make_pair(D, C, cuda_dev)
+    Xall, yall = _data(n, D, C, seed=8)
+    Xd, yd = Xall.to(cuda_dev), yall.to(cuda_dev)
+    g = torch.Generator().manual_seed(3)
+    tr.loss_accum.zero_()
+    tot = 0.0
+    for step in range(3):
+        idx = torch.randperm(n, generator=g)[:B]
+        seed = 12345 + step
+        m1 = torch.from_numpy(_dropout_keep_np(seed, B, D, 0.1))
+        m2 = torch.from_numpy(_dropout_keep_np(seed ^ 0xA5A5A5A5A5A5A5A5, B, D // 2, 0.1))
+        ce, _, gn = head_oracle.train_step(ref, opt, Xall[idx], yall[idx], masks=[m1, m2])
+        out = tr.fused_step(Xd, yd, idx.to(cuda_dev), 0.1, seed)
+        assert abs(out[0].item() - ce) < TOL and abs(out[2].item() - gn) < TOL * max(1.0, gn)
+        assert (tr.flat.cpu() - head_oracle.flat(ref)).abs().max().item() < 2e-5
+        tot += ce
+    assert abs(tr.loss_accum.item() - tot) < 1e-3            # device-side epoch loss accumulation
+    # keep-rate of the counter-based masks is ~0.9
+    assert abs(_dropout_keep_np(1, 512, 768, 0.1).mean() - 0.9) < 0.005
