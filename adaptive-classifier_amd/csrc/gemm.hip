@@ -289,12 +289,104 @@ __global__ __launch_bounds__(256) void gemm_direct(const float* __restrict__ A, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// small-M NT kernel (M <= 64): weight streaming.  out[m][n] = sum_k X[m][k] W[n][k] is computed as
+// (W rows) x (X^T) on v_mfma_f32_16x16x4_f32: the A operand is 16 rows of W straight from HBM
+// (float4 per lane, 16 rows x 64 B per wave load, exactly the kNN sweep's access shape), the B operand
+// the <= 64 activation rows (L2-resident).  One block = 16 output columns, its 8 waves split K and are
+// reduced through LDS in a fixed order.  With M this small the GEMM is bound by streaming W once, so
+// parallelism over (N/16 blocks) x (8 waves) and loads-in-flight matter, not MFMA efficiency.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSmWaves = 8;
+// k-blocks (16 columns each) per register buffer; two buffers of (1 + J) float4 per k-block
+template <int J> struct SmGroup { static constexpr int value = (J >= 4) ? 3 : 6; };
+
+template <int J>
+__global__ __launch_bounds__(kSmWaves * 64) void gemm_smallm_nt(const float* __restrict__ X, int64_t ldx,
+                                                                 const float* __restrict__ W, int64_t ldw,
+                                                                 float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                                 Epilogue epi) {
+    __shared__ float red[kSmWaves][J][4][64];
+    constexpr int kSmGroup = SmGroup<J>::value;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int i = lane & 15, h = lane >> 4;
+    int wrow = n0 + i; if (wrow > N - 1) wrow = N - 1;
+    const float* wp = W + (int64_t)wrow * ldw + 4 * h;
+    const float* xp[J];
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+        int m = 16 * jj + i; if (m > M - 1) m = M - 1;
+        xp[jj] = X + (int64_t)m * ldx + 4 * h;
+    }
+    const int nkb = (K + 15) / 16;
+    const int kb_lo = (int)(((int64_t)wave * nkb) / kSmWaves), kb_hi = (int)(((int64_t)(wave + 1) * nkb) / kSmWaves);
+    f32x4 acc[J];
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 wa[2][kSmGroup], xb[2][kSmGroup][J];
+    // loads are unconditional: k-blocks past the wave's range / past K re-read column K-4 and are
+    // zeroed when consumed (keeps hipcc's vmcnt accounting exact, cf. knn_l2.hip)
+#define AC_SM_LOAD(Bf, kb0)                                                              \
+    _Pragma("unroll") for (int u = 0; u < kSmGroup; ++u) {                               \
+        int col = ((kb0) + u) * 16;                                                      \
+        if (col + 4 * h > K - 4) col = K - 4 - 4 * h;                                    \
+        wa[Bf][u] = *reinterpret_cast<const f32x4*>(wp + col);                           \
+        _Pragma("unroll") for (int jj = 0; jj < J; ++jj)                                 \
+            xb[Bf][u][jj] = *reinterpret_cast<const f32x4*>(xp[jj] + col);               \
+    }
+#define AC_SM_COMPUTE(Bf, kb0)                                                           \
+    _Pragma("unroll") for (int u = 0; u < kSmGroup; ++u) {                               \
+        const bool ok = ((kb0) + u) < kb_hi && (((kb0) + u) * 16 + 4 * h) < K;           \
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};                                         \
+        const f32x4 a = ok ? wa[Bf][u] : zero;                                           \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                    \
+            _Pragma("unroll") for (int jj = 0; jj < J; ++jj)                             \
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[Bf][u][jj][s], acc[jj], 0, 0, 0); \
+    }
+    if (kb_lo < kb_hi) {
+        AC_SM_LOAD(0, kb_lo);
+        for (int kb = kb_lo; kb < kb_hi; kb += 2 * kSmGroup) {
+            AC_SM_LOAD(1, kb + kSmGroup);
+            __builtin_amdgcn_sched_barrier(0);
+            AC_SM_COMPUTE(0, kb);
+            __builtin_amdgcn_sched_barrier(0);
+            AC_SM_LOAD(0, kb + 2 * kSmGroup);
+            __builtin_amdgcn_sched_barrier(0);
+            AC_SM_COMPUTE(1, kb + kSmGroup);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef AC_SM_LOAD
+#undef AC_SM_COMPUTE
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][jj][r][lane] = acc[jj][r];
+    __syncthreads();
+    // J*256 outputs (16 n x 16*J m); C/D layout: n = n0 + 4*(l>>4) + r, m = 16*jj + (l & 15)
+    for (int o = tid; o < J * 256; o += kSmWaves * 64) {
+        const int jj = o >> 8, r = (o >> 6) & 3, l = o & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kSmWaves; ++w) v += red[w][jj][r][l];
+        const int m = 16 * jj + (l & 15), n = n0 + 4 * (l >> 4) + r;
+        if (m < M && n < N) C[(int64_t)m * ldc + n] = apply_epilogue(epi, v, m, n, C, ldc, N);
+    }
+}
+
 static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, const float* B, int64_t ldb,
                        float* C, int64_t ldc, int M, int N, int K, const Epilogue& epi, hipStream_t stream) {
     if (M <= 0 || N <= 0) return AC_OK;
     const bool aligned = ((lda & 3) == 0) && ((ldb & 3) == 0) && ((((uintptr_t)A) & 15) == 0) &&
                          ((((uintptr_t)B) & 15) == 0);
-    if (a_kmaj && b_kmaj && aligned && M >= 192 && K >= BK && (K % BK) == 0) {
+    if (a_kmaj && b_kmaj && aligned && M <= 64 && K >= 8 && (K % 4) == 0 && N >= 16) {
+        const dim3 grid((N + 15) / 16), block(kSmWaves * 64);
+        if (M <= 16) hipLaunchKernelGGL((gemm_smallm_nt<1>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
+        else if (M <= 32) hipLaunchKernelGGL((gemm_smallm_nt<2>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
+        else hipLaunchKernelGGL((gemm_smallm_nt<4>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
+    } else if (a_kmaj && b_kmaj && aligned && M >= 192 && K >= BK && (K % BK) == 0) {
         // pick the M-tile that wastes fewer CU-rounds: cost = rounds * (tile rows) * (resident blocks)
         const int cus = ac::dev_info().cus;
         const int64_t ntn = (N + BN - 1) / BN;

@@ -59,3 +59,11 @@ for _ in range(5): head_oracle.train_step(ref, opt, Xc, yc)
 t0 = time.perf_counter()
 for _ in range(50): head_oracle.train_step(ref, opt, Xc, yc)
 print(f"torch CPU reference step: {(time.perf_counter()-t0)/50*1e6:.0f} us/step")
+tr.loss_accum.zero_()
+Xall = torch.from_numpy(synth.synth_unit_rows(4000, 768, 6)).to(dev); yall = (torch.arange(4000) % 4).to(dev)
+order = torch.randperm(4000).to(dev)
+for i in range(20): tr.fused_step(Xall, yall, order[(i % 100) * 32:(i % 100) * 32 + 32], 0.1, i)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(n): tr.fused_step(Xall, yall, order[(i % 100) * 32:(i % 100) * 32 + 32], 0.1, i)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print(f"fused train step (gather + in-kernel dropout, one call): {dt*1e6:.1f} us/step = {1/dt:.0f} steps/s")
