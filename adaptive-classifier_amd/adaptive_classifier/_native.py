@@ -11,7 +11,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libacamd.so")
+_LIB_PATH = os.environ.get("AC_LIBACAMD_PATH") or os.path.join(_HERE, "libacamd.so")   # env override: A/B experiments only
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _lib = None
 

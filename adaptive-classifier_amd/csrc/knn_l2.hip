@@ -246,9 +246,9 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) acc[jj] = S::mfma(nsq, 1.0f, acc[jj]);
         // row norm for the error-bound certificate
-        float rn = nsq;
-#pragma unroll
-        for (int o = S::ROWS; o < 64; o <<= 1) rn += __shfl_xor(rn, o);
+        float rn = nsq;                     // lanes i, i+16, i+32, i+48 hold the 4 k-slices of row i
+        rn += __shfl_xor(rn, 16);
+        rn += __shfl_xor(rn, 32);
         wave_maxnorm = fmaxf(wave_maxnorm, rn);
 
         const int64_t row_base = (cur_tile * prm.G + g) * (int64_t)(kWaves * S::ROWS) + wave * S::ROWS;
