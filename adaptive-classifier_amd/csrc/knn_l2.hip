@@ -294,8 +294,8 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
                                    prm.cap, prm.kp, lane);
             }
             __syncthreads();
-#pragma unroll
-            for (int jj = 0; jj < J; ++jj) tau[jj] = tau_s[16 * jj + j];
+            tau[0] = tau_s[j];
+            if (J > 1) tau[J - 1] = tau_s[16 * (J - 1) + j];     // J is 1 or 2
             pend = true;   // re-test un-pushed entries against the tightened tau
         }
         nsq = 0.f;
