@@ -448,7 +448,7 @@ class AdaptiveClassifier:
         cfg = {"model_name": self.model.config._name_or_path, "embedding_dim": self.embedding_dim,
                "label_to_id": self.label_to_id, "id_to_label": {str(k): v for k, v in self.id_to_label.items()},
                "train_steps": self.train_steps, "training_history": self.training_history,
-               "config": self.config.to_dict()}
+               "config": self.config.to_dict(), "library_name": "adaptive-classifier"}
         (d / "config.json").write_text(json.dumps(cfg, indent=2))
         ex = {label: [e.to_dict() for e in exs] for label, exs in self.memory.examples.items()}
         (d / "examples.json").write_text(json.dumps(ex))
@@ -458,19 +458,42 @@ class AdaptiveClassifier:
                 tensors[f"adaptive_head_{key}"] = value.detach().cpu().contiguous()
         save_file(tensors, str(d / "model.safetensors"))
 
+    _save_pretrained = save
+
+    @classmethod
+    def load(cls, save_dir: str, device: Optional[str] = None, use_onnx: Optional[Union[bool, str]] = "auto",
+             prefer_quantized: bool = True, trust_remote_code: bool = False, *, encoder=None, tokenizer=None):
+        """classifier.py:1200-1213 / _from_pretrained :631-915: build a classifier for the saved model_name
+        and restore its state.  `encoder` / `tokenizer` may be passed to skip the HF download (offline use)."""
+        cfg = json.loads((Path(save_dir) / "config.json").read_text())
+        clf = cls(cfg["model_name"], device=device, config=cfg.get("config"), use_onnx=use_onnx,
+                  trust_remote_code=trust_remote_code, encoder=encoder, tokenizer=tokenizer)
+        return clf.load_state(save_dir)
+
+    _from_pretrained = load
+
     def load_state(self, save_dir: str):
-        """Restore labels, examples, prototypes and head from a directory written by save() or by the
-        reference's _save_pretrained (same keys, classifier.py:764-915)."""
+        """Restore labels, examples, prototypes and head from a directory written by save(), by the
+        reference's _save_pretrained (config.json + examples.json + model.safetensors, classifier.py:524-628)
+        or in the reference's older layout (examples inline in config.json + tensors.safetensors, as in its
+        scripts/adaptive_router fixture)."""
         from safetensors.torch import load_file
         d = Path(save_dir)
         cfg = json.loads((d / "config.json").read_text())
         self.label_to_id = dict(cfg["label_to_id"])
         self.id_to_label = {int(k): v for k, v in cfg["id_to_label"].items()}
         self.train_steps = cfg.get("train_steps", 0)
-        tensors = load_file(str(d / "model.safetensors"))
+        tfile = d / "model.safetensors"
+        if not tfile.exists():
+            tfile = d / "tensors.safetensors"
+        tensors = load_file(str(tfile))
+        if (d / "examples.json").exists():
+            saved = json.loads((d / "examples.json").read_text())
+        else:
+            saved = cfg.get("examples", {})
         self.memory.clear()
         saved_counts = {}
-        for label, exs in json.loads((d / "examples.json").read_text()).items():
+        for label, exs in saved.items():
             self.memory.examples[label] = [Example.from_dict(e) for e in exs]
             saved_counts[label] = len(exs)
         for label in self.label_to_id:

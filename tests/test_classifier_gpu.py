@@ -261,3 +261,30 @@ def test_continuous_learning_loop_scaled(cuda_dev):
         want = [f"c{i % (C + 1)}" if i % (C + 1) < C else "zzz_new" for i in range(30)]
         acc = np.mean([p[0][0] == w for p, w in zip(c.predict_embeddings(test, k=2), want)])
         assert acc >= 0.8, (mode, acc)
+
+
+def test_load_classmethod_and_legacy_layout(clf, tmp_path, cuda_dev):
+    """N1: directories in the reference's current layout (config.json + examples.json + model.safetensors)
+    and in its older one (examples inline + tensors.safetensors, as scripts/adaptive_router) both load."""
+    import json
+    import shutil
+    from adaptive_classifier import AdaptiveClassifier
+    cur = tmp_path / "cur"
+    clf.save(str(cur))
+    cfg = json.loads((cur / "config.json").read_text())
+    assert cfg["library_name"] == "adaptive-classifier" and cfg["embedding_dim"] == 128
+    a = AdaptiveClassifier.load(str(cur), device="cuda:0", encoder=clf.model, tokenizer=HashTokenizer())
+    old = tmp_path / "old"
+    old.mkdir()
+    cfg["examples"] = json.loads((cur / "examples.json").read_text())
+    cfg.pop("training_history")
+    (old / "config.json").write_text(json.dumps(cfg))
+    shutil.copy(cur / "model.safetensors", old / "tensors.safetensors")
+    b = AdaptiveClassifier.load(str(old), device="cuda:0", encoder=clf.model, tokenizer=HashTokenizer())
+    assert b.training_history == {l: 20 * 3 for l in ("positive", "negative", "neutral")}      # :909-913 estimate
+    for t in ["really great product", "awful thing"]:
+        want = clf.predict_batch([t], k=3)[0]
+        for other in (a, b):
+            got = other.predict_batch([t], k=3)[0]        # predict_batch weights do not depend on history
+            assert [l for l, _ in got] == [l for l, _ in want]
+            assert np.allclose([s for _, s in got], [s for _, s in want], atol=1e-6)
