@@ -293,11 +293,7 @@ class AdaptiveClassifier:
             S = Cid = probs = None
             if self.memory.index.ntotal > 0 or self.memory.updates_since_rebuild >= self.config.prototype_update_frequency:
                 S, I, _ = self.memory.search_batch(emb, k_proto)
-                lut = self.memory.row_class_ids(self.label_to_id, S.device)
-                if lut.numel() == 0:
-                    S = None
-                else:
-                    Cid = torch.where(I >= 0, lut[I.clamp(min=0) % lut.numel()], torch.full_like(I, -1))
+                Cid = self.memory.hit_class_ids(I, self.label_to_id)
             if self.adaptive_head is not None:
                 self.adaptive_head.eval()
                 probs = softmax_rows(self.adaptive_head.forward_native(emb))

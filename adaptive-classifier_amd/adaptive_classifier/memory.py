@@ -209,20 +209,27 @@ class PrototypeMemory:
             D, I = self.index.search_device(queries, k)
             return proto_scores(D, I), I, D
 
-    def row_class_ids(self, label_to_id: Dict[str, int], device):
-        """int64 [N] device tensor: classifier class id of every index row (-1 = unknown label).
-        Cached for the generalised store (N can be 10^7)."""
+    def hit_class_ids(self, I: torch.Tensor, label_to_id: Dict[str, int]) -> torch.Tensor:
+        """Classifier class id of every hit row id in I [b, k] (-1 = padding / unknown label), on device,
+        one native launch (`ac_rows_to_class`)."""
+        dev = I.device
         if self._row_labels is not None:
-            key = tuple(label_to_id.get(n, -1) for n in self._row_label_names)
-            cached = getattr(self, "_row_class_cache", None)
-            if cached is None or cached[0] != key or cached[1].device != torch.device(device):
-                lut = torch.tensor(key, dtype=torch.int64, device=device)
-                cached = (key, lut[self._row_labels.to(device).long()])
-                self._row_class_cache = cached
-            return cached[1]
-        n = self.index.ntotal
-        return torch.tensor([label_to_id.get(self.index_to_label[i], -1) for i in range(n)], dtype=torch.int64,
-                            device=device)
+            names, row_class, nrows = self._row_label_names, self._row_labels, int(self._row_labels.numel())
+        else:
+            n = self.index.ntotal
+            names, row_class, nrows = [self.index_to_label[i] for i in range(n)], None, n
+        key = tuple(label_to_id.get(nm, -1) for nm in names)
+        cached = getattr(self, "_class_lut_cache", None)
+        if cached is None or cached[0] != key or cached[1].device != dev:
+            cached = (key, torch.tensor(key if key else (-1,), dtype=torch.int64, device=dev))
+            self._class_lut_cache = cached
+        lut = cached[1]
+        I = I.contiguous()
+        out = torch.empty_like(I)
+        with torch.cuda.device(dev):
+            nv.check(nv.lib().ac_rows_to_class(nv.ptr(I), I.numel(), nv.ptr(row_class), nrows, nv.ptr(lut),
+                                               len(key), nv.ptr(out), nv.stream_ptr(dev)), "ac_rows_to_class")
+        return out
 
     # ------------------------------------------------------------------ misc API
     def get_stats(self) -> Dict[str, Any]:

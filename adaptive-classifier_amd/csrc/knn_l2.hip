@@ -716,6 +716,22 @@ __global__ __launch_bounds__(64) void proto_scores_kernel(const float* D, const 
     }
 }
 
+// row ids of the hits -> class ids through the row->class map (index_to_label, memory.py:123,174;
+// generalised int32 map of SURVEY 8a M6); padding (id < 0) and out-of-range ids give -1
+__global__ __launch_bounds__(256) void rows_to_class_kernel(const int64_t* I, int64_t n, const int32_t* row_class,
+                                                            int64_t nrows, const int64_t* class_lut, int nlut,
+                                                            int64_t* out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int64_t id = I[t];
+    int64_t c = -1;
+    if (id >= 0 && id < nrows) {
+        c = row_class ? (int64_t)row_class[id] : id;
+        if (class_lut) c = (c >= 0 && c < nlut) ? class_lut[c] : -1;
+    }
+    out[t] = c;
+}
+
 // ---- host-side planning ----
 struct Plan {
     int TQ, kp, cap, ng, Dp, G, nqt;
@@ -892,6 +908,16 @@ extern "C" int ac_topk_merge(const float* d_D_in, const int64_t* d_I_in, int sha
     (void)hipFuncSetAttribute((const void*)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(256), lds, stream, d_D_in, d_I_in, shards, nq, k,
                        d_outD, d_outI);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_rows_to_class(const int64_t* d_I, int64_t n, const int32_t* d_row_class, int64_t nrows,
+                                const int64_t* d_class_lut, int nlut, int64_t* d_out, ac_stream_t stream_) {
+    AC_REQUIRE(d_I && d_out && n >= 0 && nrows >= 0, AC_EINVAL, "rows_to_class: bad arguments");
+    if (n == 0) return AC_OK;
+    hipLaunchKernelGGL(rows_to_class_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                       d_I, n, d_row_class, nrows, d_class_lut, nlut, d_out);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

@@ -106,6 +106,17 @@ int ac_topk_merge(const float* d_D_in, const int64_t* d_I_in, int shards,
 int ac_proto_scores(const float* d_D, const int64_t* d_I, int nq, int k,
                     float* d_out, ac_stream_t stream);
 
+/*
+ * Hit row ids -> class ids (index_to_label lookup, memory.py:121-125, batched):
+ *   c = d_row_class ? d_row_class[id] : id ;  out = d_class_lut ? d_class_lut[c] : c
+ * ids < 0 (padding) or >= nrows give -1.  d_row_class int32 [nrows] (generalised
+ * store, several rows per class) may be NULL (one row per class, row == prototype
+ * index); d_class_lut int64 [nlut] maps memory label index -> classifier class id.
+ */
+int ac_rows_to_class(const int64_t* d_I, int64_t n, const int32_t* d_row_class,
+                     int64_t nrows, const int64_t* d_class_lut, int nlut,
+                     int64_t* d_out, ac_stream_t stream);
+
 /* Deterministic synthetic rows: row r, col c = unit-normalised
  * N(0,1) from a counter-based generator keyed on (seed, row_offset + r, c).
  * Bit-identical to oracle/synth.py.  d_out [n, ld] fp32. */
