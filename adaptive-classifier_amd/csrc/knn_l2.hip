@@ -29,6 +29,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -732,8 +733,63 @@ __global__ __launch_bounds__(256) void rows_to_class_kernel(const int64_t* I, in
     out[t] = c;
 }
 
+// --------------------------------------------------------------------------------------
+// small-store exact path: N <= kSmallN rows, ANY k <= N and ANY D.  The reference searches with
+// k = #classes (classifier.py:424-425), so k can exceed the fused sweep's limit while N (= #classes,
+// one prototype per class) stays tiny.  One block per query: fp64 distance of every row, full bitonic
+// sort of (distance, id) in LDS, emit the first k.  Exact by construction (no certificate needed).
+// --------------------------------------------------------------------------------------
+constexpr int kSmallN = 8192;
+constexpr int kSmallThreads = 256;
+
+__global__ __launch_bounds__(kSmallThreads) void knn_small_exact(MergeParams prm, int npow2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ds = reinterpret_cast<double*>(smem);                // [npow2]
+    int32_t* is = reinterpret_cast<int32_t*>(ds + npow2);        // [npow2]
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* qv = prm.Q + (size_t)q * prm.ldQ;
+    for (int r = tid; r < npow2; r += kSmallThreads) {
+        double a = INFINITY;
+        if (r < prm.N) {
+            const float* p = prm.P + (size_t)r * prm.ldP;
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            int c = 0;
+            for (; c + 3 < prm.D; c += 4) {
+                const double e0 = (double)p[c] - (double)qv[c], e1 = (double)p[c + 1] - (double)qv[c + 1];
+                const double e2 = (double)p[c + 2] - (double)qv[c + 2], e3 = (double)p[c + 3] - (double)qv[c + 3];
+                a0 = fma(e0, e0, a0); a1 = fma(e1, e1, a1); a2 = fma(e2, e2, a2); a3 = fma(e3, e3, a3);
+            }
+            for (; c < prm.D; ++c) { const double e = (double)p[c] - (double)qv[c]; a0 = fma(e, e, a0); }
+            a = (a0 + a1) + (a2 + a3);
+        }
+        ds[r] = a;
+        is[r] = r < prm.N ? r : 0x7fffffff;
+    }
+    __syncthreads();
+    for (int size = 2; size <= npow2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (npow2 >> 1); t += kSmallThreads) {
+                const int lo = 2 * t - (t & (stride - 1));       // index with bit `stride` cleared
+                const int hi = lo + stride;
+                const bool asc = (lo & size) == 0;
+                const double dl = ds[lo], dh = ds[hi];
+                const int32_t il = is[lo], ih = is[hi];
+                const bool gt = dl > dh || (dl == dh && il > ih);
+                if (gt == asc) { ds[lo] = dh; ds[hi] = dl; is[lo] = ih; is[hi] = il; }
+            }
+            __syncthreads();
+        }
+    for (int t = tid; t < prm.k; t += kSmallThreads) {
+        const bool real = t < prm.N;
+        prm.outD[(size_t)q * prm.k + t] = real ? (float)ds[t] : FLT_MAX;
+        prm.outI[(size_t)q * prm.k + t] = real ? (int64_t)is[t] + prm.row_offset : -1;
+    }
+}
+
 // ---- host-side planning ----
 struct Plan {
+    bool small;          // knn_small_exact instead of the fused sweep
+    int small_pow2;
     int TQ, kp, cap, ng, Dp, G, nqt;
     int64_t ntiles;
     size_t sweep_lds, merge_lds, fb_lds;
@@ -744,13 +800,32 @@ static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
     AC_REQUIRE(N >= 0 && N < 2147483647LL, AC_EINVAL, "knn: N=%lld out of range", (long long)N);
-    AC_REQUIRE(D >= 1 && nq >= 0, AC_EINVAL, "knn: bad D=%d nq=%d", D, nq);
-    AC_REQUIRE(k >= 1 && k <= AC_KNN_MAX_K, AC_EUNSUPPORTED,
-               "knn: k=%d outside the fused sweep's range [1,%d]", k, AC_KNN_MAX_K);
+    AC_REQUIRE(D >= 1 && nq >= 0 && k >= 1, AC_EINVAL, "knn: bad D=%d nq=%d k=%d", D, nq, k);
+    pl->small = false;
+    pl->Dp = (D + 3) / 4 * 4;
+    {   // does the fused sweep cover (D, k)?  LDS: one 16-query tile + its candidate lists
+        const int kp = k + kPad;
+        int cap = next_pow2(2 * kp);
+        if (cap < 64) cap = 64;
+        const int ng = (pl->Dp + 16 * kGroup - 1) / (16 * kGroup);
+        const size_t lds16 = (size_t)ng * kGroup * 64 * 16 + (size_t)16 * cap * 8 + 16 * 8 + kWaves * 4 + 64;
+        if (k > AC_KNN_MAX_K || lds16 > (size_t)kLdsLimit) {
+            AC_REQUIRE(N <= kSmallN, AC_EUNSUPPORTED,
+                       "knn: k=%d, D=%d is outside the fused sweep (k <= %d, query tile + lists <= %d B of LDS) and "
+                       "N=%lld exceeds the small-store path (N <= %d)", k, D, AC_KNN_MAX_K, kLdsLimit, (long long)N,
+                       kSmallN);
+            pl->small = true;
+            pl->small_pow2 = next_pow2((int)(N > 2 ? N : 2));
+            pl->TQ = 16; pl->kp = 0; pl->cap = 0; pl->ng = 0; pl->G = 1; pl->nqt = 1; pl->ntiles = 0;
+            pl->sweep_lds = pl->merge_lds = pl->fb_lds = 0;
+            pl->off_part_d = pl->off_part_i = pl->off_maxnorm = pl->off_flags = pl->off_zeros = 0;
+            pl->total = 256;
+            return AC_OK;
+        }
+    }
     pl->kp = k + kPad;
     pl->cap = next_pow2(2 * pl->kp);
     if (pl->cap < 64) pl->cap = 64;
-    pl->Dp = (D + 3) / 4 * 4;
     int TQ = nq > 16 ? 32 : 16;
     for (;;) {
         const int kcols = 16;
@@ -843,6 +918,17 @@ extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, c
     }
     char* ws = (char*)d_ws;
     if (d_stats) AC_HIP_CHECK(hipMemsetAsync(d_stats, 0, 4 * sizeof(int32_t), stream));
+    if (pl.small) {
+        MergeParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.P = d_P; sp.N = N; sp.ldP = ldP; sp.Q = d_Q; sp.ldQ = ldQ; sp.D = D; sp.k = k; sp.row_offset = row_offset;
+        sp.outD = d_outD; sp.outI = d_outI;
+        const size_t lds = (size_t)pl.small_pow2 * 12;
+        (void)hipFuncSetAttribute((const void*)knn_small_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(knn_small_exact, dim3(nq), dim3(kSmallThreads), lds, stream, sp, pl.small_pow2);
+        AC_LAUNCH_CHECK();
+        return AC_OK;
+    }
 
     MergeParams mp;
     mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = pl.Dp;

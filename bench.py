@@ -81,7 +81,7 @@ def predict_step(clf, ids, types, mask):
 
 def time_stages(clf, ids, types, mask, reps=5):
     """HIP-event timing of the device stages of one step (current stream)."""
-    from adaptive_classifier import index as ix
+    from adaptive_classifier.ops import softmax_rows
     ev = lambda: torch.cuda.Event(enable_timing=True)
     out = {}
     e = [ev() for _ in range(4)]
@@ -92,7 +92,7 @@ def time_stages(clf, ids, types, mask, reps=5):
         e[1].record()
         S, I, D = clf.memory.search_batch(emb, KNN_K)
         e[2].record()
-        probs = torch.softmax(clf.adaptive_head.forward_native(emb), dim=1)
+        probs = softmax_rows(clf.adaptive_head.forward_native(emb))
         e[3].record()
         torch.cuda.synchronize()
         tot += [e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])]

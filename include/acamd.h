@@ -45,7 +45,10 @@ int ac_device_info(int* cu_count, int* lds_bytes_per_block, size_t* hbm_bytes);
  *  M: PrototypeMemory kNN  (faiss.IndexFlatL2.search, memory.py:114)
  * ------------------------------------------------------------------------- */
 
-/* Limits of the fused sweep (ac_knn_l2_topk): k <= AC_KNN_MAX_K. */
+/* Limit of the fused sweep: k <= AC_KNN_MAX_K (and a 16-query tile of width D plus its
+ * candidate lists must fit the 160 KB LDS, D <~ 2000).  Outside it ac_knn_l2_topk uses an exact
+ * small-store path (any k, any D) when N <= 8192 -- the reference's own regime, one prototype per
+ * class searched with k = #classes (classifier.py:424-425) -- and returns AC_EUNSUPPORTED otherwise. */
 #define AC_KNN_MAX_K 248
 
 /* Bytes of scratch ac_knn_l2_topk needs for this problem size. */

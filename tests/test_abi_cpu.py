@@ -32,9 +32,11 @@ def test_workspace_planners_and_validation_without_gpu():
     b = ctypes.c_size_t(0)
     assert L.ac_knn_l2_topk_workspace(10_000_000, 768, 4096, 32, ctypes.byref(b)) == 0 and b.value > 0
     assert L.ac_knn_l2_topk_workspace(100, 768, 8, 4, ctypes.byref(b)) == 0
-    assert L.ac_knn_l2_topk_workspace(100, 768, 8, 1000, ctypes.byref(b)) == -2          # k beyond the fused sweep
+    assert L.ac_knn_l2_topk_workspace(100, 768, 8, 1000, ctypes.byref(b)) == 0           # small store: exact path, any k
+    assert L.ac_knn_l2_topk_workspace(100, 4096, 8, 8, ctypes.byref(b)) == 0              # ... and any D
+    assert L.ac_knn_l2_topk_workspace(100000, 768, 8, 1000, ctypes.byref(b)) == -2        # big store + k beyond the sweep
     assert b"k=1000" in L.ac_last_error()
-    assert L.ac_knn_l2_topk_workspace(100, 4096, 8, 8, ctypes.byref(b)) == -2            # D too wide for LDS
+    assert L.ac_knn_l2_topk_workspace(100000, 4096, 8, 8, ctypes.byref(b)) == -2          # big store + D too wide for LDS
     dims = nv.ac_head_dims(768, 768, 384, 4)
     assert L.ac_head_param_count(ctypes.byref(dims)) == 887428                            # P at C = 4
     assert L.ac_head_workspace(ctypes.byref(dims), 32, ctypes.byref(b)) == 0 and b.value > 0

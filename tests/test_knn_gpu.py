@@ -49,6 +49,10 @@ def _check(P, Q, k, cuda_dev, row_offset=0):
     (999, 770, 7, 9),        # D % 4 != 0 (zero padded ld)
     (20000, 768, 256, 16),
     (300, 64, 40, 200),      # large k -> TQ=16, cap 512
+    (300, 64, 40, 300),      # k > 248 = #classes-style search: small-store exact path
+    (1000, 768, 5, 1000),    # k = N, full ordering of 1000 prototypes
+    (500, 4096, 3, 10),      # D too wide for the LDS query tile: small-store exact path
+    (10, 768, 2, 300),       # small-store path with k > N (padding)
 ])
 def test_knn_matches_oracle(N, D, nq, k, cuda_dev):
     from oracle import synth
