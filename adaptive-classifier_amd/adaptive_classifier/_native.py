@@ -71,8 +71,13 @@ _SIGNATURES = {
     "ac_head_fwd_bwd_ce": (c_int, [ctypes.POINTER(ac_head_dims), c_void_p, c_void_p, c_int64, c_void_p,
                                    c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
+    "ac_head_fwd_bwd_loss": (c_int, [ctypes.POINTER(ac_head_dims), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_int64, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
+    "ac_sigmoid": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "ac_head_train_step": (c_int, [ctypes.POINTER(ac_head_dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_int64, c_void_p, c_void_p, c_int, c_float, c_uint64, c_void_p, c_void_p,
+                                   c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_float, c_uint64,
+                                   c_void_p, c_void_p,
                                    c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "ac_softmax_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -160,7 +160,10 @@ class AdaptiveClassifier:
         return torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True,
                                            generator=torch.Generator().manual_seed(42))
 
-    def _run_epochs(self, X, y, batch_size, epochs, use_scheduler, ewc=None, lambda_B=None):
+    LOSS_KIND = 0            # AC_LOSS_CE; the multi-label subclass trains new classes with CE on sigmoid outputs
+
+    def _run_epochs(self, X, y, batch_size, epochs, use_scheduler, ewc=None, lambda_B=None, loss_kind=None,
+                    targets=None):
         """Shared epoch loop: native steps, device-side loss accumulation, one sync per epoch."""
         head = self.adaptive_head
         head.train()
@@ -173,7 +176,8 @@ class AdaptiveClassifier:
         best_loss, patience, patience_counter = float("inf"), 3, 0
         steps = 0
         X = X.contiguous()
-        y = y.contiguous()
+        y = None if y is None else y.contiguous()
+        loss_kind = self.LOSS_KIND if loss_kind is None else loss_kind
         # dropout masks are generated in-kernel from (seed, step): counter-based, reproducible per
         # classifier seed; the reference draws them from torch's global generator (not replayable)
         base_seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self.train_steps * 1000003) & 0x7FFFFFFFFFFFFFFF
@@ -189,9 +193,11 @@ class AdaptiveClassifier:
                 off += nb
                 if ewc is not None:
                     trainer.fused_step(X, y, index, AdaptiveHead.DROPOUT_P, base_seed + steps, fisher=ewc.fisher_flat,
-                                       old_params=ewc.old_flat, lambda_over_B=lambda_B / nb)
+                                       old_params=ewc.old_flat, lambda_over_B=lambda_B / nb, loss_kind=loss_kind,
+                                       targets_all=targets)
                 else:
-                    trainer.fused_step(X, y, index, AdaptiveHead.DROPOUT_P, base_seed + steps)
+                    trainer.fused_step(X, y, index, AdaptiveHead.DROPOUT_P, base_seed + steps, loss_kind=loss_kind,
+                                       targets_all=targets)
                 steps += 1
             total = trainer.loss_accum
             avg_loss = float(total.item()) / len(loader)         # the only host sync of the epoch

@@ -22,8 +22,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _native as nv
-from .models import AdaptiveHead
-from .ops import softmax_rows
+from .models import _NativeMLP
+from .ops import sigmoid, softmax_rows
+from .training import LOSS_CE, LOSS_CE_SIGMOID
 
 
 class EWC:
@@ -31,7 +32,7 @@ class EWC:
         self.model = model
         self.device = device
         self.ewc_lambda = ewc_lambda
-        self._native = (isinstance(model, AdaptiveHead) and model.native_dims() is not None
+        self._native = (isinstance(model, _NativeMLP) and model.native_dims() is not None
                         and next(model.parameters()).is_cuda)
         if self._native:
             flat = model.flat_params()               # parameters become views of this block
@@ -67,12 +68,15 @@ class EWC:
         inv = 1.0 / len(loader)
         for bi, (batch_embeddings, _) in enumerate(loader):
             X = batch_embeddings.to(flat.device)
+            # a sigmoid-output head (multi-label) feeds its probabilities to softmax/nll (ewc.py:74-84)
+            sig = hasattr(head, "num_classes") and type(head).__name__ == "MultiLabelAdaptiveHead"
             if sampled_labels is None:
-                probs = softmax_rows(head.forward_native(X))
+                out = head.forward_native(X)
+                probs = softmax_rows(sigmoid(out) if sig else out)
                 y = torch.multinomial(probs, 1).squeeze(-1)     # ewc.py:81
             else:
                 y = sampled_labels[bi]
-            tr.forward_backward(X, y, None, None, 0.0)          # eval mode: no dropout
+            tr.forward_backward_loss(X, y=y, loss_kind=LOSS_CE_SIGMOID if sig else LOSS_CE, dropout_p=0.0)  # eval mode
             with torch.cuda.device(flat.device):
                 nv.check(nv.lib().ac_fisher_accumulate(nv.ptr(tr.grads), inv, nv.ptr(self.fisher_flat),
                                                        flat.numel(), nv.stream_ptr(flat.device)),

@@ -90,21 +90,11 @@ def _seeded_linear(fan_in, fan_out, kind):
     return layer
 
 
-class AdaptiveHead(nn.Module):
-    """MLP head: (Linear -> ReLU -> Dropout(0.1)) x n -> Linear (models.py:30-98)."""
+class _NativeMLP(nn.Module):
+    """Shared plumbing of the MLP heads: `.model` is an nn.Sequential whose Linear parameters are views of
+    ONE flat fp32 device block (layout of include/acamd.h) consumed by the HIP kernels."""
 
-    DROPOUT_P = 0.1
-
-    def __init__(self, input_dim: int, num_classes: int, hidden_dims: Optional[list] = None):
-        super().__init__()
-        if hidden_dims is None:
-            hidden_dims = [input_dim]
-        layers, prev = [], input_dim
-        for dim in hidden_dims:
-            layers += [_seeded_linear(prev, dim, "hidden"), nn.ReLU(), nn.Dropout(self.DROPOUT_P)]
-            prev = dim
-        layers.append(_seeded_linear(prev, num_classes, "out"))
-        self.model = nn.Sequential(*layers)
+    def _init_native(self):
         self._flat = None          # flat fp32 device block the parameters are views of
         self._ws = None
 
@@ -154,7 +144,7 @@ class AdaptiveHead(nn.Module):
 
     # ---- forward ---------------------------------------------------------------------------
     def forward_native(self, x: torch.Tensor) -> torch.Tensor:
-        """Eval-mode logits [B, C] through ac_head_forward (no autograd)."""
+        """Eval-mode LOGITS [B, C] through ac_head_forward (no autograd)."""
         dims = self.native_dims()
         if dims is None:
             raise nv.NativeError("native head forward needs hidden_dims of length 2")
@@ -172,6 +162,24 @@ class AdaptiveHead(nn.Module):
                                               nv.ptr(out), nv.ptr(ws), ws.numel(), nv.stream_ptr(flat.device)),
                      "ac_head_forward")
         return out
+
+
+class AdaptiveHead(_NativeMLP):
+    """MLP head: (Linear -> ReLU -> Dropout(0.1)) x n -> Linear (models.py:30-98)."""
+
+    DROPOUT_P = 0.1
+
+    def __init__(self, input_dim: int, num_classes: int, hidden_dims: Optional[list] = None):
+        super().__init__()
+        if hidden_dims is None:
+            hidden_dims = [input_dim]
+        layers, prev = [], input_dim
+        for dim in hidden_dims:
+            layers += [_seeded_linear(prev, dim, "hidden"), nn.ReLU(), nn.Dropout(self.DROPOUT_P)]
+            prev = dim
+        layers.append(_seeded_linear(prev, num_classes, "out"))
+        self.model = nn.Sequential(*layers)
+        self._init_native()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Always returns [B, C] (models.py:71-80).

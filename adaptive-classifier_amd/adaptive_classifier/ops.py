@@ -26,3 +26,13 @@ def l2_normalize_rows(x: torch.Tensor) -> torch.Tensor:
         nv.check(nv.lib().ac_l2_normalize_rows(nv.ptr(x), x.stride(0), x.shape[0], x.shape[1], nv.ptr(out),
                                                out.stride(0), nv.stream_ptr(x.device)), "ac_l2_normalize_rows")
     return out
+
+
+def sigmoid(x: torch.Tensor) -> torch.Tensor:
+    """torch.sigmoid on device (multilabel.py:43) via ac_sigmoid."""
+    nv.require_gpu()
+    x = x.detach().contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib().ac_sigmoid(nv.ptr(x), x.numel(), nv.ptr(out), nv.stream_ptr(x.device)), "ac_sigmoid")
+    return out

@@ -13,6 +13,7 @@ import torch
 from . import _native as nv
 
 REDUCE_SCRATCH_BYTES = 8192
+LOSS_CE, LOSS_BCE_SIGMOID, LOSS_CE_SIGMOID = 0, 1, 2      # AC_LOSS_* of include/acamd.h
 
 
 class HeadTrainer:
@@ -83,8 +84,26 @@ class HeadTrainer:
         self.optimizer_step(fisher, old_params, lambda_over_B)
         return self.loss, self.out
 
+    def forward_backward_loss(self, X, y=None, targets=None, loss_kind=LOSS_CE, mask1=None, mask2=None,
+                              dropout_p=0.1):
+        """forward_backward with a selectable loss (LOSS_CE / LOSS_BCE_SIGMOID / LOSS_CE_SIGMOID)."""
+        X = X.to(device=self.device, dtype=torch.float32)
+        if X.stride(-1) != 1:
+            X = X.contiguous()
+        B = X.shape[0]
+        y = None if y is None else y.to(device=self.device, dtype=torch.int64).contiguous()
+        targets = None if targets is None else targets.to(device=self.device, dtype=torch.float32).contiguous()
+        ws = self._workspace(B)
+        with torch.cuda.device(self.device):
+            nv.check(nv.lib().ac_head_fwd_bwd_loss(
+                ctypes.byref(self.dims), nv.ptr(self.flat), nv.ptr(X), X.stride(0), nv.ptr(y), nv.ptr(targets),
+                0 if targets is None else targets.stride(0), loss_kind, nv.ptr(mask1), nv.ptr(mask2), dropout_p, B,
+                nv.ptr(self.loss), nv.ptr(self.grads), nv.ptr(ws), ws.numel(), nv.stream_ptr(self.device)),
+                "ac_head_fwd_bwd_loss")
+        return self.loss
+
     def fused_step(self, X_all, y_all, index=None, dropout_p=0.1, seed=0, fisher=None, old_params=None,
-                   lambda_over_B=0.0):
+                   lambda_over_B=0.0, loss_kind=LOSS_CE, targets_all=None):
         """One call = gather batch (rows `index` of X_all / y_all) + train-mode forward with in-kernel
         counter-based dropout + CE + backward + EWC/clip/AdamW (`ac_head_train_step`).  No torch kernels,
         no host sync; the step's CE + penalty is added to self.loss_accum on device."""
@@ -94,7 +113,8 @@ class HeadTrainer:
         with torch.cuda.device(self.device):
             nv.check(nv.lib().ac_head_train_step(
                 ctypes.byref(self.dims), nv.ptr(self.flat), nv.ptr(self.m), nv.ptr(self.v), nv.ptr(self.grads),
-                nv.ptr(X_all), X_all.stride(0), nv.ptr(y_all), nv.ptr(index), B, dropout_p, seed,
+                nv.ptr(X_all), X_all.stride(0), nv.ptr(y_all), nv.ptr(targets_all),
+                0 if targets_all is None else targets_all.stride(0), loss_kind, nv.ptr(index), B, dropout_p, seed,
                 nv.ptr(fisher), nv.ptr(old_params), lambda_over_B, self.max_grad_norm, self.lr, self.betas[0],
                 self.betas[1], self.eps, self.weight_decay, self.t, nv.ptr(self.out3), nv.ptr(self.loss_accum),
                 nv.ptr(ws), ws.numel(), nv.stream_ptr(self.device)), "ac_head_train_step")

@@ -29,7 +29,7 @@ HeadOffsets head_offsets(const ac_head_dims& d) {
 }
 
 struct HeadWs {
-    size_t a1, a2, z, dz, d2, d1, rowloss, xg, yg, scratch, total;
+    size_t a1, a2, z, dz, d2, d1, rowloss, xg, yg, tg, scratch, total;
 };
 
 HeadWs head_ws(const ac_head_dims& d, int B) {
@@ -45,34 +45,69 @@ HeadWs head_ws(const ac_head_dims& d, int B) {
     w.rowloss = take((size_t)B);
     w.xg = take((size_t)B * d.D);          // gathered batch (ac_head_train_step with an index)
     w.yg = take((size_t)B * 2);            // int64 labels
+    w.tg = take((size_t)B * d.C);          // gathered multi-hot targets (BCE)
     w.scratch = take(AC_REDUCE_SCRATCH_BYTES / sizeof(float));
     w.total = off;
     return w;
 }
 
-// softmax + mean cross-entropy + dlogits; one wave per row, one block.
-// nn.CrossEntropyLoss (classifier.py:1463,1498): loss = mean_b( logsumexp(z_b) - z_b[y_b] ),
-// dz = (softmax(z) - onehot(y)) / B.
-__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* z, const int64_t* y, int B, int C,
-                                                         float* dz, float* rowloss, float* loss) {
+// loss + dlogits, one wave per row, one block.  kind:
+//   AC_LOSS_CE          nn.CrossEntropyLoss on logits (classifier.py:1463,1498):
+//                       loss = mean_b(logsumexp(z_b) - z_b[y_b]);  dz = (softmax(z) - onehot(y)) / B
+//   AC_LOSS_BCE_SIGMOID nn.BCELoss on sigmoid(z) against multi-hot targets T (multilabel.py:41-43,361,380):
+//                       loss = mean_{b,c} -(t log p + (1-t) log(1-p)), logs clamped at -100 like torch;
+//                       dz = (p - t) / max(p(1-p), 1e-12) / (B C) * p(1-p)
+//   AC_LOSS_CE_SIGMOID  the reference's new-class path run on a multi-label head (classifier.py:337-339 with
+//                       multilabel.py:41-43): CrossEntropyLoss applied to sigmoid(z);
+//                       dz = (softmax(p) - onehot(y)) / B * p(1-p)
+__global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const float* z, const int64_t* y, const float* T, int64_t ldt,
+                                                           int B, int C, int kind, float* dz, float* rowloss,
+                                                           float* loss) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int b = wave; b < B; b += 4) {
         const float* zr = z + (size_t)b * C;
+        if (kind == AC_LOSS_BCE_SIGMOID) {
+            const float inv = 1.f / ((float)B * (float)C);
+            float s = 0.f;
+            for (int c = lane; c < C; c += 64) {
+                const float p = 1.f / (1.f + expf(-zr[c]));
+                const float t = T[(size_t)b * ldt + c];
+                s -= t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(logf(1.f - p), -100.f);
+                const float pq = p * (1.f - p);
+                dz[(size_t)b * C + c] = (p - t) / fmaxf(pq, 1e-12f) * inv * pq;
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+            if (lane == 0) rowloss[b] = s / (float)C;
+            continue;
+        }
+        const bool sig = kind == AC_LOSS_CE_SIGMOID;
         float mx = -INFINITY;
-        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, zr[c]);
+        for (int c = lane; c < C; c += 64) {
+            const float v = sig ? 1.f / (1.f + expf(-zr[c])) : zr[c];
+            mx = fmaxf(mx, v);
+        }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float sum = 0.f;
-        for (int c = lane; c < C; c += 64) sum += expf(zr[c] - mx);
+        for (int c = lane; c < C; c += 64) {
+            const float v = sig ? 1.f / (1.f + expf(-zr[c])) : zr[c];
+            sum += expf(v - mx);
+        }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
         const int64_t yb = y[b];
         const float invB = 1.f / (float)B;
         for (int c = lane; c < C; c += 64) {
-            const float p = expf(zr[c] - mx) / sum;
-            dz[(size_t)b * C + c] = (p - (c == yb ? 1.f : 0.f)) * invB;
+            const float v = sig ? 1.f / (1.f + expf(-zr[c])) : zr[c];
+            float g = (expf(v - mx) / sum - (c == yb ? 1.f : 0.f)) * invB;
+            if (sig) g *= v * (1.f - v);
+            dz[(size_t)b * C + c] = g;
         }
-        if (lane == 0) rowloss[b] = (mx + logf(sum)) - zr[yb];
+        if (lane == 0) {
+            const float vy = sig ? 1.f / (1.f + expf(-zr[yb])) : zr[yb];
+            rowloss[b] = (mx + logf(sum)) - vy;
+        }
     }
     __syncthreads();
     if (wave == 0) {
@@ -82,6 +117,12 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* z, const i
         for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
         if (lane == 0) *loss = s / (float)B;
     }
+}
+
+// torch.sigmoid over n elements (multilabel.py:43)
+__global__ __launch_bounds__(256) void sigmoid_kernel(const float* in, int64_t n, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = 1.f / (1.f + expf(-in[i]));
 }
 
 // bias gradients: column sums of dz [B,C], d2 [B,H2], d1 [B,H1] into the flat grad block
@@ -108,11 +149,13 @@ __global__ __launch_bounds__(256) void fisher_acc_kernel(const float* g, float i
 
 // batch gather: xg[b,:] = X[idx[b],:], yg[b] = y[idx[b]]  (DataLoader batch assembly, classifier.py:1485-1487)
 __global__ __launch_bounds__(256) void gather_batch_kernel(const float* X, int64_t ldx, const int64_t* y,
-                                                           const int64_t* idx, int B, int D, float* xg, int64_t* yg) {
+                                                           const float* T, int64_t ldt, int C, const int64_t* idx,
+                                                           int B, int D, float* xg, int64_t* yg, float* tg) {
     const int b = blockIdx.x;
     const int64_t r = idx[b];
     for (int c = threadIdx.x; c < D; c += 256) xg[(size_t)b * D + c] = X[r * ldx + c];
-    if (threadIdx.x == 0) yg[b] = y[r];
+    if (T) for (int c = threadIdx.x; c < C; c += 256) tg[(size_t)b * C + c] = T[r * ldt + c];
+    if (threadIdx.x == 0 && y) yg[b] = y[r];
 }
 
 // F.softmax(logits, dim=1) (classifier.py:435,1345), one wave per row
@@ -282,7 +325,8 @@ namespace {
 // in-kernel from `seed` when dropout_p > 0 and no mask is given with use_seed.
 int head_fwd_bwd(const ac_head_dims& d, const float* P, const float* X, int64_t ldx, const int64_t* y,
                  const uint8_t* mask1, const uint8_t* mask2, float dropout_p, bool use_seed, uint64_t seed, int B,
-                 float* d_loss, float* G, char* ws, const HeadWs& w, hipStream_t stream) {
+                 float* d_loss, float* G, char* ws, const HeadWs& w, hipStream_t stream, int loss_kind = AC_LOSS_CE,
+                 const float* targets = nullptr, int64_t ldt = 0) {
     const HeadOffsets o = head_offsets(d);
     float* a1 = (float*)(ws + w.a1);
     float* a2 = (float*)(ws + w.a2);
@@ -305,7 +349,8 @@ int head_fwd_bwd(const ac_head_dims& d, const float* P, const float* X, int64_t 
     if (rc) return rc;
     rc = ac::linear_f32(a2, d.H2, P + o.w3, d.H2, P + o.b3, nullptr, 0, z, d.C, B, d.C, d.H2, 0, nullptr, 1.f, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(1), dim3(256), 0, stream, z, y, B, d.C, dz, rowloss, d_loss);
+    hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(1), dim3(256), 0, stream, z, y, targets, ldt, B, d.C, loss_kind, dz,
+                       rowloss, d_loss);
     AC_LAUNCH_CHECK();
     // backward.  dW = dY^T A  (transA=1: dY stored [B,out] is the [K,M] layout), dA = dY W gated
     // by relu'/dropout (a != 0 ? scale : 0).
@@ -366,8 +411,34 @@ extern "C" int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_param
                         (char*)d_ws, w, stream);
 }
 
+extern "C" int ac_head_fwd_bwd_loss(const ac_head_dims* dims, const float* d_params, const float* d_X, int64_t ldx,
+                                    const int64_t* d_y, const float* d_targets, int64_t ldt, int loss_kind,
+                                    const uint8_t* d_mask1, const uint8_t* d_mask2, float dropout_p, int B,
+                                    float* d_loss, float* d_grads, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    AC_REQUIRE(d_params && d_X && d_loss && d_grads && B > 0 && ldx >= dims->D, AC_EINVAL, "head_fwd_bwd_loss: bad arguments");
+    AC_REQUIRE(loss_kind >= AC_LOSS_CE && loss_kind <= AC_LOSS_CE_SIGMOID, AC_EINVAL, "head_fwd_bwd_loss: loss_kind=%d", loss_kind);
+    AC_REQUIRE(loss_kind == AC_LOSS_BCE_SIGMOID ? (d_targets && ldt >= dims->C) : (d_y != nullptr), AC_EINVAL,
+               "head_fwd_bwd_loss: BCE needs float targets [B, C]; CE needs int64 labels");
+    AC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, AC_EINVAL, "head_fwd_bwd_loss: dropout_p=%f", dropout_p);
+    const HeadWs w = head_ws(*dims, B);
+    AC_REQUIRE(d_ws && ws_bytes >= w.total, AC_EWORKSPACE, "head_fwd_bwd_loss: workspace %zu < %zu", ws_bytes, w.total);
+    return head_fwd_bwd(*dims, d_params, d_X, ldx, d_y, d_mask1, d_mask2, dropout_p, false, 0, B, d_loss, d_grads,
+                        (char*)d_ws, w, (hipStream_t)stream_, loss_kind, d_targets, ldt);
+}
+
+extern "C" int ac_sigmoid(const float* d_in, int64_t n, float* d_out, ac_stream_t stream) {
+    AC_REQUIRE(d_in && d_out && n >= 0, AC_EINVAL, "sigmoid: bad arguments");
+    if (n == 0) return AC_OK;
+    hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_in, n, d_out);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
 extern "C" int ac_head_train_step(const ac_head_dims* dims, float* d_params, float* d_m, float* d_v, float* d_grads,
-                                  const float* d_X, int64_t ldx, const int64_t* d_y, const int64_t* d_index, int B,
+                                  const float* d_X, int64_t ldx, const int64_t* d_y, const float* d_targets,
+                                  int64_t ldt, int loss_kind, const int64_t* d_index, int B,
                                   float dropout_p, uint64_t dropout_seed, const float* d_fisher, const float* d_old,
                                   float lambda_over_B, float max_grad_norm, float lr, float beta1, float beta2,
                                   float eps, float weight_decay, int step, float* d_out, float* d_loss_accum,
@@ -375,8 +446,11 @@ extern "C" int ac_head_train_step(const ac_head_dims* dims, float* d_params, flo
     int rc = check_dims(dims);
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    AC_REQUIRE(d_params && d_m && d_v && d_grads && d_X && d_y && d_out && B > 0 && ldx >= dims->D && step >= 1,
+    AC_REQUIRE(d_params && d_m && d_v && d_grads && d_X && d_out && B > 0 && ldx >= dims->D && step >= 1,
                AC_EINVAL, "head_train_step: bad arguments");
+    AC_REQUIRE(loss_kind >= AC_LOSS_CE && loss_kind <= AC_LOSS_CE_SIGMOID, AC_EINVAL, "head_train_step: loss_kind=%d", loss_kind);
+    AC_REQUIRE(loss_kind == AC_LOSS_BCE_SIGMOID ? (d_targets && ldt >= dims->C) : (d_y != nullptr), AC_EINVAL,
+               "head_train_step: BCE needs float targets [rows, C]; CE needs int64 labels");
     AC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, AC_EINVAL, "head_train_step: dropout_p=%f", dropout_p);
     AC_REQUIRE((d_fisher == nullptr) == (d_old == nullptr), AC_EINVAL,
                "head_train_step: fisher and old params must be given together");
@@ -386,16 +460,20 @@ extern "C" int ac_head_train_step(const ac_head_dims* dims, float* d_params, flo
     char* ws = (char*)d_ws;
     const float* X = d_X;
     const int64_t* y = d_y;
-    int64_t ld = ldx;
+    const float* T = d_targets;
+    int64_t ld = ldx, ldT = ldt;
     if (d_index) {       // assemble the batch on device: rows d_index[0..B) of the stored examples
         float* xg = (float*)(ws + w.xg);
         int64_t* yg = (int64_t*)(ws + w.yg);
-        hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, stream, d_X, ldx, d_y, d_index, B, d.D, xg, yg);
+        float* tg = (float*)(ws + w.tg);
+        hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, stream, d_X, ldx, d_y, d_targets, ldt, d.C,
+                           d_index, B, d.D, xg, yg, tg);
         AC_LAUNCH_CHECK();
-        X = xg; y = yg; ld = d.D;
+        X = xg; y = d_y ? yg : nullptr; ld = d.D;
+        if (d_targets) { T = tg; ldT = d.C; }
     }
     rc = head_fwd_bwd(d, d_params, X, ld, y, nullptr, nullptr, dropout_p, dropout_p > 0.f, dropout_seed, B, d_out, d_grads,
-                      ws, w, stream);
+                      ws, w, stream, loss_kind, T, ldT);
     if (rc) return rc;
     // d_out[0] = CE loss (written above); [1] = EWC penalty, [2] = grad norm
     return adamw_launch(d_params, d_grads, d_m, d_v, d_fisher, d_old, head_offsets(d).total, lambda_over_B,

@@ -177,6 +177,24 @@ int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_params,
 
 #define AC_REDUCE_SCRATCH_BYTES 8192
 
+/* Loss applied to the head's output layer in the training entry points. */
+#define AC_LOSS_CE          0  /* nn.CrossEntropyLoss on logits, int64 labels (classifier.py:1463) */
+#define AC_LOSS_BCE_SIGMOID 1  /* nn.BCELoss on sigmoid(logits), float multi-hot targets (multilabel.py:361) */
+#define AC_LOSS_CE_SIGMOID  2  /* CrossEntropyLoss on sigmoid(logits): what the reference's new-class loop
+                                  computes when the head is a MultiLabelAdaptiveHead (classifier.py:337-339) */
+
+/* ac_head_fwd_bwd_ce generalised to the three losses (explicit dropout masks, parity path).
+ * d_y int64 [B] for the CE kinds, d_targets float [B, ldt] for BCE. */
+int ac_head_fwd_bwd_loss(const ac_head_dims* dims, const float* d_params,
+                         const float* d_X, int64_t ldx, const int64_t* d_y,
+                         const float* d_targets, int64_t ldt, int loss_kind,
+                         const uint8_t* d_mask1, const uint8_t* d_mask2,
+                         float dropout_p, int B, float* d_loss, float* d_grads,
+                         void* d_ws, size_t ws_bytes, ac_stream_t stream);
+
+/* torch.sigmoid over n floats (MultiLabelAdaptiveHead.forward, multilabel.py:41-43). */
+int ac_sigmoid(const float* d_in, int64_t n, float* d_out, ac_stream_t stream);
+
 /*
  * One whole training step of classifier.py:1485-1507 / :329-353 in a single call:
  * (optional) batch gather X[index], y[index] -> train-mode forward with in-kernel
@@ -184,11 +202,13 @@ int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_params,
  * + clip_grad_norm_ + AdamW.  d_out[0] = CE loss, [1] = EWC penalty, [2] = grad
  * norm; if d_loss_accum != NULL, *d_loss_accum += CE + penalty (the epoch's
  * `total_loss += loss.item()` without a host sync).  d_grads: flat scratch for
- * the gradients.  Workspace size: ac_head_workspace(dims, B).
+ * the gradients.  loss_kind: AC_LOSS_* (d_y for the CE kinds, d_targets [rows, ldt]
+ * for BCE; both indexed through d_index when given).  Workspace: ac_head_workspace.
  */
 int ac_head_train_step(const ac_head_dims* dims, float* d_params, float* d_m,
                        float* d_v, float* d_grads, const float* d_X, int64_t ldx,
-                       const int64_t* d_y, const int64_t* d_index, int B,
+                       const int64_t* d_y, const float* d_targets, int64_t ldt,
+                       int loss_kind, const int64_t* d_index, int B,
                        float dropout_p, uint64_t dropout_seed,
                        const float* d_fisher, const float* d_old,
                        float lambda_over_B, float max_grad_norm, float lr,

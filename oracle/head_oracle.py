@@ -95,3 +95,29 @@ def fisher_from_labels(seq, batches, sampled):
         F.nll_loss(F.log_softmax(out, dim=1), yb).backward()
         fl += flat(seq, "grad") ** 2 / len(batches)
     return fl
+
+
+# ---- multi-label head (multilabel.py:15-68, :361-384) -------------------------------------------
+def make_multilabel_head(D, C, hidden=None, seed=7):
+    """MultiLabelAdaptiveHead's layers with torch's default nn.Linear init under a fixed global seed."""
+    hidden = hidden if hidden is not None else [D, D // 2]
+    torch.manual_seed(seed)
+    layers, prev = [], D
+    for h in hidden:
+        layers += [nn.Linear(prev, h), nn.ReLU(), nn.Dropout(0.1)]
+        prev = h
+    layers.append(nn.Linear(prev, C))
+    return nn.Sequential(*layers)
+
+
+def train_step_loss(seq, opt, x, target, kind, masks=None, p=0.1, max_norm=1.0):
+    """One step with the multi-label losses: kind 'bce' = BCELoss(sigmoid(z), multi-hot) (multilabel.py:361-380),
+    kind 'ce_sigmoid' = CrossEntropyLoss(sigmoid(z), y) (classifier.py:337-339 on a sigmoid head)."""
+    opt.zero_grad()
+    probs = torch.sigmoid(forward_masked(seq, x, masks, p))
+    loss = F.binary_cross_entropy(probs, target) if kind == "bce" else F.cross_entropy(probs, target)
+    loss.backward()
+    params = [p_ for l in linears(seq) for p_ in (l.weight, l.bias)]
+    gn = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+    opt.step()
+    return float(loss.detach()), float(gn)

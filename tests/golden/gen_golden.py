@@ -197,8 +197,71 @@ def gen_ewc():
     json.dump(out, open(os.path.join(HERE, "ewc.json"), "w"))
 
 
+def gen_multilabel():
+    """Reference MultiLabelAdaptiveHead: BCE steps (multilabel.py:361-384) and one CrossEntropy-on-sigmoid
+    step (what classifier.py:337-351 does to a sigmoid head), dropout masks captured; plus the threshold /
+    min / max decision logic of predict_multilabel driven with fixed probabilities."""
+    from adaptive_classifier.multilabel import MultiLabelAdaptiveClassifier, MultiLabelAdaptiveHead
+    D, C, B = 768, 5, 32
+    torch.manual_seed(7)
+    head = MultiLabelAdaptiveHead(D, C, [D, D // 2])
+    init = {k: summarize(v) for k, v in head.state_dict().items()}
+    head.train()
+    opt = torch.optim.AdamW(head.parameters(), lr=0.001, weight_decay=0.01)
+    X = torch.from_numpy(synth.synth_unit_rows(B, D, 41))
+    T = torch.from_numpy(((np.arange(B)[:, None] * 3 + np.arange(C)[None, :] * 5) % 7 < 2).astype(np.float32))
+    y = torch.from_numpy((np.arange(B) * 3 % C).astype(np.int64))
+    cap, steps, masks = [], [], {}
+    hooks = [m.register_forward_hook(lambda mod, inp, out: cap.append(((out != 0) | (inp[0] == 0)).to(torch.uint8)))
+             for m in head.model if isinstance(m, torch.nn.Dropout)]
+    torch.manual_seed(321)
+    for s, kind in enumerate(["bce", "bce", "ce_sigmoid"]):
+        cap.clear()
+        opt.zero_grad()
+        out = head(X)
+        loss = torch.nn.BCELoss()(out, T) if kind == "bce" else torch.nn.CrossEntropyLoss()(out, y)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(head.parameters(), max_norm=1.0)
+        opt.step()
+        masks[f"m1_{s}"], masks[f"m2_{s}"] = cap[0].numpy().copy(), cap[1].numpy().copy()
+        steps.append({"kind": kind, "loss": float(loss.detach()), "grad_norm": float(gn),
+                      "params": {k: summarize(v) for k, v in head.state_dict().items()}})
+    for h in hooks:
+        h.remove()
+    head.eval()
+    with torch.no_grad():
+        probs_after = head(X[:4]).numpy().tolist()
+    np.savez_compressed(os.path.join(HERE, "multilabel_masks.npz"), **masks)
+
+    # decision logic with fixed probabilities
+    clf = MultiLabelAdaptiveClassifier.__new__(MultiLabelAdaptiveClassifier)
+    labels = [f"l{i}" for i in range(6)]
+    clf.label_to_id = {l: i for i, l in enumerate(labels)}; clf.id_to_label = {i: l for i, l in enumerate(labels)}
+    clf.default_threshold = 0.5; clf.device = "cpu"
+    table = {"a": [0.9, 0.45, 0.31, 0.05, 0.29, 0.6], "b": [0.1, 0.2, 0.05, 0.02, 0.01, 0.03],
+             "c": [0.31, 0.31, 0.8, 0.7, 0.65, 0.62]}
+    cur = {}
+    clf._get_embeddings = lambda ts: [torch.zeros(4)]
+    class FakeHead:
+        def eval(self): return self
+        def __call__(self, x): return torch.tensor([cur["p"]])
+    clf.adaptive_head = FakeHead()
+    decisions = []
+    for (mn, mx, lt) in [(1, None, {}), (2, 3, {}), (1, 2, {"l1": 0.15, "l0": 0.95}), (3, None, {"l5": 0.0})]:
+        clf.min_predictions, clf.max_predictions, clf.label_thresholds = mn, mx, lt
+        for name, p in table.items():
+            cur["p"] = p
+            for thr, ml in [(None, None), (0.3, None), (None, 2)]:
+                decisions.append({"min": mn, "max": mx, "label_thresholds": lt, "probs": p, "threshold": thr,
+                                  "max_labels": ml, "out": clf.predict_multilabel(name, threshold=thr, max_labels=ml)})
+    json.dump({"init": init, "steps": steps, "x_seed": 41, "probs_after": probs_after, "decisions": decisions,
+               "adaptive_thresholds": {str(n): clf._get_adaptive_threshold(n) for n in (1, 2, 3, 5, 6, 10, 11, 20, 21, 50)}},
+              open(os.path.join(HERE, "multilabel.json"), "w"))
+
+
 if __name__ == "__main__":
-    gen_router(); gen_knn(); gen_memory_and_blend(); gen_head_step(); gen_ewc()
+    gen_router(); gen_knn(); gen_memory_and_blend(); gen_head_step(); gen_ewc(); gen_multilabel()
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         print(f"  {f:28s} {os.path.getsize(os.path.join(HERE, f)):8d} B")
+

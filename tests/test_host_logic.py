@@ -233,3 +233,29 @@ def test_blend_matches_reference_golden():
         Dd, I = knn_oracle.knn_l2_topk(protos, Q, k)
         for a, w in zip(clf._blend(knn_oracle.proto_scores(Dd, I), I, P, k, False), want):
             same(a, w)
+
+
+# ---- multi-label decision logic (multilabel.py:112-226) against the reference's outputs ------------
+def test_multilabel_thresholds_and_decisions_match_reference():
+    import json
+    import os
+    from adaptive_classifier import MultiLabelAdaptiveClassifier, MultiLabelAdaptiveHead
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "multilabel.json")))
+    clf = MultiLabelAdaptiveClassifier.__new__(MultiLabelAdaptiveClassifier)
+    labels = [f"l{i}" for i in range(6)]
+    clf.label_to_id = {l: i for i, l in enumerate(labels)}
+    clf.id_to_label = {i: l for i, l in enumerate(labels)}
+    clf.default_threshold = 0.5
+    for n, want in g["adaptive_thresholds"].items():
+        assert clf._get_adaptive_threshold(int(n)) == want
+    for d in g["decisions"]:
+        clf.min_predictions, clf.max_predictions, clf.label_thresholds = d["min"], d["max"], d["label_thresholds"]
+        thr = d["threshold"] if d["threshold"] is not None else clf._get_adaptive_threshold(6)
+        got = clf._decide(d["probs"], thr, d["max_labels"] or clf.max_predictions)
+        assert [l for l, _ in got] == [l for l, _ in d["out"]], d
+        assert all(abs(a - b) < 1e-6 for (_, a), (_, b) in zip(got, d["out"]))
+    h = MultiLabelAdaptiveHead(16, 3, [16, 8])
+    assert h.num_classes == 3 and h(torch.randn(2, 16)).min() >= 0 and h(torch.randn(2, 16)).max() <= 1
+    w = h.model[-1].weight.detach().clone()
+    h.update_num_classes(5)
+    assert h.num_classes == 5 and torch.equal(h.model[-1].weight[:3], w) and h(torch.randn(4, 16)).shape == (4, 5)

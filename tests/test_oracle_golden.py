@@ -97,3 +97,24 @@ def test_ewc_oracle_matches_reference():
             p += 0.1
     assert abs(float(head_oracle.ewc_penalty(head, f, old, 100.0)) - g["loss_p01"]) < 1e-6
     assert abs(float(head_oracle.ewc_penalty(head, f, old, 100.0 / 32)) - g["loss_p01_b32"]) < 1e-7
+
+
+def test_multilabel_oracle_reproduces_reference_steps():
+    """BCE and CE-on-sigmoid steps of the reference MultiLabelAdaptiveHead (tests/golden/multilabel.json)."""
+    g = json.load(open(os.path.join(G, "multilabel.json")))
+    m = np.load(os.path.join(G, "multilabel_masks.npz"))
+    D, C, B = 768, 5, 32
+    head = head_oracle.make_multilabel_head(D, C, seed=7)
+    for (k, v) in zip(g["init"], [p for l in head_oracle.linears(head) for p in (l.weight, l.bias)]):
+        _check_summary(v, g["init"][k], 1e-9)                 # same default init under the same seed
+    head.train()
+    opt = torch.optim.AdamW(head.parameters(), lr=0.001, weight_decay=0.01)
+    X = torch.from_numpy(synth.synth_unit_rows(B, D, g["x_seed"]))
+    T = torch.from_numpy(((np.arange(B)[:, None] * 3 + np.arange(C)[None, :] * 5) % 7 < 2).astype(np.float32))
+    y = torch.from_numpy((np.arange(B) * 3 % C).astype(np.int64))
+    for s, step in enumerate(g["steps"]):
+        masks = [torch.from_numpy(m[f"m1_{s}"]), torch.from_numpy(m[f"m2_{s}"])]
+        loss, gn = head_oracle.train_step_loss(head, opt, X, T if step["kind"] == "bce" else y, step["kind"], masks)
+        assert abs(loss - step["loss"]) < 1e-6 and abs(gn - step["grad_norm"]) < 1e-6
+        for (k, v) in zip(step["params"], [p for l in head_oracle.linears(head) for p in (l.weight, l.bias)]):
+            _check_summary(v, step["params"][k], 1e-7)
