@@ -2,7 +2,7 @@
 
 Replaces `self.model(**inputs).last_hidden_state[:, 0, :]` + `F.normalize`
 (/root/reference/src/adaptive_classifier/classifier.py:1271-1275) for BERT-architecture
-checkpoints (bert-base-uncased, bert-large, e5-large-v2, bert-tiny ...) with one native call,
+and DistilBERT checkpoints (bert-base-uncased, bert-large, e5-large-v2, bert-tiny, distilbert-base-*) with one native call,
 `ac_bert_encode_cls`, that writes unit-norm CLS vectors straight into a device buffer usable as the
 kNN query block (no device->host copy, cf. classifier.py:1282).
 
@@ -29,19 +29,37 @@ class HipBertEncoder:
     def __init__(self, hf_bert, device=None):
         nv.require_gpu()
         cfg = hf_bert.config
-        if getattr(cfg, "model_type", "bert") != "bert":
-            raise nv.NativeError(f"HipBertEncoder covers BERT-architecture encoders, got {cfg.model_type!r}")
-        if getattr(cfg, "position_embedding_type", "absolute") not in (None, "absolute"):
-            raise nv.NativeError("HipBertEncoder: only absolute position embeddings are supported")
-        if cfg.hidden_act not in ("gelu",):
-            raise nv.NativeError(f"HipBertEncoder: hidden_act={cfg.hidden_act!r} unsupported (erf-GELU only)")
+        mtype = getattr(cfg, "model_type", "bert")
+        if mtype not in ("bert", "distilbert"):
+            raise nv.NativeError(f"HipBertEncoder covers BERT / DistilBERT encoders, got {mtype!r}")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-        self.config = _Cfg(cfg.hidden_size, getattr(cfg, "_name_or_path", ""))
-        self.training = False
-        self.ccfg = nv.ac_bert_config(cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
-                                      cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings,
-                                      cfg.type_vocab_size, float(cfg.layer_norm_eps))
         sd = {k: v.detach() for k, v in hf_bert.state_dict().items()}
+        if mtype == "bert":
+            if getattr(cfg, "position_embedding_type", "absolute") not in (None, "absolute"):
+                raise nv.NativeError("HipBertEncoder: only absolute position embeddings are supported")
+            act = cfg.hidden_act
+            H, L, A, I = cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.intermediate_size
+            type_vocab, eps = cfg.type_vocab_size, float(cfg.layer_norm_eps)
+            names = {"word": "embeddings.word_embeddings.weight", "pos": "embeddings.position_embeddings.weight",
+                     "type": "embeddings.token_type_embeddings.weight", "eln": "embeddings.LayerNorm",
+                     "layer": "encoder.layer.{}.", "q": "attention.self.query", "k": "attention.self.key",
+                     "v": "attention.self.value", "ao": "attention.output.dense", "ln1": "attention.output.LayerNorm",
+                     "ff1": "intermediate.dense", "ff2": "output.dense", "ln2": "output.LayerNorm"}
+        else:
+            # DistilBERT (modeling_distilbert.py): same block, no token-type embeddings -> a single zero row
+            act = cfg.activation
+            H, L, A, I = cfg.dim, cfg.n_layers, cfg.n_heads, cfg.hidden_dim
+            type_vocab, eps = 1, 1e-12
+            names = {"word": "embeddings.word_embeddings.weight", "pos": "embeddings.position_embeddings.weight",
+                     "type": None, "eln": "embeddings.LayerNorm",
+                     "layer": "transformer.layer.{}.", "q": "attention.q_lin", "k": "attention.k_lin",
+                     "v": "attention.v_lin", "ao": "attention.out_lin", "ln1": "sa_layer_norm",
+                     "ff1": "ffn.lin1", "ff2": "ffn.lin2", "ln2": "output_layer_norm"}
+        if act not in ("gelu",):
+            raise nv.NativeError(f"HipBertEncoder: activation {act!r} unsupported (erf-GELU only)")
+        self.config = _Cfg(H, getattr(cfg, "_name_or_path", ""))
+        self.training = False
+        self.ccfg = nv.ac_bert_config(H, L, A, I, cfg.vocab_size, cfg.max_position_embeddings, type_vocab, eps)
 
         def dev(t):
             return t.to(device=self.device, dtype=torch.float32).contiguous()
@@ -53,31 +71,26 @@ class HipBertEncoder:
             self._keep.append(t)
             return t
 
-        L = cfg.num_hidden_layers
         per = {k: [] for k in ("qkv_w", "qkv_b", "ao_w", "ao_b", "ln1_g", "ln1_b", "ff1_w", "ff1_b",
                                "ff2_w", "ff2_b", "ln2_g", "ln2_b")}
         for l in range(L):
-            p = f"encoder.layer.{l}."
-            a = p + "attention.self."
-            per["qkv_w"].append(own(torch.cat([sd[a + "query.weight"], sd[a + "key.weight"], sd[a + "value.weight"]], 0)))
-            per["qkv_b"].append(own(torch.cat([sd[a + "query.bias"], sd[a + "key.bias"], sd[a + "value.bias"]], 0)))
-            per["ao_w"].append(own(sd[p + "attention.output.dense.weight"]))
-            per["ao_b"].append(own(sd[p + "attention.output.dense.bias"]))
-            per["ln1_g"].append(own(sd[p + "attention.output.LayerNorm.weight"]))
-            per["ln1_b"].append(own(sd[p + "attention.output.LayerNorm.bias"]))
-            per["ff1_w"].append(own(sd[p + "intermediate.dense.weight"]))
-            per["ff1_b"].append(own(sd[p + "intermediate.dense.bias"]))
-            per["ff2_w"].append(own(sd[p + "output.dense.weight"]))
-            per["ff2_b"].append(own(sd[p + "output.dense.bias"]))
-            per["ln2_g"].append(own(sd[p + "output.LayerNorm.weight"]))
-            per["ln2_b"].append(own(sd[p + "output.LayerNorm.bias"]))
+            p = names["layer"].format(l)
+            per["qkv_w"].append(own(torch.cat([sd[p + names[x] + ".weight"] for x in ("q", "k", "v")], 0)))
+            per["qkv_b"].append(own(torch.cat([sd[p + names[x] + ".bias"] for x in ("q", "k", "v")], 0)))
+            for dst, src in (("ao", "ao"), ("ff1", "ff1"), ("ff2", "ff2")):
+                per[dst + "_w"].append(own(sd[p + names[src] + ".weight"]))
+                per[dst + "_b"].append(own(sd[p + names[src] + ".bias"]))
+            for dst in ("ln1", "ln2"):
+                per[dst + "_g"].append(own(sd[p + names[dst] + ".weight"]))
+                per[dst + "_b"].append(own(sd[p + names[dst] + ".bias"]))
         self._arrays = {}
         w = nv.ac_bert_weights()
-        w.word_emb = own(sd["embeddings.word_embeddings.weight"]).data_ptr()
-        w.pos_emb = own(sd["embeddings.position_embeddings.weight"]).data_ptr()
-        w.type_emb = own(sd["embeddings.token_type_embeddings.weight"]).data_ptr()
-        w.emb_ln_g = own(sd["embeddings.LayerNorm.weight"]).data_ptr()
-        w.emb_ln_b = own(sd["embeddings.LayerNorm.bias"]).data_ptr()
+        w.word_emb = own(sd[names["word"]]).data_ptr()
+        w.pos_emb = own(sd[names["pos"]]).data_ptr()
+        w.type_emb = own(sd[names["type"]] if names["type"] else torch.zeros(1, H)).data_ptr()
+        w.emb_ln_g = own(sd[names["eln"] + ".weight"]).data_ptr()
+        w.emb_ln_b = own(sd[names["eln"] + ".bias"]).data_ptr()
+        self._has_types = names["type"] is not None
         for k, tensors in per.items():
             arr = (ctypes.c_void_p * L)(*[t.data_ptr() for t in tensors])
             self._arrays[k] = arr             # host array of device pointers; must outlive the calls
@@ -109,6 +122,8 @@ class HipBertEncoder:
         """int64 [b, S] ids (+ optional type ids / mask) -> unit-norm CLS embeddings [b, H] on device."""
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         b, S = ids.shape
+        if not self._has_types:
+            token_type_ids = None           # DistilBERT has no segment embeddings (tokenizer may still emit ids)
         tt = None if token_type_ids is None else token_type_ids.to(device=self.device, dtype=torch.int64).contiguous()
         mk = None if attention_mask is None else attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
         H = self.ccfg.hidden

@@ -37,3 +37,24 @@ def test_encoder_no_mask_and_large_batch(cuda_dev):
     enc = HipBertEncoder(model, device=cuda_dev)
     got = enc.encode_cls(ids).cpu()            # type ids / mask omitted = zeros / ones
     assert (got - want).abs().max().item() < 1e-4
+
+
+def test_distilbert_encoder_matches_transformers(cuda_dev):
+    """N4 (part): DistilBERT = the BERT block without token-type embeddings; same kernels, mapped weights."""
+    import torch.nn.functional as F
+    from transformers import DistilBertConfig, DistilBertModel
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    cfg = DistilBertConfig(vocab_size=2000, dim=768, n_layers=3, n_heads=12, hidden_dim=3072)
+    try:
+        cfg._attn_implementation = "eager"
+    except Exception:
+        pass
+    torch.manual_seed(0)
+    model = DistilBertModel(cfg).eval()
+    ids, types, mask = bert_oracle.synthetic_batch(6, 40, vocab=2000, seed=7, ragged=True)
+    with torch.no_grad():
+        want = F.normalize(model(input_ids=ids, attention_mask=mask).last_hidden_state[:, 0, :], p=2, dim=1)
+    enc = HipBertEncoder(model, device=cuda_dev)
+    got = enc.encode_cls(ids, types, mask).cpu()          # token_type_ids ignored for DistilBERT
+    assert (got - want).abs().max().item() < 1e-4
