@@ -356,53 +356,54 @@ class AdaptiveClassifier:
             wp = np.full(C, 0.7)
             wh = np.full(C, 0.3)
         combined = np.zeros((b, C), dtype=np.float64)
-        present = np.zeros((b, C), dtype=bool)
         BIG = 1 << 30
         ins = np.full((b, C), BIG, dtype=np.int64)          # insertion rank, for stable tie order
-        rows = np.arange(b)
         kp = 0
         if S is not None:
             kp = S.shape[1]
-            multi = self.memory._row_labels is not None      # M6: several rows per class vote (sum)
             S64 = S.astype(np.float64)
-            for j in range(kp):                              # hit order = ascending distance
-                c = Cid[:, j]
-                ok = c >= 0
-                r, cc = rows[ok], c[ok]
-                contrib = S64[ok, j] * wp[cc]
-                if multi:
-                    combined[r, cc] += contrib
-                else:
-                    combined[r, cc] = contrib                # reference: dict assignment
-                first = ok.copy()
-                first[ok] = ~present[r, cc]
-                ins[rows[first], c[first]] = j
-                present[r, cc] = True
+            jidx = np.arange(kp, dtype=np.int64)[None, :]
+            # one pass per class (C is small next to b * kp).  With one row per class each class occurs
+            # once per query, so summing == the reference's dict assignment; with the generalised store
+            # (M6, several rows per class) the hits of a class vote (sum).
+            if C <= 64:
+                for c in range(C):
+                    hit = Cid == c
+                    if hit.any():
+                        combined[:, c] = np.where(hit, S64, 0.0).sum(axis=1) * wp[c]
+                        ins[:, c] = np.where(hit, jidx, BIG).min(axis=1)       # first hit position
+            else:                                            # many classes: scatter instead of a pass per class
+                ok = Cid >= 0
+                r = np.broadcast_to(np.arange(b)[:, None], Cid.shape)[ok]
+                cc = Cid[ok]
+                np.add.at(combined, (r, cc), S64[ok] * wp[cc])
+                np.minimum.at(ins, (r, cc), np.broadcast_to(jidx, Cid.shape)[ok])
+        present = ins < BIG
         if P is not None:
             P64 = P.astype(np.float64)
             ncls = C if regular else min(k, C)
-            top = np.argsort(-P, axis=1, kind="stable")[:, :ncls]          # torch.topk order
-            for j in range(ncls):
-                c = top[:, j]
-                combined[rows, c] += P64[rows, c] * wh[c]
-                newly = ~present[rows, c]
-                ins[rows[newly], c[newly]] = kp + j
-                present[rows, c] = True
+            if ncls == C:
+                in_top = np.ones((b, C), dtype=bool)
+                rank = np.argsort(np.argsort(-P, axis=1, kind="stable"), axis=1, kind="stable")
+            else:
+                top = np.argsort(-P, axis=1, kind="stable")[:, :ncls]                 # torch.topk order
+                in_top = np.zeros((b, C), dtype=bool)
+                np.put_along_axis(in_top, top, True, axis=1)
+                rank = np.full((b, C), BIG, dtype=np.int64)
+                np.put_along_axis(rank, top, np.broadcast_to(np.arange(ncls), top.shape), axis=1)
+            combined += np.where(in_top, P64 * wh[None, :], 0.0)
+            newly = in_top & ~present
+            ins = np.where(newly, kp + rank, ins)
+            present |= in_top
         score = np.where(present, combined, -np.inf)
         order = np.lexsort((ins, -score), axis=1)                         # desc score, then insertion order
         total = np.where(present, combined, 0.0).sum(axis=1)
-        results = []
-        names = [self.id_to_label[c] for c in range(C)]
-        npres = present.sum(axis=1)
-        for q in range(b):
-            n = min(k, int(npres[q]))
-            t = total[q]
-            cs = order[q, :n]
-            if t > 0:
-                results.append([(names[c], float(combined[q, c] / t)) for c in cs])
-            else:
-                results.append([(names[c], float(combined[q, c])) for c in cs])
-        return results
+        denom = np.where(total > 0, total, 1.0)
+        vals = np.take_along_axis(combined / denom[:, None], order, axis=1).tolist()
+        names = np.array([self.id_to_label[c] for c in range(C)], dtype=object)
+        labs = names[order].tolist()
+        npres = np.minimum(present.sum(axis=1), k).tolist()
+        return [list(zip(labs[q][:n], vals[q][:n])) for q, n in enumerate(npres)]
 
     # ------------------------------------------------------------------------------ misc API
     def get_memory_stats(self) -> Dict[str, Any]:
