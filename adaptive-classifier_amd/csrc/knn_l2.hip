@@ -149,6 +149,7 @@ template <int J>
 __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
     typedef Shape S;
     typedef S::acc_t acc_t;
+    static_assert(J == 1 || J == 2, "query tile = 1 or 2 sub-tiles of 16 (LDS budget; tau[] reload below)");
     constexpr int TQ = 16 * J;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
