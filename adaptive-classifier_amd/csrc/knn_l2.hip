@@ -20,7 +20,8 @@
 //                     those k' distances exactly (fp64 sum of (p-q)^2), order by (exact, id),
 //                     emit top-k, and certify with an fp32 error bound that no unseen row can
 //                     beat the k-th (see acamd.h "exactness contract").
-//  3. knn_exact_fallback  only for queries whose certificate failed: a plain fp64 sweep.
+//  3. knn_exact_fallback + knn_exact_fb_merge  only for queries whose certificate failed: a plain fp64
+//                     sweep, parallel over row slabs.
 //
 // Roofline: algorithmic bytes per sweep = N*D*4; MFMA time at TQ=32 is
 // 16 B/clk/CU (> the 10.3 B/clk/CU HBM feed), so the sweep is HBM-bound for nq <= 32.
@@ -392,8 +393,13 @@ struct MergeParams {
     const float* part_maxnorm;
     float* outD;
     int64_t* outI;
-    int32_t* flags;   // [nq] 1 = certificate failed -> exact fallback
+    int32_t* flags;   // [nq] 0 = certified; slot + 1 = exact fallback over fb_S row slabs; -1 = fallback, no slot
     int32_t* stats;   // optional
+    // slab-parallel exact fallback: fb_F slots of fb_S slabs x k (exact distance, id) partial results
+    int fb_S, fb_F;
+    double* fb_d;
+    int32_t* fb_i;
+    int32_t* fb_slotctr;
 };
 
 constexpr int kMergeThreads = 256;
@@ -568,8 +574,13 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
             const double kth = dmisc[1];
             ok = (ns >= kout) && (kth < a_last - E + qn2);
         }
-        prm.flags[q] = ok ? 0 : 1;
-        if (!ok && prm.stats) atomicAdd(&prm.stats[0], 1);
+        int flag = 0;
+        if (!ok) {
+            const int slot = atomicAdd(prm.fb_slotctr, 1);
+            flag = slot < prm.fb_F ? slot + 1 : -1;
+            if (prm.stats) atomicAdd(&prm.stats[0], 1);
+        }
+        prm.flags[q] = flag;
     }
 }
 
@@ -582,9 +593,16 @@ constexpr int kFbWaves = kFbThreads / 64;
 constexpr int kFbCap = 1024;          // list capacity (k <= 248 -> prune keeps k)
 constexpr int kFbRound = 32;          // rows per wave between barriers
 
+// grid = (fb_S, nq): block (s, q) scans row slab s of a flagged query and writes its exact top-k to the
+// query's slot; knn_exact_fb_merge then merges the slabs.  A flagged query without a slot (more than fb_F
+// failures in one call) is handled by its s == 0 block alone over the whole store.
 __global__ __launch_bounds__(kFbThreads) void knn_exact_fallback(MergeParams prm) {
-    const int q = blockIdx.x;
-    if (!prm.flags[q]) return;
+    const int q = blockIdx.y, slab = blockIdx.x;
+    const int flag = prm.flags[q];
+    if (flag == 0 || (flag < 0 && slab != 0)) return;
+    const bool direct = flag < 0;
+    const int64_t row_lo = direct ? 0 : (prm.N * slab) / prm.fb_S;
+    const int64_t row_hi = direct ? prm.N : (prm.N * (slab + 1)) / prm.fb_S;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* ld = reinterpret_cast<double*>(smem);                  // [kFbCap]
@@ -630,11 +648,11 @@ __global__ __launch_bounds__(kFbThreads) void knn_exact_fallback(MergeParams prm
         __syncthreads();
     };
 
-    for (int64_t base = 0; base < prm.N; base += (int64_t)kFbWaves * kFbRound) {
+    for (int64_t base = row_lo; base < row_hi; base += (int64_t)kFbWaves * kFbRound) {
         const double td = *tau_d; const int32_t ti = *tau_i;
         for (int m = 0; m < kFbRound; ++m) {
             const int64_t row = base + (int64_t)m * kFbWaves + wave;
-            if (row >= prm.N) break;
+            if (row >= row_hi) break;
             const f32x4* prow = reinterpret_cast<const f32x4*>(prm.P + (size_t)row * prm.ldP);
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             for (int c4 = lane; c4 < nc4; c4 += 64) {
@@ -659,9 +677,52 @@ __global__ __launch_bounds__(kFbThreads) void knn_exact_fallback(MergeParams prm
     }
     prune();
     const int n = misc[0];
-    for (int t = tid; t < k; t += kFbThreads) {
-        prm.outD[(size_t)q * k + t] = t < n ? (float)ld[t] : FLT_MAX;
-        prm.outI[(size_t)q * k + t] = t < n ? (int64_t)li[t] + prm.row_offset : -1;
+    if (direct) {
+        for (int t = tid; t < k; t += kFbThreads) {
+            prm.outD[(size_t)q * k + t] = t < n ? (float)ld[t] : FLT_MAX;
+            prm.outI[(size_t)q * k + t] = t < n ? (int64_t)li[t] + prm.row_offset : -1;
+        }
+    } else {
+        const size_t base = ((size_t)(flag - 1) * prm.fb_S + slab) * k;
+        for (int t = tid; t < k; t += kFbThreads) {
+            prm.fb_d[base + t] = t < n ? ld[t] : INFINITY;
+            prm.fb_i[base + t] = t < n ? li[t] : 0x7fffffff;
+        }
+    }
+}
+
+// merge the fb_S slab results of a flagged query: bitonic sort of fb_S * k (<= 4096) exact entries
+__global__ __launch_bounds__(256) void knn_exact_fb_merge(MergeParams prm, int npow2) {
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int flag = prm.flags[q];
+    if (flag <= 0) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ds = reinterpret_cast<double*>(smem);
+    int32_t* is = reinterpret_cast<int32_t*>(ds + npow2);
+    const int n = prm.fb_S * prm.k;
+    const size_t base = (size_t)(flag - 1) * n;
+    for (int t = tid; t < npow2; t += 256) {
+        ds[t] = t < n ? prm.fb_d[base + t] : INFINITY;
+        is[t] = t < n ? prm.fb_i[base + t] : 0x7fffffff;
+    }
+    __syncthreads();
+    for (int size = 2; size <= npow2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (npow2 >> 1); t += 256) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool asc = (lo & size) == 0;
+                const double dl = ds[lo], dh = ds[hi];
+                const int32_t il = is[lo], ih = is[hi];
+                const bool gt = dl > dh || (dl == dh && il > ih);
+                if (gt == asc) { ds[lo] = dh; ds[hi] = dl; is[lo] = ih; is[hi] = il; }
+            }
+            __syncthreads();
+        }
+    for (int t = tid; t < prm.k; t += 256) {
+        const bool real = is[t] != 0x7fffffff;
+        prm.outD[(size_t)q * prm.k + t] = real ? (float)ds[t] : FLT_MAX;
+        prm.outI[(size_t)q * prm.k + t] = real ? (int64_t)is[t] + prm.row_offset : -1;
     }
 }
 
@@ -794,7 +855,8 @@ struct Plan {
     int TQ, kp, cap, ng, Dp, G, nqt;
     int64_t ntiles;
     size_t sweep_lds, merge_lds, fb_lds;
-    size_t off_part_d, off_part_i, off_maxnorm, off_flags, off_zeros, total;
+    size_t off_part_d, off_part_i, off_maxnorm, off_flags, off_zeros, off_fb_d, off_fb_i, off_fb_ctr, total;
+    int fb_S, fb_F;
 };
 
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
@@ -820,6 +882,7 @@ static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
             pl->TQ = 16; pl->kp = 0; pl->cap = 0; pl->ng = 0; pl->G = 1; pl->nqt = 1; pl->ntiles = 0;
             pl->sweep_lds = pl->merge_lds = pl->fb_lds = 0;
             pl->off_part_d = pl->off_part_i = pl->off_maxnorm = pl->off_flags = pl->off_zeros = 0;
+            pl->off_fb_d = pl->off_fb_i = pl->off_fb_ctr = 0; pl->fb_S = pl->fb_F = 1;
             pl->total = 256;
             return AC_OK;
         }
@@ -872,6 +935,15 @@ static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
     pl->off_maxnorm = off; off += ac::align_up((size_t)pl->G * pl->nqt * 4, 256);
     pl->off_flags = off; off += ac::align_up((size_t)(nq > 0 ? nq : 1) * 4, 256);
     pl->off_zeros = off; off += 256;
+    // slab-parallel exact fallback: fb_S * k <= 4096 entries per slot, up to 64 slots
+    pl->fb_S = 4096 / next_pow2(k);
+    if (pl->fb_S > 64) pl->fb_S = 64;
+    if (pl->fb_S < 1) pl->fb_S = 1;
+    pl->fb_F = nq < 64 ? (nq > 0 ? nq : 1) : 64;
+    const size_t fb_entries = (size_t)pl->fb_F * pl->fb_S * k;
+    pl->off_fb_d = off; off += ac::align_up(fb_entries * 8, 256);
+    pl->off_fb_i = off; off += ac::align_up(fb_entries * 4, 256);
+    pl->off_fb_ctr = off; off += 256;
     pl->total = off;
     pl->merge_lds = ac::align_up((size_t)pl->G * pl->kp * 4, 16) + ac::align_up((size_t)pl->Dp * 4, 16) +
                     (size_t)pl->kp * 16 + 256 * 4 + 64;
@@ -942,6 +1014,11 @@ extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, c
     mp.outD = d_outD; mp.outI = d_outI;
     mp.flags = (int32_t*)(ws + pl.off_flags);
     mp.stats = d_stats;
+    mp.fb_S = pl.fb_S; mp.fb_F = pl.fb_F;
+    mp.fb_d = (double*)(ws + pl.off_fb_d);
+    mp.fb_i = (int32_t*)(ws + pl.off_fb_i);
+    mp.fb_slotctr = (int32_t*)(ws + pl.off_fb_ctr);
+    AC_HIP_CHECK(hipMemsetAsync(ws + pl.off_fb_ctr, 0, 256, stream));
 
     if (N == 0) {
         // empty shard: everything is padding; reuse the merge kernel with all-padding partials
@@ -978,7 +1055,11 @@ extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, c
     if (N > 0) {
         (void)hipFuncSetAttribute((const void*)knn_exact_fallback, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)pl.fb_lds);
-        hipLaunchKernelGGL(knn_exact_fallback, dim3(nq), dim3(kFbThreads), pl.fb_lds, stream, mp);
+        hipLaunchKernelGGL(knn_exact_fallback, dim3(pl.fb_S, nq), dim3(kFbThreads), pl.fb_lds, stream, mp);
+        AC_LAUNCH_CHECK();
+        const int np2 = next_pow2(pl.fb_S * k > 2 ? pl.fb_S * k : 2);
+        (void)hipFuncSetAttribute((const void*)knn_exact_fb_merge, hipFuncAttributeMaxDynamicSharedMemorySize, np2 * 12);
+        hipLaunchKernelGGL(knn_exact_fb_merge, dim3(nq), dim3(256), (size_t)np2 * 12, stream, mp, np2);
         AC_LAUNCH_CHECK();
     }
     return AC_OK;

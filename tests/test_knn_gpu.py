@@ -156,3 +156,14 @@ def test_topk_merge_and_scores(cuda_dev):
     ref = knn_oracle.proto_scores(oD, oI)
     assert np.allclose(sc, ref, atol=1e-6)            # fp32 exp/softmax: 1e-6 absolute
     assert np.allclose(sc.sum(1), 1.0, atol=1e-5)     # tests/test_memory.py:84-85
+
+
+def test_knn_many_fallbacks_slots_and_direct(cuda_dev):
+    """More flagged queries (100) than fallback slots (64): slab-parallel path and single-block path agree
+    with the oracle; ties resolved lowest-id first."""
+    from oracle import synth
+    base = synth.synth_unit_rows(100, 256, seed=11)
+    P = np.concatenate([base] * 30, axis=0)          # 30 exact copies: the tie group straddles k' = k + 8
+    Q = base[:100].copy()
+    nfb = _check(P, Q, 16, cuda_dev)
+    assert nfb == 100
