@@ -233,3 +233,31 @@ def test_fused_train_step_with_in_kernel_dropout_and_gather(cuda_dev):
     assert abs(tr.loss_accum.item() - tot) < 1e-3            # device-side epoch loss accumulation
     # keep-rate of the counter-based masks is ~0.9
     assert abs(_dropout_keep_np(1, 512, 768, 0.1).mean() - 0.9) < 0.005
+
+
+def test_linear_randomised_shapes(cuda_dev):
+    """Random (M, N, K, act, residual) through ac_linear_f32: exercises the small-M weight-streaming kernel,
+    the direct kernel and both LDS tile heights, with ragged edges."""
+    from adaptive_classifier import _native as nv
+    rng = np.random.default_rng(7)
+    for case in range(36):
+        M = int(rng.choice([1, 3, 16, 17, 33, 64, 65, 150, 192, 200, 257, 640, 1000]))
+        N = int(rng.choice([4, 16, 20, 100, 128, 130, 384, 768, 1000]))
+        K = int(rng.choice([4, 8, 12, 32, 36, 64, 96, 100, 384, 768]))
+        act = int(rng.integers(0, 3))
+        use_res = bool(rng.integers(0, 2))
+        g = torch.Generator().manual_seed(case)
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        R = torch.randn(M, N, generator=g)
+        ref = A.double() @ W.double().T + b.double()
+        ref = torch.relu(ref) if act == 1 else torch.nn.functional.gelu(ref) if act == 2 else ref
+        if use_res:
+            ref = ref + R.double()
+        Ad, Wd, bd, Rd = (t.to(cuda_dev) for t in (A, W, b, R))
+        C = torch.full((M, N), float("nan"), device=cuda_dev)
+        nv.check(nv.lib().ac_linear_f32(nv.ptr(Ad), K, nv.ptr(Wd), K, nv.ptr(bd), nv.ptr(Rd) if use_res else None, N,
+                                        nv.ptr(C), N, M, N, K, act, nv.stream_ptr(cuda_dev)), "ac_linear_f32")
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (M, N, K, act, use_res, err)

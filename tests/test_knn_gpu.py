@@ -167,3 +167,22 @@ def test_knn_many_fallbacks_slots_and_direct(cuda_dev):
     Q = base[:100].copy()
     nfb = _check(P, Q, 16, cuda_dev)
     assert nfb == 100
+
+
+def test_knn_randomised_shapes(cuda_dev):
+    """40 seeded random (N, D, nq, k) combinations incl. odd sizes, k near the limits, scaled / shifted data
+    and sprinkled duplicate rows: ids bit-exact, distances to 1 ulp."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        N = int(rng.choice([1, 2, 7, 63, 64, 65, 127, 129, 500, 1023, 2049, 6000, 12345]))
+        D = int(rng.choice([4, 12, 60, 64, 100, 128, 384, 768, 772, 1024, 1536]))
+        nq = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 70]))
+        k = int(rng.choice([1, 2, 5, 16, 32, 57, 100, 240, 248]))
+        scale = float(rng.choice([1.0, 1e-3, 50.0]))
+        P = (rng.standard_normal((N, D)) * scale + float(rng.choice([0.0, 3.0]))).astype(np.float32)
+        if N > 10 and rng.random() < 0.5:
+            P[rng.integers(0, N, size=N // 5)] = P[rng.integers(0, N)]      # duplicate rows
+        Q = (rng.standard_normal((nq, D)) * scale).astype(np.float32)
+        if rng.random() < 0.3:
+            Q[0] = P[0]
+        _check(P, Q, k, cuda_dev, row_offset=int(rng.choice([0, 7, 1 << 40])))
