@@ -102,31 +102,45 @@ def time_stages(clf, ids, types, mask, reps=5):
 
 
 def sweep_roofline(dev, n_rows):
-    """knn_sweep alone over n_rows x 768 with 16 resident queries: algorithmic bytes / kernel time."""
+    """knn_sweep alone over n_rows x 768: algorithmic bytes / kernel time (HIP events around the kernel).
+    The headline entry uses 16 resident queries; `by_resident_queries` lists 1 / 8 / 16 / 32."""
     from adaptive_classifier import _native as nv
     from adaptive_classifier import index as ix
-    nq, k = 16, 32
+    k = 32
     P = ix.synth_unit_rows(n_rows, DIM, 1, device=dev)
-    Q = ix.synth_unit_rows(nq, DIM, 2, device=dev)
-    ws = torch.empty(ix.knn_workspace_bytes(n_rows, DIM, nq, k), dtype=torch.uint8, device=dev)
-    stats = torch.zeros(4, dtype=torch.int32, device=dev)
-    out = (torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev))
+    bytes_alg = n_rows * DIM * 4
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); e1.record(); torch.cuda.synchronize()          # materialise the hipEvent handles
-    for _ in range(2):
-        ix.knn_l2_topk(P, n_rows, DIM, Q, k, out=out, workspace=ws, stats=stats)
-    torch.cuda.synchronize()
-    times = []
-    nv.lib().ac_knn_set_profile_events(e0.cuda_event, e1.cuda_event)
-    try:
-        for _ in range(8):
+
+    def measure(nq, reps):
+        Q = ix.synth_unit_rows(nq, DIM, 2, device=dev)
+        ws = torch.empty(ix.knn_workspace_bytes(n_rows, DIM, nq, k), dtype=torch.uint8, device=dev)
+        stats = torch.zeros(4, dtype=torch.int32, device=dev)
+        out = (torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev))
+        for _ in range(2):
             ix.knn_l2_topk(P, n_rows, DIM, Q, k, out=out, workspace=ws, stats=stats)
-            torch.cuda.synchronize()
-            times.append(e0.elapsed_time(e1))
-    finally:
-        nv.lib().ac_knn_set_profile_events(None, None)
-    ms = float(np.mean(times))
-    bytes_alg = n_rows * DIM * 4
+        torch.cuda.synchronize()
+        times, calls = [], []
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nv.lib().ac_knn_set_profile_events(e0.cuda_event, e1.cuda_event)
+        try:
+            for _ in range(reps):
+                c0.record()
+                ix.knn_l2_topk(P, n_rows, DIM, Q, k, out=out, workspace=ws, stats=stats)
+                c1.record()
+                torch.cuda.synchronize()
+                times.append(e0.elapsed_time(e1))
+                calls.append(c0.elapsed_time(c1))
+        finally:
+            nv.lib().ac_knn_set_profile_events(None, None)
+        return float(np.mean(times)), float(np.min(times)), float(np.mean(calls)), int(stats[0].item())
+
+    ms, ms_min, call_ms, nfb = measure(16, 8)
+    table = {}
+    for nq in (1, 8, 16, 32):
+        t, _, c, _ = (ms, ms_min, call_ms, nfb) if nq == 16 else measure(nq, 4)
+        table[str(nq)] = {"kernel_ms": t, "GBps": bytes_alg / t / 1e6, "frac": bytes_alg / t / 1e6 / HBM_PEAK_GBS,
+                          "whole_call_ms": c}
     # HBM traffic per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 gfx950 correction,
     # profiles/<round>/knn_sweep_pmc.json); null when no pass exists for this problem size.
     traffic, traffic_src = None, None
@@ -140,9 +154,9 @@ def sweep_roofline(dev, n_rows):
     torch.cuda.empty_cache()
     return {"bound": "hbm", "achieved": bytes_alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "knn_sweep<1> (16-query tile)", "rows": n_rows, "dim": DIM, "resident_queries": nq,
-            "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": ms, "min_kernel_ms": float(np.min(times)),
-            "exact_fallback_queries": int(stats[0].item())}
+            "kernel": "knn_sweep<1> (16-query tile)", "rows": n_rows, "dim": DIM, "resident_queries": 16,
+            "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": ms, "min_kernel_ms": ms_min,
+            "whole_call_ms": call_ms, "exact_fallback_queries": nfb, "by_resident_queries": table}
 
 
 def cpu_baseline(hf, clf, rows_dev, sample=2048, chunk=64):
