@@ -46,7 +46,8 @@ class PrototypeMemory:
         self.label_to_index = {}
         self.index_to_label = {}
         self.updates_since_rebuild = 0
-        self._sums = {}                      # label -> fp64 running sum of the stored embeddings
+        self._sums = {}                      # label -> (fp64 running sum of the stored embeddings, count)
+        self._mats = {}                      # label -> [host matrix of the stored embeddings, count]
         self._dirty = set()                  # labels whose index row is out of date
         self._lock = threading.RLock()       # add_example is called from threads (test_memory.py:226-256)
         self._row_labels = None              # int32 device tensor when load_rows() is in use
@@ -56,6 +57,24 @@ class PrototypeMemory:
         return HipFlatL2Index(self.embedding_dim, device=self._device)
 
     # ------------------------------------------------------------------ add / prune / prototype
+    def _class_matrix(self, label, n_needed):
+        """[rows >= n_needed, D] host matrix mirroring self.examples[label][:count]; rebuilt when the
+        list was edited behind our back (the classifier assigns / deletes lists directly)."""
+        ent = self._mats.get(label)
+        exs = self.examples[label]
+        count = len(exs) - 1                       # rows that must already be mirrored (all but the new one)
+        if ent is None or ent[1] != count or ent[0].shape[0] < n_needed:
+            rows = max(n_needed, 2 * (ent[0].shape[0] if ent is not None else 0), 64)
+            mat = torch.empty((rows, self.embedding_dim), dtype=torch.float32)
+            if count:
+                if ent is not None and ent[1] == count:
+                    mat[:count] = ent[0][:count]
+                else:
+                    mat[:count] = torch.stack([ex.embedding for ex in exs[:count]])
+            ent = [mat, count]
+            self._mats[label] = ent
+        return ent
+
     def add_example(self, example: Example, label: str):
         if example.embedding is None:
             raise ValueError("Example must have an embedding")
@@ -67,16 +86,17 @@ class PrototypeMemory:
             if example.embedding.is_cuda:
                 example.embedding = example.embedding.detach().cpu()   # prototypes stay on the host
             self.examples[label].append(example)
-            n_prev = len(self.examples[label]) - 1
+            n = len(self.examples[label])
+            ent = self._class_matrix(label, n)
+            ent[0][n - 1] = example.embedding
+            ent[1] = n
             cached = self._sums.get(label)
-            if cached is None or cached[1] != n_prev:       # first add, or the list was edited behind us
-                s = torch.zeros(self.embedding_dim, dtype=torch.float64)
-                for ex in self.examples[label][:-1]:
-                    s += ex.embedding.double()
+            if cached is None or cached[1] != n - 1:        # first add, or the list was edited behind us
+                s = ent[0][: n - 1].double().sum(0)
             else:
                 s = cached[0]
-            self._sums[label] = (s + example.embedding.detach().double(), n_prev + 1)
-            if len(self.examples[label]) > self.config.max_examples_per_class:
+            self._sums[label] = (s + example.embedding.detach().double(), n)
+            if n > self.config.max_examples_per_class:
                 self._prune_examples(label)
             self._update_prototype(label)
             # counter / lazy rebuild logic of memory.py:70-81
@@ -101,20 +121,37 @@ class PrototypeMemory:
             self._dirty.add(label)           # row refreshed in place at the next search
 
     def _prune_examples(self, label: str):
-        """Keep the max_examples_per_class examples closest to the class mean (memory.py:196-217)."""
+        """Keep the max_examples_per_class examples closest to the class mean, in ascending-distance
+        order like the reference (memory.py:196-217).  One vectorised pass over the class matrix instead of
+        re-stacking every stored embedding."""
         examples = self.examples[label]
         if not examples:
             return
-        emb = torch.stack([ex.embedding for ex in examples])
-        cached = self._sums.get(label)
-        if cached is not None and cached[1] == len(examples):
-            mean = (cached[0] / len(examples)).to(torch.float32)
+        n = len(examples)
+        ent = self._mats.get(label)
+        if ent is not None and ent[1] == n:
+            emb = ent[0][:n]
         else:
-            mean = emb.mean(0)
+            emb = torch.stack([ex.embedding for ex in examples])
+        cached = self._sums.get(label)
+        total = cached[0] if cached is not None and cached[1] == n else emb.double().sum(0)
+        mean = (total / n).to(torch.float32)
         dist = torch.linalg.vector_norm(emb - mean, dim=1).numpy()
-        keep = np.argsort(dist)[: self.config.max_examples_per_class]
+        order = np.argsort(dist)
+        keep = order[: self.config.max_examples_per_class]
         self.examples[label] = [examples[i] for i in keep]
-        self._sums[label] = (emb[torch.from_numpy(np.asarray(keep))].double().sum(0), len(keep))
+        kept = emb[torch.from_numpy(np.ascontiguousarray(keep))]
+        dropped = order[self.config.max_examples_per_class:]
+        if len(dropped) <= 8:                       # the usual case: one over the cap
+            new_sum = total - emb[torch.from_numpy(np.ascontiguousarray(dropped))].double().sum(0)
+        else:
+            new_sum = kept.double().sum(0)
+        self._sums[label] = (new_sum, len(keep))
+        if ent is not None and ent[0].shape[0] >= len(keep):
+            ent[0][: len(keep)] = kept
+            ent[1] = len(keep)
+        else:
+            self._mats.pop(label, None)
         assert len(self.examples[label]) <= self.config.max_examples_per_class
 
     # ------------------------------------------------------------------ index maintenance
@@ -246,6 +283,7 @@ class PrototypeMemory:
             self.examples.clear()
             self.prototypes.clear()
             self._sums.clear()
+            self._mats.clear()
             self._dirty.clear()
             self.index = self._new_index()
             self.label_to_index.clear()
@@ -257,4 +295,5 @@ class PrototypeMemory:
     def drop_label(self, label):
         """Forget cached sums when the classifier deletes a label's examples (classifier.py:1396-1399)."""
         self._sums.pop(label, None)
+        self._mats.pop(label, None)
         self._dirty.discard(label)

@@ -259,3 +259,22 @@ def test_multilabel_thresholds_and_decisions_match_reference():
     w = h.model[-1].weight.detach().clone()
     h.update_num_classes(5)
     assert h.num_classes == 5 and torch.equal(h.model[-1].weight[:3], w) and h(torch.randn(4, 16)).shape == (4, 5)
+
+
+def test_prune_matches_reference_algorithm_step_by_step():
+    """memory.py:196-217 restated literally (stack, mean, per-example torch.norm, argsort, keep closest in
+    ascending-distance order) vs the vectorised class-matrix implementation, after every add."""
+    import numpy as np
+    m = PrototypeMemory(16, ModelConfig({"max_examples_per_class": 7}))
+    E = torch.randn(60, 16, generator=torch.Generator().manual_seed(0))
+    ref = []
+    for i in range(60):
+        m.add_example(Example(f"t{i}", "x", E[i]), "x")
+        ref.append(E[i])
+        if len(ref) > 7:
+            mean = torch.stack(ref).mean(0)
+            keep = np.argsort([torch.norm(e - mean).item() for e in ref])[:7]
+            ref = [ref[j] for j in keep]
+        assert len(m.examples["x"]) == len(ref)
+        assert all(torch.equal(a.embedding, b) for a, b in zip(m.examples["x"], ref)), i
+        assert torch.allclose(m.prototypes["x"], torch.stack(ref).mean(0), atol=1e-6)
