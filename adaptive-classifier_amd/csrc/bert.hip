@@ -114,95 +114,110 @@ __global__ __launch_bounds__(256) void cls_normalize_kernel(const float* x, int 
     for (int c = H + lane; c < ldo; c += 64) out[(int64_t)i * ldo + c] = 0.f;
 }
 
-// ---- fused attention, head dim 64, fp32 ----
-// grid = (ceil(S/64), heads, batch), block = one wave.  Lane = one query row.
-constexpr int DH = 64;
-constexpr int KT = 64;        // keys per LDS tile
-constexpr int CH = 16;        // keys per online-softmax chunk
+constexpr int DH = 64;        // head dim (checked in ac_bert_encode_cls)
+constexpr int KT = 64;        // keys per LDS tile of the CLS-only kernel
 
-__global__ __launch_bounds__(64) void attention_kernel(const float* qkv, const int64_t* mask, int S, int H,
-                                                       float scale, float* ctx) {
-    __shared__ __attribute__((aligned(16))) float Ks[KT][DH];
-    __shared__ __attribute__((aligned(16))) float Vs[KT][DH];
-    __shared__ int valid_s[KT];
+// ---- fused attention on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), head dim 64 ----
+// One wave per (sequence, head, 32-query tile); grid = (ceil(S/32), heads, batch).
+//   S^T tile = K_tile . Q^T  : A = K rows (lane (key j, k-slice h) holds float4 K[j][8kb+4h..]),
+//                              B = Q rows (same shape, pre-scaled, resident in registers)
+//                              -> C layout: lane & 31 = QUERY, registers = the tile's 32 keys
+//   so the online softmax (max / sum over keys) is per-lane register work plus ONE exchange with the
+//   partner lane (lane ^ 32) -- no LDS, no row reductions across the wave.
+//   O^T += V_tile^T . P^T    : B = P, which is ALREADY in B-operand layout (lane = query, k = lane >> 5:
+//                              MFMA step r consumes keys row(r,0) and row(r,1)); A = V^T read as
+//                              V[key][32t + (lane & 31)] (128-B coalesced rows).  C layout again has
+//                              lane & 31 = query, so the rescale by exp(m_old - m_new) is per lane.
+// The k-order inside a tile is whatever the C layout dictates -- a dot product does not care.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int crow32(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, const int64_t* mask, int S, int H,
+                                                            float scale, float* ctx) {
     const int lane = threadIdx.x;
     const int qt = blockIdx.x, head = blockIdx.y, bi = blockIdx.z;
     const int64_t ld = 3 * (int64_t)H;
     const float* base = qkv + (int64_t)bi * S * ld + head * DH;
-    const int qi = qt * 64 + lane;
+    const int j = lane & 31, h = lane >> 5;
+    const int qi = qt * 32 + j;
     const bool qvalid = qi < S;
 
-    f32x4 q[DH / 4], o[DH / 4];
+    f32x4 Qf[8];
     {
-        const float* qp = base + (int64_t)(qvalid ? qi : S - 1) * ld;
+        const float* qp = base + (int64_t)(qvalid ? qi : S - 1) * ld + 4 * h;
 #pragma unroll
-        for (int d = 0; d < DH / 4; ++d) {
-            q[d] = *reinterpret_cast<const f32x4*>(qp + 4 * d) * scale;
-            o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int kb = 0; kb < 8; ++kb) Qf[kb] = *reinterpret_cast<const f32x4*>(qp + 8 * kb) * scale;
     }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = -INFINITY, l = 0.f;
 
-    for (int k0 = 0; k0 < S; k0 += KT) {
-        const int nk = (S - k0) < KT ? (S - k0) : KT;
-        __syncthreads();
-        // stage K/V tile: 16 lanes per key row (256 B contiguous), 4 keys per pass
-        for (int r = lane >> 4; r < KT; r += 4) {
-            const int c = (lane & 15) * 4;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (r < nk) {
-                const float* kp = base + (int64_t)(k0 + r) * ld + H;
-                kv = *reinterpret_cast<const f32x4*>(kp + c);
-                vv = *reinterpret_cast<const f32x4*>(kp + H + c);
-            }
-            *reinterpret_cast<f32x4*>(&Ks[r][c]) = kv;
-            *reinterpret_cast<f32x4*>(&Vs[r][c]) = vv;
+    // K fragment of a tile (keys past S are clamped; they are masked below).  The next tile's fragment is
+    // requested right after the QK^T MFMAs have consumed this one, so its latency hides under softmax + PV.
+    f32x4 Kf[8];
+    auto load_k = [&](int k0) {
+        int kr = k0 + j; if (kr > S - 1) kr = S - 1;
+        const float* kp = base + (int64_t)kr * ld + H + 4 * h;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) Kf[kb] = *reinterpret_cast<const f32x4*>(kp + 8 * kb);
+    };
+    load_k(0);
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        // key validity as a 32-bit mask shared by the wave
+        const int kj = k0 + j;
+        const bool kv = kj < S && (!mask || mask[(int64_t)bi * S + kj] != 0);
+        const unsigned vmask = (unsigned)(__ballot(kv && h == 0) & 0xffffffffull);
+        if (vmask == 0u) { load_k(k0 + 32); continue; }              // wave-uniform
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                st = __builtin_amdgcn_mfma_f32_32x32x2f32(Kf[kb][s4], Qf[kb][s4], st, 0, 0, 0);
+        load_k(k0 + 32);                                             // clamped past the end: harmless re-read
+        // online softmax for query `j` (this lane + partner lane hold its 32 keys)
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = (vmask >> crow32(r, h)) & 1u;
+            st[r] = ok ? st[r] : -INFINITY;
+            cmax = fmaxf(cmax, st[r]);
         }
-        if (lane < KT) valid_s[lane] = (lane < nk) && (!mask || mask[(int64_t)bi * S + k0 + lane] != 0);
-        __syncthreads();
-
-        for (int c0 = 0; c0 < nk; c0 += CH) {
-            float s[CH];
-            float cmax = -INFINITY;
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float m_new = fmaxf(m, cmax);                          // finite: the tile has a valid key
+        const float corr = expf(m - m_new);                         // m = -inf -> 0
+        float psum = 0.f;
+        float p[16];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                float acc = 0.f;
-                const f32x4* kr = reinterpret_cast<const f32x4*>(&Ks[c0 + j][0]);   // uniform address: broadcast
+        for (int r = 0; r < 16; ++r) { p[r] = expf(st[r] - m_new); psum += p[r]; }
+        psum += __shfl_xor(psum, 32);
+        l = l * corr + psum;
+        m = m_new;
 #pragma unroll
-                for (int d = 0; d < DH / 4; ++d) {
-                    const f32x4 kk = kr[d];
-                    acc = fmaf(q[d].x, kk.x, acc); acc = fmaf(q[d].y, kk.y, acc);
-                    acc = fmaf(q[d].z, kk.z, acc); acc = fmaf(q[d].w, kk.w, acc);
-                }
-                s[j] = (c0 + j < KT && valid_s[c0 + j]) ? acc : -INFINITY;   // additive -inf mask
-                cmax = fmaxf(cmax, s[j]);
-            }
-            const float m_new = fmaxf(m, cmax);
-            if (m_new == -INFINITY) continue;      // wave-uniform in practice (mask is per key)
-            const float corr = expf(m - m_new);    // m = -inf -> 0
-            l *= corr;
+        for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+        // O^T += V^T P^T
 #pragma unroll
-            for (int d = 0; d < DH / 4; ++d) o[d] *= corr;
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const float p = expf(s[j] - m_new);
-                l += p;
-                const f32x4* vr = reinterpret_cast<const f32x4*>(&Vs[c0 + j][0]);
-#pragma unroll
-                for (int d = 0; d < DH / 4; ++d) {
-                    const f32x4 vv = vr[d];
-                    o[d].x = fmaf(p, vv.x, o[d].x); o[d].y = fmaf(p, vv.y, o[d].y);
-                    o[d].z = fmaf(p, vv.z, o[d].z); o[d].w = fmaf(p, vv.w, o[d].w);
-                }
-            }
-            m = m_new;
+        for (int r = 0; r < 16; ++r) {
+            int vr = k0 + crow32(r, h); if (vr > S - 1) vr = S - 1;
+            const float* vp = base + (int64_t)vr * ld + 2 * H + j;
+            const float v0 = vp[0], v1 = vp[32];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, p[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, p[r], o1, 0, 0, 0);
         }
     }
     if (qvalid) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
         float* dst = ctx + ((int64_t)bi * S + qi) * H + head * DH;
+        // C layout of O^T: lane & 31 = query (this lane), register r = output dim crow32(r, h) (+32 for o1)
 #pragma unroll
-        for (int d = 0; d < DH / 4; ++d) *reinterpret_cast<f32x4*>(dst + 4 * d) = o[d] * inv;
+        for (int r = 0; r < 16; ++r) {
+            dst[crow32(r, h)] = o0[r] * inv;
+            dst[32 + crow32(r, h)] = o1[r] * inv;
+        }
     }
 }
 
@@ -336,8 +351,8 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
         if (last) {
             hipLaunchKernelGGL(attention_cls_kernel, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale, ctx);
         } else {
-            hipLaunchKernelGGL(attention_kernel, dim3((S + 63) / 64, c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H,
-                               scale, ctx);
+            hipLaunchKernelGGL(attention_mfma_kernel, dim3((S + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv, d_mask,
+                               S, H, scale, ctx);
         }
         AC_LAUNCH_CHECK();
         const int lblocks = (Ml + 3) / 4;

@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
     (768, 12, 12, 3072, 8, 32, True),     # bert-base, BASELINE configs[0] shape (batch 8)
     (768, 2, 12, 3072, 3, 130, True),     # S > one key tile, odd sizes
     (1024, 3, 16, 4096, 4, 24, False),    # bert-large / e5-large-v2 width
+    (768, 2, 12, 3072, 2, 512, True),     # the reference's max_length (classifier.py:1262), 16 key tiles
+    (768, 1, 12, 3072, 3, 33, True),      # one key past a tile boundary
 ])
 def test_encoder_cls_matches_transformers(hidden, layers, heads, inter, b, S, ragged, cuda_dev):
     from adaptive_classifier.encoder import HipBertEncoder
