@@ -54,7 +54,7 @@ __host__ __device__ static inline size_t align_up(size_t x, size_t a) { return (
 int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
                const uint8_t* mask, float mask_scale, hipStream_t stream, float drop_p = 0.f,
-               uint64_t drop_seed = 0);
+               uint64_t drop_seed = 0, const uint16_t* W_planes = nullptr, const uint16_t* A_planes = nullptr);
 
 // counter-based Bernoulli(1-p) keep decision for in-kernel dropout (stateless: seed + element index)
 __host__ __device__ static inline bool dropout_keep(uint64_t seed, uint64_t idx, float p) {
@@ -64,6 +64,9 @@ __host__ __device__ static inline bool dropout_keep(uint64_t seed, uint64_t idx,
     z ^= z >> 31;
     return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;
 }
+// arithmetic of the LDS-tiled GEMMs (ac_gemm_set_arith / env AC_GEMM_ARITH = f32 | bf16x3)
+int gemm_arith();
+void set_gemm_arith(int mode);
 //   C = alpha * op(A) op(B) + beta * C; if gate != null: C = gate[m,n] != 0 ? C * gate_scale : 0
 int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
              const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* gate,

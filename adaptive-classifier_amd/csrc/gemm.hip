@@ -16,6 +16,9 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
 
 namespace {
 
@@ -71,6 +74,53 @@ __device__ __forceinline__ float fast_epilogue(float acc, float bias, float res)
 }
 
 __device__ __forceinline__ int acc_row32(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// shared epilogue of the LDS-tiled kernels: the 32x32 C/D layout (lane owns column lane & 31, 16 rows)
+template <int EPI, int TM>
+__device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][2], float* __restrict__ C, int64_t ldc, int M, int N,
+                                           int m0, int n0, int wm, int wn, int lane, const Epilogue& epi) {
+    constexpr int BM = 64 * TM;
+    // epilogue: lane owns column (lane & 31) of each 32x32 tile, 16 rows
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+            if (col >= N) continue;
+            const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
+            if (EPI == EPI_GENERIC) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = rbase + acc_row32(r, lane);
+                    if (row < M) C[row * ldc + col] = apply_epilogue(epi, acc[mi][ni][r], row, col, C, ldc, N);
+                }
+            } else {
+                const float bias = epi.bias[col];
+                float res[16];
+                if (EPI == EPI_BIAS_RES) {   // issue all residual loads first, then compute + store
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int64_t row = rbase + acc_row32(r, lane);
+                        if (row > M - 1) row = M - 1;
+                        res[r] = epi.residual[row * epi.ldr + col];
+                    }
+                }
+                if (m0 + BM <= M) {          // block-uniform: interior tile, branch-free stores
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        C[(rbase + acc_row32(r, lane)) * ldc + col] =
+                            fast_epilogue<EPI>(acc[mi][ni][r], bias, EPI == EPI_BIAS_RES ? res[r] : 0.f);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = rbase + acc_row32(r, lane);
+                        const float v = fast_epilogue<EPI>(acc[mi][ni][r], bias, EPI == EPI_BIAS_RES ? res[r] : 0.f);
+                        if (row < M) C[row * ldc + col] = v;
+                    }
+                }
+            }
+        }
+}
 
 // ---------------------------------------------------------------------------------------------
 // LDS-tiled NT kernel: (64*TM) x 128 x 32 block tile, 4 waves as 2(M) x 2(N), wave tile (32*TM) x 64.
@@ -180,46 +230,294 @@ __global__ __launch_bounds__(kTileThreads, TM == 2 ? 2 : 3) void gemm_tile_nt(
         __syncthreads();
     }
 
-    // epilogue: lane owns column (lane & 31) of each 32x32 tile, 16 rows
+    store_tile<EPI, TM>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, epi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-operand NT kernel: the same (64*TM) x 128 x 32 tile on the bf16 matrix pipe at fp32 accuracy.
+//   Every fp32 operand element is split while it is staged into LDS:  x = h + m + l  with
+//   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)  (round-to-nearest-even, v_cvt_pk_bf16_f32; the two
+//   subtractions are exact, so h + m + l == x to 2^-27 |x|).  A tile product is then six
+//   v_mfma_f32_32x32x16_bf16 (h.h, h.m, m.h, m.m, h.l, l.h), each product exact in the fp32 accumulator;
+//   the dropped m.l + l.m + l.l terms are <= 2^-26 |a||b| per product -- below the 2^-24 rounding an
+//   fp32 fma makes on the same product.  Six bf16 MFMAs cost 6/16 of the fp32-input MFMAs they replace.
+//   Non-finite operands give NaN (inf - inf in the split), unlike a true fp32 fma.
+//   LDS image per operand and plane: [row groups of 32][2 k-chunks of 16][64 x 16 B] in fragment order
+//   (lane (i, kg) of chunk c reads 8 bf16 = k 16c + 8kg .. +7 of row i with one ds_read_b128), slots
+//   XOR-swizzled by the k-slot so the 8-lane ds_write_b128 groups hit distinct banks.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const f32x2 f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
+
+// 8 consecutive fp32 (two float4) -> three planes of 8 bf16
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, uint4& H, uint4& Mi, uint4& L) {
+    uint32_t h[4], m[4], l[4];
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
+    for (int p = 0; p < 4; ++p) {
+        const float a = p < 2 ? x0[2 * p] : x1[2 * p - 4], b = p < 2 ? x0[2 * p + 1] : x1[2 * p - 3];
+        h[p] = pack_bf16(a, b);
+        const float ra = a - __uint_as_float(h[p] << 16), rb = b - __uint_as_float(h[p] & 0xffff0000u);
+        m[p] = pack_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(m[p] << 16), sb = rb - __uint_as_float(m[p] & 0xffff0000u);
+        l[p] = pack_bf16(sa, sb);
+    }
+    H = make_uint4(h[0], h[1], h[2], h[3]);
+    Mi = make_uint4(m[0], m[1], m[2], m[3]);
+    L = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+__device__ __forceinline__ int split_slot(int row, int q) {   // q = k-slot of 8 in [0,4)
+    const int rg = row >> 5, i = row & 31, c = q >> 1, kg = q & 1;
+    return ((rg * 2 + c) << 6) + (((kg << 5) + i) ^ (q << 2));
+}
+
+template <int EPI, int TM>
+__global__ __launch_bounds__(kTileThreads, TM == 2 ? 3 : 4) void gemm_split_nt(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
+    float* __restrict__ C, int64_t ldc, int M, int N, int K, Epilogue epi) {
+    constexpr int BM = 64 * TM;
+    constexpr int A_SLOTS = (BM / 32) * 2 * 64, W_SLOTS = (BN / 32) * 2 * 64;
+    constexpr int PA = BM / 64, PW = BN / 64;                // staging passes (64 rows x 4 k-slots each)
+    __shared__ uint4 lds[3][A_SLOTS + W_SLOTS];              // [plane h,m,l][A | W]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (N + BN - 1) / BN;
+    const int bn = blockIdx.x % ntn, bm = blockIdx.x / ntn;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // staging assignment: thread -> (row = tid/4 + 64*p, q = tid%4): 32 B of a row per thread
+    const int srow = tid >> 2, sq = tid & 3;
+    const float* aptr[PA];
+    const float* wptr[PW];
+    int aslot[PA], wslot[PW];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
-            if (col >= N) continue;
-            const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
-            if (EPI == EPI_GENERIC) {
+    for (int p = 0; p < PA; ++p) {
+        int ra = m0 + srow + 64 * p; if (ra > M - 1) ra = M - 1;
+        aptr[p] = A + (int64_t)ra * lda + 8 * sq;
+        aslot[p] = split_slot(srow + 64 * p, sq);
+    }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = rbase + acc_row32(r, lane);
-                    if (row < M) C[row * ldc + col] = apply_epilogue(epi, acc[mi][ni][r], row, col, C, ldc, N);
-                }
-            } else {
-                const float bias = epi.bias[col];
-                float res[16];
-                if (EPI == EPI_BIAS_RES) {   // issue all residual loads first, then compute + store
+    for (int p = 0; p < PW; ++p) {
+        int rw = n0 + srow + 64 * p; if (rw > N - 1) rw = N - 1;
+        wptr[p] = W + (int64_t)rw * ldw + 8 * sq;
+        wslot[p] = A_SLOTS + split_slot(srow + 64 * p, sq);
+    }
+
+    f32x16 acc[TM][2];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int64_t row = rbase + acc_row32(r, lane);
-                        if (row > M - 1) row = M - 1;
-                        res[r] = epi.residual[row * epi.ldr + col];
-                    }
-                }
-                if (m0 + BM <= M) {          // block-uniform: interior tile, branch-free stores
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        C[(rbase + acc_row32(r, lane)) * ldc + col] =
-                            fast_epilogue<EPI>(acc[mi][ni][r], bias, EPI == EPI_BIAS_RES ? res[r] : 0.f);
-                } else {
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t row = rbase + acc_row32(r, lane);
-                        const float v = fast_epilogue<EPI>(acc[mi][ni][r], bias, EPI == EPI_BIAS_RES ? res[r] : 0.f);
-                        if (row < M) C[row * ldc + col] = v;
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    f32x4 ra[PA][2], rw[PW][2];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            ra[p][0] = *reinterpret_cast<const f32x4*>(aptr[p] + k0);
+            ra[p][1] = *reinterpret_cast<const f32x4*>(aptr[p] + k0 + 4);
         }
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            rw[p][0] = *reinterpret_cast<const f32x4*>(wptr[p] + k0);
+            rw[p][1] = *reinterpret_cast<const f32x4*>(wptr[p] + k0 + 4);
+        }
+    };
+    auto store_tile_lds = [&]() {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            uint4 H, Mi, L;
+            split8(ra[p][0], ra[p][1], H, Mi, L);
+            lds[0][aslot[p]] = H; lds[1][aslot[p]] = Mi; lds[2][aslot[p]] = L;
+        }
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            uint4 H, Mi, L;
+            split8(rw[p][0], rw[p][1], H, Mi, L);
+            lds[0][wslot[p]] = H; lds[1][wslot[p]] = Mi; lds[2][wslot[p]] = L;
+        }
+    };
+
+    const int nk = K / BK;
+    load_tile(0);
+    store_tile_lds();
+    __syncthreads();
+
+    const int kg = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        // prefetch the next k-tile into registers (unconditional: see gemm_tile_nt)
+        load_tile((kt + 1 < nk) ? (kt + 1) * BK : kt * BK);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int sl = lane ^ ((2 * c + kg) << 2);
+            bf16x8_t af[TM][3], bf[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+                    af[a][pl] = __builtin_bit_cast(bf16x8_t, lds[pl][(((TM * wm + a) * 2 + c) << 6) + sl]);
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    bf[b][pl] = __builtin_bit_cast(bf16x8_t, lds[pl][A_SLOTS + (((2 * wn + b) * 2 + c) << 6) + sl]);
+            }
+            // smallest products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+            constexpr int PAIRS[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PAIRS[pr][0]], bf[b][PAIRS[pr][1]],
+                                                                            acc[a][b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();          // every wave is done reading this k-tile
+        store_tile_lds();         // unconditional (the last one is a duplicate nobody reads)
+        __syncthreads();
+    }
+    store_tile<EPI, TM>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, epi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pre-split operands ("planes").  A matrix X[rows, K] (K % 8 == 0) is stored as three bf16 planes
+//   P[p][q][row][e],  p = 0,1,2 (h, m, l),  q = k / 8,  e = k % 8          (bf16 units: 3 * rows * K)
+// i.e. k-slot-major: the 16 bytes a lane feeds to v_mfma_f32_32x32x16_bf16 are contiguous, and the
+// 32 rows x 2 k-slots a wave stages for one MFMA chunk are two contiguous 512-B runs -- so a
+// global_load_lds dwordx4 per lane drops the fragment image into LDS in exactly the order the
+// ds_read_b128 of lane (i, kg) wants it (slot = kg * 32 + i): no VGPR staging, no LDS stores, no swizzle.
+// Weights are split once (HipBertEncoder init); activations by their producers or split in-kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows,
+                                                           int K, uint16_t* __restrict__ P) {
+    const int nq = K >> 3;
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= rows * nq) return;
+    const int64_t row = u / nq;
+    const int q = (int)(u - row * nq);
+    const float* src = X + row * ldx + 8 * q;
+    uint4 H, Mi, L;
+    split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), H, Mi, L);
+    const int64_t plane = rows * (int64_t)K;
+    uint16_t* dst = P + ((int64_t)q * rows + row) * 8;
+    *reinterpret_cast<uint4*>(dst) = H;
+    *reinterpret_cast<uint4*>(dst + plane) = Mi;
+    *reinterpret_cast<uint4*>(dst + 2 * plane) = L;
+}
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+constexpr int SBK = 16;   // k per stage = one bf16 MFMA chunk
+
+// C[M,N] = epi(A . W^T) with W given as planes; A as fp32 (split while staged) or as planes.
+//   (64*TM) x 128 x 16 stages, two LDS buffers, ONE barrier per stage (24 MFMAs per wave at TM = 2).
+//   (A three-buffer ring with loads spanning the barrier -- raw s_barrier + counted vmcnt -- measured 12 %
+//   SLOWER at 8192^3: 72 KB of LDS leaves 2 blocks per CU instead of 3, and occupancy is what hides the
+//   fragment-read latency here.)
+template <int EPI, int TM, bool A_PLANES>
+__global__ __launch_bounds__(kTileThreads, 3) void gemm_planes_nt(
+    const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Ap, int64_t a_rows,
+    const uint16_t* __restrict__ Wp, int64_t w_rows, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+    Epilogue epi) {
+    constexpr int BM = 64 * TM;
+    constexpr int RA = BM / 32, RW = BN / 32;                       // 32-row groups per operand
+    __shared__ uint4 lds[2][3][(RA + RW) * 64];                     // [buffer][plane][A groups | W groups][lane]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (N + BN - 1) / BN;
+    const int bn = blockIdx.x % ntn, bm = blockIdx.x / ntn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int i = lane & 31, kg = lane >> 5;
+
+    // W: wave w stages row group w.  Source of (plane p, stage kt): wsrc + p * w_plane + kt * w_step
+    int wrow = n0 + 32 * wave + i; if (wrow > N - 1) wrow = N - 1;
+    const uint16_t* wsrc = Wp + ((int64_t)kg * w_rows + wrow) * 8;
+    const int64_t w_plane = w_rows * (int64_t)K, w_step = 2 * w_rows * 8;
+    // A as planes: waves < RA stage row group `wave`
+    int arow = m0 + 32 * wave + i; if (arow > M - 1) arow = M - 1;
+    const uint16_t* asrc = A_PLANES ? Ap + ((int64_t)kg * a_rows + arow) * 8 : nullptr;
+    const int64_t a_plane = a_rows * (int64_t)K, a_step = 2 * a_rows * 8;
+    // A as fp32: thread -> (row = tid / 2, k-slot = tid % 2), 32 B of a row per thread
+    const int frow = tid >> 1, fkg = tid & 1;
+    int farow = m0 + frow; if (farow > M - 1) farow = M - 1;
+    const float* fsrc = A_PLANES ? nullptr : A + (int64_t)farow * lda + 8 * fkg;
+    const int fslot = (frow >> 5) * 64 + fkg * 32 + (frow & 31);
+    const bool fact = frow < BM;                                    // TM = 1: half the threads stage A
+
+    auto stage_glds = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc + p * w_plane + kt * w_step),
+                                             (lds_void_t*)&lds[buf][p][(RA + wave) * 64], 16, 0, 0);
+        if (A_PLANES && wave < RA) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(asrc + p * a_plane + kt * a_step),
+                                                 (lds_void_t*)&lds[buf][p][wave * 64], 16, 0, 0);
+        }
+    };
+    f32x4 fa0, fa1;
+    auto load_a = [&](int kt) {
+        fa0 = *reinterpret_cast<const f32x4*>(fsrc + kt * SBK);
+        fa1 = *reinterpret_cast<const f32x4*>(fsrc + kt * SBK + 4);
+    };
+    auto store_a = [&](int buf) {
+        uint4 H, Mi, L;
+        split8(fa0, fa1, H, Mi, L);
+        if (fact) { lds[buf][0][fslot] = H; lds[buf][1][fslot] = Mi; lds[buf][2][fslot] = L; }
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = K / SBK;
+    stage_glds(0, 0);
+    if (!A_PLANES) { load_a(0); store_a(0); }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int nxt = (kt + 1 < nk) ? kt + 1 : kt;     // unconditional staging (the last one is a duplicate)
+        stage_glds(nxt, cur ^ 1);
+        if (!A_PLANES) load_a(nxt);
+        bf16x8_t af[TM][3], bf[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a][pl] = __builtin_bit_cast(bf16x8_t, lds[cur][pl][(TM * wm + a) * 64 + lane]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b][pl] = __builtin_bit_cast(bf16x8_t, lds[cur][pl][(RA + 2 * wn + b) * 64 + lane]);
+        }
+        constexpr int PAIRS[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};   // smallest products first
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PAIRS[pr][0]], bf[b][PAIRS[pr][1]],
+                                                                        acc[a][b], 0, 0, 0);
+        if (!A_PLANES) store_a(cur ^ 1);
+        __syncthreads();      // drains the global_load_lds queue (vmcnt(0)) and ends every read of `cur`
+    }
+    store_tile<EPI, TM>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -377,7 +675,9 @@ __global__ __launch_bounds__(kSmWaves * 64) void gemm_smallm_nt(const float* __r
 }
 
 static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, const float* B, int64_t ldb,
-                       float* C, int64_t ldc, int M, int N, int K, const Epilogue& epi, hipStream_t stream) {
+                       float* C, int64_t ldc, int M, int N, int K, const Epilogue& epi, hipStream_t stream,
+                       const uint16_t* Bp = nullptr, int64_t b_rows = 0, const uint16_t* Ap = nullptr,
+                       int64_t a_rows = 0) {
     if (M <= 0 || N <= 0) return AC_OK;
     const bool aligned = ((lda & 3) == 0) && ((ldb & 3) == 0) && ((((uintptr_t)A) & 15) == 0) &&
                          ((((uintptr_t)B) & 15) == 0);
@@ -391,9 +691,11 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         const int cus = ac::dev_info().cus;
         const int64_t ntn = (N + BN - 1) / BN;
         const int64_t b128 = (int64_t)((M + 127) / 128) * ntn, b64 = (int64_t)((M + 63) / 64) * ntn;
-        const int64_t cost128 = ((b128 + 2 * cus - 1) / (2 * cus)) * 128 * 2;
-        const int64_t cost64 = ((b64 + 3 * cus - 1) / (3 * cus)) * 64 * 3;
-        int tm = cost64 < cost128 ? 1 : 2;
+        const int r128 = ac::gemm_arith() == AC_GEMM_BF16X3 ? 3 : 2, r64 = r128 + 1;   // resident blocks per CU
+        const int64_t cost128 = ((b128 + r128 * cus - 1) / (r128 * cus)) * 128 * r128;
+        const int64_t cost64 = ((b64 + r64 * cus - 1) / (r64 * cus)) * 64 * r64;
+        // the 128-row tile does ~15 % more work per staged byte: take the 64-row one only for a clear win
+        int tm = (double)cost64 * 1.15 < (double)cost128 ? 1 : 2;
         if (const char* e = getenv("AC_GEMM_TM")) { int v = atoi(e); if (v == 1 || v == 2) tm = v; }
         const int64_t nblk = tm == 2 ? b128 : b64;
         const bool plain = epi.alpha == 1.f && epi.beta == 0.f && epi.bias && !epi.mask && !epi.gate &&
@@ -404,11 +706,30 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         else if (plain && !epi.residual && epi.act == ACT_RELU) cls = EPI_BIAS_RELU;
         else if (plain && epi.residual && epi.act == ACT_NONE) cls = EPI_BIAS_RES;
         const dim3 grid((unsigned)nblk), block(kTileThreads);
+        const bool split = ac::gemm_arith() == AC_GEMM_BF16X3;
+        const bool planes = split && Bp != nullptr;      // (K % 32 == 0 here, so K % SBK == 0)
+#define AC_LAUNCH_PLANES(E, AP)                                                                               \
+    do {                                                                                                      \
+        if (tm == 2) hipLaunchKernelGGL((gemm_planes_nt<E, 2, AP>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, C, ldc, M, N, K, epi); \
+        else hipLaunchKernelGGL((gemm_planes_nt<E, 1, AP>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, C, ldc, M, N, K, epi);         \
+    } while (0)
 #define AC_LAUNCH_TILE(E)                                                                                     \
     do {                                                                                                      \
-        if (tm == 2) hipLaunchKernelGGL((gemm_tile_nt<E, 2>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi); \
-        else hipLaunchKernelGGL((gemm_tile_nt<E, 1>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);         \
+        if (split && tm == 2) hipLaunchKernelGGL((gemm_split_nt<E, 2>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi); \
+        else if (split) hipLaunchKernelGGL((gemm_split_nt<E, 1>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);      \
+        else if (tm == 2) hipLaunchKernelGGL((gemm_tile_nt<E, 2>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);     \
+        else hipLaunchKernelGGL((gemm_tile_nt<E, 1>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);                  \
     } while (0)
+        if (planes) {
+            const bool ap = Ap != nullptr;
+            switch (cls) {
+                case EPI_BIAS: if (ap) AC_LAUNCH_PLANES(EPI_BIAS, true); else AC_LAUNCH_PLANES(EPI_BIAS, false); break;
+                case EPI_BIAS_GELU: if (ap) AC_LAUNCH_PLANES(EPI_BIAS_GELU, true); else AC_LAUNCH_PLANES(EPI_BIAS_GELU, false); break;
+                case EPI_BIAS_RELU: if (ap) AC_LAUNCH_PLANES(EPI_BIAS_RELU, true); else AC_LAUNCH_PLANES(EPI_BIAS_RELU, false); break;
+                case EPI_BIAS_RES: if (ap) AC_LAUNCH_PLANES(EPI_BIAS_RES, true); else AC_LAUNCH_PLANES(EPI_BIAS_RES, false); break;
+                default: if (ap) AC_LAUNCH_PLANES(EPI_GENERIC, true); else AC_LAUNCH_PLANES(EPI_GENERIC, false); break;
+            }
+        } else
         switch (cls) {
             case EPI_BIAS: AC_LAUNCH_TILE(EPI_BIAS); break;
             case EPI_BIAS_GELU: AC_LAUNCH_TILE(EPI_BIAS_GELU); break;
@@ -417,6 +738,7 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
             default: AC_LAUNCH_TILE(EPI_GENERIC); break;
         }
 #undef AC_LAUNCH_TILE
+#undef AC_LAUNCH_PLANES
     } else {
         dim3 grid((N + 31) / 32, (M + 31) / 32);
         if (a_kmaj && b_kmaj)
@@ -435,15 +757,27 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
 }  // namespace
 
 namespace ac {
+static std::atomic<int> g_gemm_arith{-1};
+int gemm_arith() {
+    int v = g_gemm_arith.load(std::memory_order_relaxed);
+    if (v < 0) {
+        v = AC_GEMM_BF16X3;
+        if (const char* e = getenv("AC_GEMM_ARITH")) v = (strcmp(e, "f32") == 0) ? AC_GEMM_F32 : AC_GEMM_BF16X3;
+        g_gemm_arith.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+void set_gemm_arith(int v) { g_gemm_arith.store(v, std::memory_order_relaxed); }
 // internal entry used by head.hip / bert.hip
 int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
-               const uint8_t* mask, float mask_scale, hipStream_t stream, float drop_p, uint64_t drop_seed) {
+               const uint8_t* mask, float mask_scale, hipStream_t stream, float drop_p, uint64_t drop_seed,
+               const uint16_t* Wp, const uint16_t* Ap) {
     Epilogue e;
     e.bias = bias; e.residual = residual; e.ldr = ldr; e.act = act; e.alpha = 1.f; e.beta = 0.f;
     e.mask = mask; e.mask_scale = mask_scale; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f;
     e.drop_p = mask ? 0.f : drop_p; e.drop_seed = drop_seed;
-    return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream);
+    return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream, Wp, N, Ap, M);
 }
 int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
              const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* gate, int64_t ldg,
@@ -474,4 +808,38 @@ extern "C" int ac_gemm_f32(int transA, int transB, int M, int N, int K, float al
     AC_REQUIRE(M >= 0 && N >= 0 && K >= 1, AC_EINVAL, "gemm: bad shape");
     return ac::gemm_f32(transA, transB, M, N, K, alpha, d_A, lda, d_B, ldb, beta, d_C, ldc, nullptr, 0, 1.f,
                         (hipStream_t)stream);
+}
+
+extern "C" int ac_gemm_set_arith(int mode) {
+    AC_REQUIRE(mode == AC_GEMM_F32 || mode == AC_GEMM_BF16X3, AC_EINVAL, "gemm arith: unknown mode %d", mode);
+    ac::set_gemm_arith(mode);
+    return AC_OK;
+}
+extern "C" int ac_gemm_get_arith(void) { return ac::gemm_arith(); }
+
+extern "C" int ac_split_bf16x3(const float* d_X, int64_t ldx, int64_t rows, int K, uint16_t* d_planes,
+                               ac_stream_t stream) {
+    AC_REQUIRE(d_X && d_planes, AC_EINVAL, "split: null pointer");
+    AC_REQUIRE(rows >= 0 && K >= 8 && (K % 8) == 0 && ldx >= K && (ldx % 4) == 0 && (((uintptr_t)d_X) & 15) == 0 &&
+                   (((uintptr_t)d_planes) & 15) == 0,
+               AC_EINVAL, "split: K=%d must be a multiple of 8, rows 16-byte aligned", K);
+    if (rows == 0) return AC_OK;
+    const int64_t units = rows * (K / 8);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_X, ldx, rows, K, d_planes);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_linear_bf16x3(const float* d_A, int64_t lda, const uint16_t* d_A_planes, const float* d_W,
+                                int64_t ldw, const uint16_t* d_W_planes, const float* d_bias,
+                                const float* d_residual, int64_t ldr, float* d_C, int64_t ldc, int M, int N, int K,
+                                int act, ac_stream_t stream) {
+    AC_REQUIRE(d_A && d_W && d_C, AC_EINVAL, "linear: null pointer");
+    AC_REQUIRE(M >= 0 && N >= 0 && K >= 1 && lda >= K && ldw >= K && ldc >= N, AC_EINVAL,
+               "linear: bad shape M=%d N=%d K=%d", M, N, K);
+    AC_REQUIRE(act >= 0 && act <= 2, AC_EINVAL, "linear: bad activation %d", act);
+    AC_REQUIRE(!d_A_planes || d_W_planes, AC_EINVAL, "linear: A planes need W planes");
+    return ac::linear_f32(d_A, lda, d_W, ldw, d_bias, d_residual, ldr, d_C, ldc, M, N, K, act, nullptr, 1.f,
+                          (hipStream_t)stream, 0.f, 0, d_W_planes, d_A_planes);
 }

@@ -14,7 +14,11 @@ roofline the kNN distance sweep in its HBM-bound regime (the north star's roofli
          over 10M x 768 fp32 rows (30.7 GB) with 16 resident queries, timed with HIP events recorded
          around that kernel on its own stream (ac_knn_set_profile_events).  algorithmic bytes = N*D*4.
          The encoder GEMM chain and the batched kNN of the timed step are MFMA-bound; their achieved
-         TFLOP/s against the 157.3 TFLOP/s fp32-MFMA peak are reported next to it.
+         TFLOP/s are reported next to it.  The encoder's large GEMMs default to the bf16x3 split arithmetic
+         (every fp32 operand = h + m + l exactly, six bf16 MFMA products, fp32 accumulate: fp32-grade, see
+         tests/test_gemm_split_gpu.py), whose matrix-pipe ceiling is 2500 / 6 = 416.7 fp32-equivalent
+         TFLOP/s; the same timed loop is repeated with the fp32-input MFMA arithmetic (AC_GEMM_F32,
+         157.3 TFLOP/s peak) and reported as config.value_f32_mfma.
 cpu_baseline  the oracle port of the same predict() step (transformers BertModel fp32 on torch-CPU +
          C fp32 brute-force kNN + torch head) on the host cores, on a bounded sample, rank 0, N = 1 only.
 """
@@ -35,6 +39,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak; the bf16x3 split spends 6 of them per product
 
 BATCH, SEQ, NPROTO, DIM, KNN_K, NCLASS, VOCAB = 256, 32, 100_000, 768, 16, 4, 30522
 
@@ -241,6 +246,25 @@ def main():
     assert len(preds) == BATCH and all(len(p) >= 1 for p in preds)
 
     stages = time_stages(clf, ids, types, mask)
+
+    # the same loop with the fp32-input MFMA arithmetic for the large GEMMs (reported next to `value`)
+    from adaptive_classifier import _native as nv
+    arith = nv.lib().ac_gemm_get_arith()
+    nv.check(nv.lib().ac_gemm_set_arith(0), "ac_gemm_set_arith")
+    for _ in range(2):
+        predict_step(clf, ids, types, mask)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        predict_step(clf, ids, types, mask)
+    barrier()
+    dt32 = time.perf_counter() - t0
+    nv.check(nv.lib().ac_gemm_set_arith(arith), "ac_gemm_set_arith")
+    if world > 1:
+        t = torch.tensor([dt32], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt32 = float(t.item())
+    enc_peak = BF16_MFMA_PEAK_TF / 6.0 if arith == 1 else F32_MFMA_PEAK_TF
     if rank == 0:
         enc_flops = clf.model.flops(BATCH, SEQ)
         rows_local = clf.memory.index.ntotal
@@ -254,12 +278,19 @@ def main():
             "config": {"workload": "BASELINE configs[1]: bert-base-uncased arch (random init), 768-d, 100k prototypes "
                                    "row-sharded over the ranks, k=16, batch=256 per GPU, S=32, 4 classes",
                        "batch_per_gpu": BATCH, "seq_len": SEQ, "prototypes": NPROTO, "dim": DIM, "k": KNN_K,
-                       "classes": NCLASS, "parallelism": f"dp{world}+rowshard{world}"},
+                       "classes": NCLASS, "parallelism": f"dp{world}+rowshard{world}",
+                       "gemm_arith": ("bf16x3 split: fp32 operands = h+m+l exactly, 6 bf16 MFMA products, fp32 "
+                                      "accumulate (fp32-grade; tests/test_gemm_split_gpu.py)" if arith == 1
+                                      else "fp32-input MFMA"),
+                       "value_f32_mfma": BATCH * world * args.steps / dt32,
+                       "ms_per_step_f32_mfma": dt32 / args.steps * 1e3},
             "stages_ms": stages,
             "roofline_encoder": {"bound": "mfma", "achieved": enc_flops / stages["encode_ms"] / 1e9,
-                                 "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                 "frac": enc_flops / stages["encode_ms"] / 1e9 / F32_MFMA_PEAK_TF,
+                                 "peak": enc_peak, "unit": "TFLOP/s",
+                                 "frac": enc_flops / stages["encode_ms"] / 1e9 / enc_peak,
                                  "flops_per_step": enc_flops,
+                                 "peak_note": ("fp32-equivalent: bf16 MFMA dense peak 2500 / 6 products" if arith == 1
+                                               else "fp32-input MFMA dense peak"),
                                  "note": "executed FLOPs (last layer runs its post-attention part on the CLS rows only); "
                                          "full BertModel.forward would be %.4g" % clf.model.flops(BATCH, SEQ, executed=False)},
             "roofline_knn_batch": {"bound": "mfma", "achieved": knn_flops / stages["knn_ms"] / 1e9,

@@ -145,6 +145,39 @@ int ac_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                 const float* d_A, int64_t lda, const float* d_B, int64_t ldb,
                 float beta, float* d_C, int64_t ldc, ac_stream_t stream);
 
+/* Arithmetic of the large-M (M >= 192) NT GEMMs behind ac_linear_f32 / ac_bert_encode_cls / ac_head_*:
+ *   AC_GEMM_F32     fp32-input MFMA (v_mfma_f32_32x32x2_f32): bitwise an fp32 fma chain.
+ *   AC_GEMM_BF16X3  every fp32 operand split exactly into three bf16 terms (x = h + m + l), six bf16 MFMA
+ *                   products (hh, hm, mh, mm, hl, lh) accumulated in fp32: per-product error <= 2^-26,
+ *                   i.e. fp32-grade results (tests/test_gemm_split_gpu.py bounds it against fp64), at
+ *                   6/16 of the matrix-pipe time.  Non-finite operands yield NaN.
+ * The reference computes these products with torch fp32 matmuls (transformers BertModel called at
+ * classifier.py:1271; nn.Linear in models.py:49-80).  Process-wide; the initial value comes from the
+ * environment variable AC_GEMM_ARITH ("f32" | "bf16x3"; default bf16x3). */
+#define AC_GEMM_F32 0
+#define AC_GEMM_BF16X3 1
+int ac_gemm_set_arith(int mode);
+int ac_gemm_get_arith(void);
+
+/* Pre-split operands for AC_GEMM_BF16X3.  X[rows, K] fp32 (K % 8 == 0, 16-byte aligned rows) -> three bf16
+ * planes h, m, l with X == h + m + l (to 2^-27 |x|), stored k-slot-major
+ *     planes[p][k / 8][row][k % 8]        (uint16 units; 3 * rows * K in total)
+ * so the GEMM stages MFMA fragments with direct global->LDS loads.  Weights are split once at load
+ * (adaptive_classifier/encoder.py); activations are split inside the GEMM unless a producer already
+ * emitted planes. */
+int ac_split_bf16x3(const float* d_X, int64_t ldx, int64_t rows, int K,
+                    uint16_t* d_planes, ac_stream_t stream);
+
+/* ac_linear_f32 with optional pre-split operands (either may be NULL; A planes require W planes).  The
+ * planes are used when the arithmetic mode is AC_GEMM_BF16X3 and the shape takes the LDS-tiled path
+ * (M >= 192, K % 32 == 0); otherwise the fp32 operands are read, so both must always be valid.
+ * d_W_planes is ac_split_bf16x3 of W[N, K]; d_A_planes of A[M, K]. */
+int ac_linear_bf16x3(const float* d_A, int64_t lda, const uint16_t* d_A_planes,
+                     const float* d_W, int64_t ldw, const uint16_t* d_W_planes,
+                     const float* d_bias, const float* d_residual, int64_t ldr,
+                     float* d_C, int64_t ldc, int M, int N, int K, int act,
+                     ac_stream_t stream);
+
 /* Flat parameter block of an AdaptiveHead with hidden dims [H1, H2]
  * (classifier.py:1241: H1 = D, H2 = D/2).  All six tensors live in ONE
  * contiguous fp32 buffer in state_dict order

@@ -1,0 +1,142 @@
+"""The bf16x3 split-operand GEMM (AC_GEMM_BF16X3: six bf16 MFMA products per tile, fp32 accumulate) must be
+fp32-GRADE: its error against an fp64 product is bounded by a small multiple of the error the fp32-input
+MFMA kernel (an exact fma chain) makes on the same operands, and by the a-priori fp32 dot-product bound
+K * 2^-24 * sum|a||b|.  Tolerances are written out below."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16X3 = 0, 1
+
+
+@pytest.fixture()
+def arith():
+    from adaptive_classifier import _native as nv
+    lib = nv.lib()
+    before = lib.ac_gemm_get_arith()
+    yield lambda mode: nv.check(lib.ac_gemm_set_arith(mode), "ac_gemm_set_arith")
+    lib.ac_gemm_set_arith(before)
+
+
+def _planes(nv, dev, Xd):
+    rows, K = Xd.shape
+    P = torch.empty(3 * rows * K, dtype=torch.int16, device=dev)
+    nv.check(nv.lib().ac_split_bf16x3(nv.ptr(Xd), K, rows, K, nv.ptr(P), nv.stream_ptr(dev)), "ac_split_bf16x3")
+    return P
+
+
+def _linear(nv, dev, A, W, b, R, act, planes=""):
+    """planes: "" -> ac_linear_f32; "w" -> W pre-split; "aw" -> both operands pre-split."""
+    M, K = A.shape
+    N = W.shape[0]
+    Ad, Wd, bd = (torch.from_numpy(x).to(dev) for x in (A, W, b))
+    Rd = torch.from_numpy(R).to(dev) if R is not None else None
+    C = torch.empty((M, N), device=dev)
+    if not planes:
+        nv.check(nv.lib().ac_linear_f32(nv.ptr(Ad), K, nv.ptr(Wd), K, nv.ptr(bd), nv.ptr(Rd) if R is not None else None,
+                                        N, nv.ptr(C), N, M, N, K, act, nv.stream_ptr(dev)), "ac_linear_f32")
+    else:
+        Wp = _planes(nv, dev, Wd)
+        Ap = _planes(nv, dev, Ad) if "a" in planes else None
+        nv.check(nv.lib().ac_linear_bf16x3(nv.ptr(Ad), K, nv.ptr(Ap) if Ap is not None else None, nv.ptr(Wd), K,
+                                           nv.ptr(Wp), nv.ptr(bd), nv.ptr(Rd) if R is not None else None, N,
+                                           nv.ptr(C), N, M, N, K, act, nv.stream_ptr(dev)), "ac_linear_bf16x3")
+    return C.cpu().numpy().astype(np.float64)
+
+
+def _ref(A, W, b, R, act):
+    z = A.astype(np.float64) @ W.astype(np.float64).T + b
+    if act == 1:
+        z = np.maximum(z, 0)
+    elif act == 2:
+        from scipy.special import erf
+        z = 0.5 * z * (1 + erf(z / np.sqrt(2)))
+    if R is not None:
+        z = z + R
+    return z
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (8192, 768, 768, 0, True),      # attention output projection at BASELINE configs[1] (256 x 32 tokens)
+    (8192, 2304, 768, 0, False),    # fused QKV
+    (1024, 3072, 768, 2, False),    # FFN up + GELU
+    (1024, 768, 3072, 0, True),     # FFN down + residual
+    (200, 130, 96, 1, False),       # ragged edges: M, N not tile multiples, 64-row tile
+    (333, 257, 32, 0, True),        # single k-tile
+])
+def test_split_gemm_is_fp32_grade(M, N, K, act, res, cuda_dev, arith):
+    from adaptive_classifier import _native as nv
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    want = _ref(A, W, b, R, act)
+    arith(F32)
+    e32 = np.abs(_linear(nv, cuda_dev, A, W, b, R, act) - want)
+    arith(BF16X3)
+    bound = K * 2.0 ** -24 * (np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T) + 1e-6
+    for planes in ("", "w", "aw"):        # split in-kernel / weights pre-split / both operands pre-split
+        got = _linear(nv, cuda_dev, A, W, b, R, act, planes)
+        es = np.abs(got - want)
+        assert np.all(es <= bound), (planes, es.max(), bound.min())          # a-priori fp32 dot-product bound
+        assert es.max() <= 3.0 * e32.max() + 1e-7, (planes, es.max(), e32.max())
+        assert es.mean() <= 3.0 * e32.mean() + 1e-9, (planes, es.mean(), e32.mean())
+
+
+def test_split_planes_reconstruct_exactly(cuda_dev):
+    """h + m + l == x bit for bit (fp32 has 24 significand bits, the three bf16 terms carry 8 each plus signs),
+    and the k-slot-major layout is planes[p][k // 8][row][k % 8]."""
+    from adaptive_classifier import _native as nv
+    rng = np.random.default_rng(3)
+    rows, K = 77, 40
+    X = (rng.standard_normal((rows, K)) * 10.0 ** rng.uniform(-8, 8, (rows, K))).astype(np.float32)
+    X[0, :4] = [0.0, -0.0, 1.0, -1.5]
+    P = _planes(nv, cuda_dev, torch.from_numpy(X).to(cuda_dev)).cpu().numpy().view(np.uint16)
+    P = P.reshape(3, K // 8, rows, 8).transpose(0, 2, 1, 3).reshape(3, rows, K)
+    f = (P.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    assert np.array_equal((f[0] + f[1] + f[2]).astype(np.float32), X)
+    assert np.all(np.abs(f[1]) <= np.abs(f[0]) * 2.0 ** -8 + 1e-45) and np.all(np.abs(f[2]) <= np.abs(f[0]) * 2.0 ** -16 + 1e-45)
+
+
+def test_split_gemm_wide_dynamic_range_and_asymmetric_layout(cuda_dev, arith):
+    """Operands spanning 12 orders of magnitude (every plane of the split matters) and an asymmetric W so
+    a transposed / permuted fragment mapping cannot pass."""
+    from adaptive_classifier import _native as nv
+    rng = np.random.default_rng(7)
+    M, N, K = 256, 256, 128
+    A = (rng.standard_normal((M, K)) * 10.0 ** rng.uniform(-6, 6, (M, K))).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 10.0 ** rng.uniform(-6, 6, (N, K))).astype(np.float32)
+    W[:, ::3] *= -3.0
+    b = np.zeros(N, np.float32)
+    want = _ref(A, W, b, None, 0)
+    arith(BF16X3)
+    scale = np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T
+    eye = np.eye(256, 128, dtype=np.float32)
+    for planes in ("", "w", "aw"):
+        got = _linear(nv, cuda_dev, A, W, b, None, 0, planes)
+        assert np.max(np.abs(got - want) / scale) < 2.0 ** -20, planes      # fp32 fma chain bound: K * 2^-24 = 2^-17
+        # identity check: A = I picks out W^T exactly (h + m + l == x, products with 1.0 exact)
+        got = _linear(nv, cuda_dev, eye, W, b, None, 0, planes)
+        assert np.array_equal(got[:128], W.T.astype(np.float64)) and not got[128:].any(), planes
+
+
+def test_encoder_parity_holds_under_split_arithmetic(cuda_dev, arith):
+    """SURVEY 8c tolerance (1e-4 max-abs on the unit-norm CLS embedding) with the split GEMMs, and the
+    distance to the fp32-MFMA embedding is at fp32 rounding level."""
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_bert(768, 12, 12, 3072, vocab=2000, seed=0)
+    ids, types, mask = bert_oracle.synthetic_batch(16, 32, vocab=2000, seed=99, ragged=True)
+    want = bert_oracle.encode_cls(model, ids, types, mask)
+    enc = HipBertEncoder(model, device=cuda_dev)
+    arith(F32)
+    g32 = enc.encode_cls(ids, types, mask).cpu()
+    arith(BF16X3)
+    gs = enc.encode_cls(ids, types, mask).cpu()
+    e32, es = (g32 - want).abs().max().item(), (gs - want).abs().max().item()
+    assert es < 1e-4, es
+    assert es <= 3 * e32 + 1e-6, (es, e32)
+    assert (gs - g32).abs().max().item() < 5e-6
