@@ -44,7 +44,8 @@ class ac_bert_weights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b",
         "qkv_w", "qkv_b", "ao_w", "ao_b", "ln1_g", "ln1_b",
-        "ff1_w", "ff1_b", "ff2_w", "ff2_b", "ln2_g", "ln2_b")]
+        "ff1_w", "ff1_b", "ff2_w", "ff2_b", "ln2_g", "ln2_b",
+        "qkv_w3", "ao_w3", "ff1_w3", "ff2_w3")]
 
 
 # name -> (restype, argtypes); must list every symbol include/acamd.h declares

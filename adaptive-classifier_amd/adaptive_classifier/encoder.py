@@ -95,6 +95,21 @@ class HipBertEncoder:
             arr = (ctypes.c_void_p * L)(*[t.data_ptr() for t in tensors])
             self._arrays[k] = arr             # host array of device pointers; must outlive the calls
             setattr(w, k, ctypes.cast(arr, ctypes.c_void_p).value)
+        # bf16x3 operand planes of the four weight matrices per layer (ac_split_bf16x3, once): with them the
+        # token-row GEMMs stage pre-split operands instead of splitting inside every tile (AC_GEMM_BF16X3)
+        self._planes = []
+        stream = nv.stream_ptr(self.device)
+        for k in ("qkv_w", "ao_w", "ff1_w", "ff2_w"):
+            planes = []
+            for t in per[k]:
+                rows, K = t.shape
+                pl = torch.empty(3 * rows * K, dtype=torch.int16, device=self.device)
+                nv.check(nv.lib().ac_split_bf16x3(t.data_ptr(), K, rows, K, pl.data_ptr(), stream), "ac_split_bf16x3")
+                planes.append(pl)
+            self._planes.extend(planes)
+            arr = (ctypes.c_void_p * L)(*[t.data_ptr() for t in planes])
+            self._arrays[k + "3"] = arr
+            setattr(w, k + "3", ctypes.cast(arr, ctypes.c_void_p).value)
         self.weights = w
         self._ws = None
         self.num_params = sum(t.numel() for t in self._keep)

@@ -26,8 +26,10 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// dst: the fp32 row; planes (optional): the same row as bf16x3 operand planes of a [rows, H] matrix
 __device__ __forceinline__ void layernorm_store(f32x4 (&x)[kMaxVec], int H, int lane, const float* g,
-                                                const float* b, float eps, float* dst) {
+                                                const float* b, float eps, float* dst, uint16_t* planes = nullptr,
+                                                int64_t rows = 0, int64_t row = 0) {
     const int nv = H >> 2;
     float s = 0.f;
 #pragma unroll
@@ -55,6 +57,15 @@ __device__ __forceinline__ void layernorm_store(f32x4 (&x)[kMaxVec], int H, int 
             y.z = (x[e].z - mean) * rstd * gg.z + bb.z;
             y.w = (x[e].w - mean) * rstd * gg.w + bb.w;
             *reinterpret_cast<f32x4*>(dst + 4 * c4) = y;
+            if (planes) {     // lanes 2j, 2j+1 fill the two halves of k-slot j
+                uint2 Hh, Mm, Ll;
+                ac::split4(y, Hh, Mm, Ll);
+                uint16_t* p = planes + ac::plane_off(rows, row, 4 * c4);
+                const int64_t plane = rows * (int64_t)H;
+                *reinterpret_cast<uint2*>(p) = Hh;
+                *reinterpret_cast<uint2*>(p + plane) = Mm;
+                *reinterpret_cast<uint2*>(p + 2 * plane) = Ll;
+            }
         }
     }
 }
@@ -63,7 +74,7 @@ __device__ __forceinline__ void layernorm_store(f32x4 (&x)[kMaxVec], int H, int 
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const int64_t* type_ids, int T, int S,
                                                        int H, const float* word, const float* pos,
                                                        const float* type, const float* g, const float* b,
-                                                       float eps, float* out) {
+                                                       float eps, float* out, uint16_t* planes) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -82,11 +93,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const
             x[e] = (w + ty) + po;     // inputs_embeds + token_type_embeddings, then + position
         }
     }
-    layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H);
+    layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t);
 }
 
 __global__ __launch_bounds__(256) void ln_kernel(const float* in, int T, int H, const float* g, const float* b,
-                                                 float eps, float* out) {
+                                                 float eps, float* out, uint16_t* planes) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* in, int T, int H, 
         const int c4 = lane + 64 * e;
         if (c4 < nv) x[e] = *reinterpret_cast<const f32x4*>(in + (int64_t)t * H + 4 * c4);
     }
-    layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H);
+    layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t);
 }
 
 // last_hidden_state[:, 0, :] -> F.normalize(p=2, dim=1, eps=1e-12)
@@ -133,8 +144,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int crow32(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// ctx_planes (optional): emit the context as bf16x3 operand planes of the [batch*S, H] output-projection input
+// instead of fp32 rows.
 __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, const int64_t* mask, int S, int H,
-                                                            float scale, float* ctx) {
+                                                            float scale, float* ctx, uint16_t* ctx_planes) {
     const int lane = threadIdx.x;
     const int qt = blockIdx.x, head = blockIdx.y, bi = blockIdx.z;
     const int64_t ld = 3 * (int64_t)H;
@@ -211,12 +224,32 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
     }
     if (qvalid) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
-        float* dst = ctx + ((int64_t)bi * S + qi) * H + head * DH;
         // C layout of O^T: lane & 31 = query (this lane), register r = output dim crow32(r, h) (+32 for o1)
+        if (ctx_planes) {
+            // registers 4g .. 4g+3 are dims 8g + 4h .. +3: half of k-slot (head * 8 + 4t + g); the partner lane
+            // (h ^ 1) writes the other half
+            const int64_t rows = (int64_t)gridDim.z * S, row = (int64_t)bi * S + qi, plane = rows * H;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dst[crow32(r, h)] = o0[r] * inv;
-            dst[32 + crow32(r, h)] = o1[r] * inv;
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (t ? o1[4 * g + e] : o0[4 * g + e]) * inv;
+                    uint2 Hh, Mm, Ll;
+                    ac::split4(v, Hh, Mm, Ll);
+                    uint16_t* p = ctx_planes + ac::plane_off(rows, row, head * DH + 32 * t + 8 * g + 4 * h);
+                    *reinterpret_cast<uint2*>(p) = Hh;
+                    *reinterpret_cast<uint2*>(p + plane) = Mm;
+                    *reinterpret_cast<uint2*>(p + 2 * plane) = Ll;
+                }
+        } else {
+            float* dst = ctx + ((int64_t)bi * S + qi) * H + head * DH;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dst[crow32(r, h)] = o0[r] * inv;
+                dst[32 + crow32(r, h)] = o1[r] * inv;
+            }
         }
     }
 }
@@ -277,7 +310,7 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
 }
 
 struct BertWs {
-    size_t x, qkv, ctx, y, ffn, total;
+    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
 };
 BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     BertWs w;
@@ -289,6 +322,10 @@ BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     w.ctx = take(T * c.hidden);
     w.y = take(T * c.hidden);
     w.ffn = take(T * c.intermediate);
+    auto take16 = [&](size_t n) { size_t o = off; off += ac::align_up(n * sizeof(uint16_t), 256); return o; };
+    w.xp = take16(3 * T * c.hidden);
+    w.ctxp = take16(3 * T * c.hidden);
+    w.ffnp = take16(3 * T * c.intermediate);
     w.total = off;
     return w;
 }
@@ -335,40 +372,61 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
     const int T = b * S, H = c.hidden, I = c.intermediate;
     const int tok_blocks = (T + 3) / 4;
 
+    uint16_t* xp = (uint16_t*)(base + ws.xp);
+    uint16_t* ctxp = (uint16_t*)(base + ws.ctxp);
+    uint16_t* ffnp = (uint16_t*)(base + ws.ffnp);
+    // Pre-split operand planes (AC_GEMM_BF16X3 with weight planes present): every producer of a GEMM input
+    // -- the LayerNorms, the attention kernel, the GELU epilogue of FFN1 -- emits the bf16x3 planes the next
+    // GEMM stages with direct global->LDS loads, so no GEMM splits its operands again.  The T-row GEMMs of
+    // layers 0 .. L-2 qualify; the CLS-only last layer (b rows) keeps fp32 activations.
+    const bool wplanes = w->qkv_w3 && w->ao_w3 && w->ff1_w3 && w->ff2_w3;
+    const bool pl = wplanes && ac::linear_takes_planes(T, H, H) && ac::linear_takes_planes(T, H, I) && (H % 8) == 0;
+
     hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, T, S, H,
-                       w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x);
+                       w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x,
+                       pl ? xp : nullptr);
     AC_LAUNCH_CHECK();
     const float scale = 1.0f / sqrtf((float)DH);
     for (int l = 0; l < c.layers; ++l) {
-        rc = ac::linear_f32(x, H, w->qkv_w[l], H, w->qkv_b[l], nullptr, 0, qkv, 3 * H, T, 3 * H, H, 0, nullptr, 1.f, stream);
+        const uint16_t* qkv_w3 = wplanes ? w->qkv_w3[l] : nullptr;
+        const uint16_t* ao_w3 = wplanes ? w->ao_w3[l] : nullptr;
+        const uint16_t* ff1_w3 = wplanes ? w->ff1_w3[l] : nullptr;
+        const uint16_t* ff2_w3 = wplanes ? w->ff2_w3[l] : nullptr;
+        rc = ac::linear_f32(x, H, w->qkv_w[l], H, w->qkv_b[l], nullptr, 0, qkv, 3 * H, T, 3 * H, H, 0, nullptr, 1.f,
+                            stream, 0.f, 0, qkv_w3, pl ? xp : nullptr);
         if (rc) return rc;
         const bool last = (l == c.layers - 1);
         // After the last layer's attention only the CLS row of each sequence is consumed, so the
         // output projection, both LayerNorms and the FFN run on b rows instead of b*S.
         const int Ml = last ? b : T;
+        const bool lp = pl && !last;                   // this layer's post-attention GEMMs run on planes
         const float* resid = x;                        // residual = layer input
         const int64_t ldres = last ? (int64_t)S * H : H;   // CLS rows of x are S*H apart
         if (last) {
             hipLaunchKernelGGL(attention_cls_kernel, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale, ctx);
         } else {
             hipLaunchKernelGGL(attention_mfma_kernel, dim3((S + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv, d_mask,
-                               S, H, scale, ctx);
+                               S, H, scale, ctx, lp ? ctxp : nullptr);
         }
         AC_LAUNCH_CHECK();
         const int lblocks = (Ml + 3) / 4;
-        rc = ac::linear_f32(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f, stream);
+        rc = ac::linear_f32(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f, stream,
+                            0.f, 0, ao_w3, lp ? ctxp : nullptr);
         if (rc) return rc;
         // (last layer: x is overwritten with b compact rows; its old contents are no longer needed)
         hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln1_g[l], w->ln1_b[l],
-                           c.ln_eps, last ? ctx : x);
+                           c.ln_eps, last ? ctx : x, lp ? xp : nullptr);
         AC_LAUNCH_CHECK();
         float* x1 = last ? ctx : x;                    // ctx is free again after the AO projection
-        rc = ac::linear_f32(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, nullptr, 1.f, stream);
+        rc = ac::linear_f32(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, nullptr, 1.f, stream,
+                            0.f, 0, ff1_w3, lp ? xp : nullptr, lp ? ffnp : nullptr);
         if (rc) return rc;
-        rc = ac::linear_f32(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, nullptr, 1.f, stream);
+        rc = ac::linear_f32(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, nullptr, 1.f, stream, 0.f, 0,
+                            ff2_w3, lp ? ffnp : nullptr);
         if (rc) return rc;
+        // the next layer's QKV GEMM reads x as planes; the last layer's output (b compact rows) stays fp32
         hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln2_g[l], w->ln2_b[l],
-                           c.ln_eps, x);
+                           c.ln_eps, x, lp ? xp : nullptr);
         AC_LAUNCH_CHECK();
     }
     // after the CLS-only last layer x holds b compact rows (sequence stride 1)

@@ -54,7 +54,10 @@ __host__ __device__ static inline size_t align_up(size_t x, size_t a) { return (
 int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
                const uint8_t* mask, float mask_scale, hipStream_t stream, float drop_p = 0.f,
-               uint64_t drop_seed = 0, const uint16_t* W_planes = nullptr, const uint16_t* A_planes = nullptr);
+               uint64_t drop_seed = 0, const uint16_t* W_planes = nullptr, const uint16_t* A_planes = nullptr,
+               uint16_t* C_planes = nullptr);
+// true when linear_f32(M, N, K) with W planes takes the pre-split kernel (only then may A / C planes be passed)
+bool linear_takes_planes(int M, int N, int K);
 
 // counter-based Bernoulli(1-p) keep decision for in-kernel dropout (stateless: seed + element index)
 __host__ __device__ static inline bool dropout_keep(uint64_t seed, uint64_t idx, float p) {
@@ -64,6 +67,41 @@ __host__ __device__ static inline bool dropout_keep(uint64_t seed, uint64_t idx,
     z ^= z >> 31;
     return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;
 }
+#ifdef __HIPCC__
+// ---- bf16x3 split helpers (AC_GEMM_BF16X3): x = h + m + l, each term a bf16, RNE via v_cvt_pk_bf16_f32 ----
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const f32x2_t f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
+// two fp32 -> one dword per plane (a in the low half)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = pack_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = pack_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = pack_bf16(sa, sb);
+}
+__device__ __forceinline__ void split4(const f32x4_t& x, uint2& H, uint2& M, uint2& L) {
+    split2(x[0], x[1], H.x, M.x, L.x);
+    split2(x[2], x[3], H.y, M.y, L.y);
+}
+// 8 consecutive fp32 (two float4) -> three planes of 8 bf16
+__device__ __forceinline__ void split8(const f32x4_t& x0, const f32x4_t& x1, uint4& H, uint4& M, uint4& L) {
+    split2(x0[0], x0[1], H.x, M.x, L.x);
+    split2(x0[2], x0[3], H.y, M.y, L.y);
+    split2(x1[0], x1[1], H.z, M.z, L.z);
+    split2(x1[2], x1[3], H.w, M.w, L.w);
+}
+// element offset (uint16 units) of (row, k) inside one plane of a [rows, K] operand: planes[p][k/8][row][k%8]
+__device__ __forceinline__ int64_t plane_off(int64_t rows, int64_t row, int k) {
+    return ((int64_t)(k >> 3) * rows + row) * 8 + (k & 7);
+}
+#endif
+
 // arithmetic of the LDS-tiled GEMMs (ac_gemm_set_arith / env AC_GEMM_ARITH = f32 | bf16x3)
 int gemm_arith();
 void set_gemm_arith(int mode);

@@ -122,6 +122,33 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][2], float* __restri
         }
 }
 
+// epilogue that emits the result as operand planes of the NEXT GEMM (C[M,N] -> planes[p][n/8][row][n%8]):
+// lane owns column (lane & 31), so 8 neighbouring lanes fill one 16-byte k-slot of a row
+template <int EPI, int TM>
+__device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][2], uint16_t* __restrict__ Cp, int M, int N,
+                                                  int m0, int n0, int wm, int wn, int lane, const Epilogue& epi) {
+    const int64_t plane = (int64_t)M * N;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+            if (col >= N) continue;
+            const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
+            const float bias = epi.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = rbase + acc_row32(r, lane);
+                if (row >= M) continue;
+                const float v = fast_epilogue<EPI>(acc[mi][ni][r], bias, 0.f);
+                uint32_t h, m, l;
+                ac::split2(v, 0.f, h, m, l);
+                uint16_t* dst = Cp + ac::plane_off(M, row, col);
+                dst[0] = (uint16_t)h; dst[plane] = (uint16_t)m; dst[2 * plane] = (uint16_t)l;
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS-tiled NT kernel: (64*TM) x 128 x 32 block tile, 4 waves as 2(M) x 2(N), wave tile (32*TM) x 64.
 //   TM = 2: 128x128 tile, 64 KB LDS, 2 blocks/CU        TM = 1: 64x128 tile, 48 KB LDS, 3 blocks/CU
@@ -246,31 +273,8 @@ __global__ __launch_bounds__(kTileThreads, TM == 2 ? 2 : 3) void gemm_tile_nt(
 //   (lane (i, kg) of chunk c reads 8 bf16 = k 16c + 8kg .. +7 of row i with one ds_read_b128), slots
 //   XOR-swizzled by the k-slot so the 8-lane ds_write_b128 groups hit distinct banks.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    const f32x2 f = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
-}
-
-// 8 consecutive fp32 (two float4) -> three planes of 8 bf16
-__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, uint4& H, uint4& Mi, uint4& L) {
-    uint32_t h[4], m[4], l[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float a = p < 2 ? x0[2 * p] : x1[2 * p - 4], b = p < 2 ? x0[2 * p + 1] : x1[2 * p - 3];
-        h[p] = pack_bf16(a, b);
-        const float ra = a - __uint_as_float(h[p] << 16), rb = b - __uint_as_float(h[p] & 0xffff0000u);
-        m[p] = pack_bf16(ra, rb);
-        const float sa = ra - __uint_as_float(m[p] << 16), sb = rb - __uint_as_float(m[p] & 0xffff0000u);
-        l[p] = pack_bf16(sa, sb);
-    }
-    H = make_uint4(h[0], h[1], h[2], h[3]);
-    Mi = make_uint4(m[0], m[1], m[2], m[3]);
-    L = make_uint4(l[0], l[1], l[2], l[3]);
-}
+using ac::split8;
 
 __device__ __forceinline__ int split_slot(int row, int q) {   // q = k-slot of 8 in [0,4)
     const int rg = row >> 5, i = row & 31, c = q >> 1, kg = q & 1;
@@ -424,7 +428,7 @@ constexpr int SBK = 16;   // k per stage = one bf16 MFMA chunk
 //   (A three-buffer ring with loads spanning the barrier -- raw s_barrier + counted vmcnt -- measured 12 %
 //   SLOWER at 8192^3: 72 KB of LDS leaves 2 blocks per CU instead of 3, and occupancy is what hides the
 //   fragment-read latency here.)
-template <int EPI, int TM, bool A_PLANES>
+template <int EPI, int TM, bool A_PLANES, bool C_PLANES>
 __global__ __launch_bounds__(kTileThreads, 3) void gemm_planes_nt(
     const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Ap, int64_t a_rows,
     const uint16_t* __restrict__ Wp, int64_t w_rows, float* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -517,7 +521,8 @@ __global__ __launch_bounds__(kTileThreads, 3) void gemm_planes_nt(
         if (!A_PLANES) store_a(cur ^ 1);
         __syncthreads();      // drains the global_load_lds queue (vmcnt(0)) and ends every read of `cur`
     }
-    store_tile<EPI, TM>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, epi);
+    if (C_PLANES) store_tile_planes<EPI, TM>(acc, reinterpret_cast<uint16_t*>(C), M, N, m0, n0, wm, wn, lane, epi);
+    else store_tile<EPI, TM>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -677,10 +682,12 @@ __global__ __launch_bounds__(kSmWaves * 64) void gemm_smallm_nt(const float* __r
 static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, const float* B, int64_t ldb,
                        float* C, int64_t ldc, int M, int N, int K, const Epilogue& epi, hipStream_t stream,
                        const uint16_t* Bp = nullptr, int64_t b_rows = 0, const uint16_t* Ap = nullptr,
-                       int64_t a_rows = 0) {
+                       int64_t a_rows = 0, uint16_t* Cp = nullptr) {
     if (M <= 0 || N <= 0) return AC_OK;
     const bool aligned = ((lda & 3) == 0) && ((ldb & 3) == 0) && ((((uintptr_t)A) & 15) == 0) &&
                          ((((uintptr_t)B) & 15) == 0);
+    AC_REQUIRE((!Ap && !Cp) || (a_kmaj && b_kmaj && aligned && ac::linear_takes_planes(M, N, K) && Bp),
+               AC_EUNSUPPORTED, "gemm: operand / result planes given for a shape that does not take the pre-split kernel");
     if (a_kmaj && b_kmaj && aligned && M <= 64 && K >= 8 && (K % 4) == 0 && N >= 16) {
         const dim3 grid((N + 15) / 16), block(kSmWaves * 64);
         if (M <= 16) hipLaunchKernelGGL((gemm_smallm_nt<1>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
@@ -710,8 +717,8 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         const bool planes = split && Bp != nullptr;      // (K % 32 == 0 here, so K % SBK == 0)
 #define AC_LAUNCH_PLANES(E, AP)                                                                               \
     do {                                                                                                      \
-        if (tm == 2) hipLaunchKernelGGL((gemm_planes_nt<E, 2, AP>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, C, ldc, M, N, K, epi); \
-        else hipLaunchKernelGGL((gemm_planes_nt<E, 1, AP>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, C, ldc, M, N, K, epi);         \
+        if (tm == 2) hipLaunchKernelGGL((gemm_planes_nt<E, 2, AP, false>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, C, ldc, M, N, K, epi); \
+        else hipLaunchKernelGGL((gemm_planes_nt<E, 1, AP, false>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, C, ldc, M, N, K, epi);         \
     } while (0)
 #define AC_LAUNCH_TILE(E)                                                                                     \
     do {                                                                                                      \
@@ -720,7 +727,19 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         else if (tm == 2) hipLaunchKernelGGL((gemm_tile_nt<E, 2>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);     \
         else hipLaunchKernelGGL((gemm_tile_nt<E, 1>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);                  \
     } while (0)
-        if (planes) {
+        if (Cp) {
+            // result emitted as planes for the next GEMM: both operands pre-split, bias (+GELU) epilogues only
+            AC_REQUIRE(planes && Ap && (cls == EPI_BIAS || cls == EPI_BIAS_GELU), AC_EUNSUPPORTED,
+                       "gemm: planes output needs pre-split operands and a bias / bias+gelu epilogue");
+            float* Cq = reinterpret_cast<float*>(Cp);
+            if (cls == EPI_BIAS_GELU) {
+                if (tm == 2) hipLaunchKernelGGL((gemm_planes_nt<EPI_BIAS_GELU, 2, true, true>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, Cq, ldc, M, N, K, epi);
+                else hipLaunchKernelGGL((gemm_planes_nt<EPI_BIAS_GELU, 1, true, true>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, Cq, ldc, M, N, K, epi);
+            } else {
+                if (tm == 2) hipLaunchKernelGGL((gemm_planes_nt<EPI_BIAS, 2, true, true>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, Cq, ldc, M, N, K, epi);
+                else hipLaunchKernelGGL((gemm_planes_nt<EPI_BIAS, 1, true, true>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, Cq, ldc, M, N, K, epi);
+            }
+        } else if (planes) {
             const bool ap = Ap != nullptr;
             switch (cls) {
                 case EPI_BIAS: if (ap) AC_LAUNCH_PLANES(EPI_BIAS, true); else AC_LAUNCH_PLANES(EPI_BIAS, false); break;
@@ -768,16 +787,20 @@ int gemm_arith() {
     return v;
 }
 void set_gemm_arith(int v) { g_gemm_arith.store(v, std::memory_order_relaxed); }
+bool linear_takes_planes(int M, int N, int K) {
+    // mirrors launch_gemm: not the small-M kernel, the LDS-tiled path, split arithmetic
+    return gemm_arith() == AC_GEMM_BF16X3 && !(M <= 64 && N >= 16) && M >= 192 && K >= 32 && (K % 32) == 0 && N >= 1;
+}
 // internal entry used by head.hip / bert.hip
 int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
                const uint8_t* mask, float mask_scale, hipStream_t stream, float drop_p, uint64_t drop_seed,
-               const uint16_t* Wp, const uint16_t* Ap) {
+               const uint16_t* Wp, const uint16_t* Ap, uint16_t* Cp) {
     Epilogue e;
     e.bias = bias; e.residual = residual; e.ldr = ldr; e.act = act; e.alpha = 1.f; e.beta = 0.f;
     e.mask = mask; e.mask_scale = mask_scale; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f;
     e.drop_p = mask ? 0.f : drop_p; e.drop_seed = drop_seed;
-    return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream, Wp, N, Ap, M);
+    return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream, Wp, N, Ap, M, Cp);
 }
 int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
              const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* gate, int64_t ldg,
@@ -841,5 +864,6 @@ extern "C" int ac_linear_bf16x3(const float* d_A, int64_t lda, const uint16_t* d
     AC_REQUIRE(act >= 0 && act <= 2, AC_EINVAL, "linear: bad activation %d", act);
     AC_REQUIRE(!d_A_planes || d_W_planes, AC_EINVAL, "linear: A planes need W planes");
     return ac::linear_f32(d_A, lda, d_W, ldw, d_bias, d_residual, ldr, d_C, ldc, M, N, K, act, nullptr, 1.f,
-                          (hipStream_t)stream, 0.f, 0, d_W_planes, d_A_planes);
+                          (hipStream_t)stream, 0.f, 0, d_W_planes,
+                          (d_A_planes && ac::linear_takes_planes(M, N, K)) ? d_A_planes : nullptr);
 }

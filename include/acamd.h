@@ -319,6 +319,14 @@ typedef struct {
     const float* const* ff2_b;
     const float* const* ln2_g;  /* output LayerNorm */
     const float* const* ln2_b;
+    /* Optional (all four or none; NULL = absent): ac_split_bf16x3 of the four weight matrices of every
+     * layer.  With them and AC_GEMM_BF16X3 the token-row GEMMs run entirely on pre-split operands (the
+     * LayerNorm / attention / GELU producers emit activation planes); without them operands are split
+     * inside the GEMMs.  Same results to fp32 rounding either way. */
+    const uint16_t* const* qkv_w3;
+    const uint16_t* const* ao_w3;
+    const uint16_t* const* ff1_w3;
+    const uint16_t* const* ff2_w3;
 } ac_bert_weights;
 
 int ac_bert_workspace(const ac_bert_config* cfg, int b, int S, size_t* bytes);

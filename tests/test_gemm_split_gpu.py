@@ -140,3 +140,13 @@ def test_encoder_parity_holds_under_split_arithmetic(cuda_dev, arith):
     assert es < 1e-4, es
     assert es <= 3 * e32 + 1e-6, (es, e32)
     assert (gs - g32).abs().max().item() < 5e-6
+    # the same arithmetic without pre-split planes (operands split inside the GEMM tiles): the planes path
+    # (LayerNorm / attention / GELU producers emitting operand planes) is a layout change, not a numeric one
+    saved = [getattr(enc.weights, k) for k in ("qkv_w3", "ao_w3", "ff1_w3", "ff2_w3")]
+    for k in ("qkv_w3", "ao_w3", "ff1_w3", "ff2_w3"):
+        setattr(enc.weights, k, None)
+    gi = enc.encode_cls(ids, types, mask).cpu()
+    for k, v in zip(("qkv_w3", "ao_w3", "ff1_w3", "ff2_w3"), saved):
+        setattr(enc.weights, k, v)
+    assert (gi - want).abs().max().item() < 1e-4
+    assert (gi - gs).abs().max().item() < 5e-6
