@@ -69,7 +69,7 @@ _SIGNATURES = {
     "ac_gemm_get_arith": (c_int, []),
     "ac_split_bf16x3": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "ac_linear_bf16x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-                                 c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+                                 c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ac_head_param_count": (c_int64, [ctypes.POINTER(ac_head_dims)]),
     "ac_head_workspace": (c_int, [ctypes.POINTER(ac_head_dims), c_int, ctypes.POINTER(c_size_t)]),
     "ac_head_forward": (c_int, [ctypes.POINTER(ac_head_dims), c_void_p, c_void_p, c_int64, c_int, c_void_p,

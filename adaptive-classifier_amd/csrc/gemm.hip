@@ -13,6 +13,9 @@
 //                    a fixed order (deterministic).  Any operand layout; used for the small
 //                    latency-bound head GEMMs (B = 32) and odd shapes.
 #include "common.h"
+#ifndef AC_XCD_REMAP
+#define AC_XCD_REMAP 1
+#endif
 
 #include <math.h>
 #include <stdlib.h>
@@ -122,30 +125,49 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][2], float* __restri
         }
 }
 
-// epilogue that emits the result as operand planes of the NEXT GEMM (C[M,N] -> planes[p][n/8][row][n%8]):
-// lane owns column (lane & 31), so 8 neighbouring lanes fill one 16-byte k-slot of a row
+// epilogue that emits the result as operand planes of the NEXT GEMM (C[M,N] -> planes[p][n/8][row][n%8]).
+// In the C/D layout a lane owns one column, but a plane k-slot is 8 neighbouring columns of one row: each
+// wave transposes its 32x32 tiles through a private LDS scratch (the staging buffers are idle by now), so
+// every lane ends up with 8 consecutive columns of a row = one split8 and three 16-byte stores.
+constexpr int kTrLd = 36;                                  // padded row of the 32x32 transpose scratch (floats)
+constexpr int kTrFloats = 32 * kTrLd;                      // per wave
+
 template <int EPI, int TM>
 __device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][2], uint16_t* __restrict__ Cp, int M, int N,
-                                                  int m0, int n0, int wm, int wn, int lane, const Epilogue& epi) {
+                                                  int m0, int n0, int wm, int wn, int lane, const Epilogue& epi,
+                                                  float* scratch /* this wave's kTrFloats floats of LDS */) {
     const int64_t plane = (int64_t)M * N;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
-            if (col >= N) continue;
+            const int c0 = n0 + wn * 64 + ni * 32;
+            const int col = c0 + (lane & 31);
             const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
-            const float bias = epi.bias[col];
+            const float bias = col < N ? epi.bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = rbase + acc_row32(r, lane);
-                if (row >= M) continue;
-                const float v = fast_epilogue<EPI>(acc[mi][ni][r], bias, 0.f);
-                uint32_t h, m, l;
-                ac::split2(v, 0.f, h, m, l);
-                uint16_t* dst = Cp + ac::plane_off(M, row, col);
-                dst[0] = (uint16_t)h; dst[plane] = (uint16_t)m; dst[2 * plane] = (uint16_t)l;
+            for (int r = 0; r < 16; ++r)
+                scratch[acc_row32(r, lane) * kTrLd + (lane & 31)] = fast_epilogue<EPI>(acc[mi][ni][r], bias, 0.f);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int rr = (lane >> 2) + 16 * u, q = lane & 3;       // row of the tile, k-slot of 8 columns
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(scratch + rr * kTrLd + 8 * q);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(scratch + rr * kTrLd + 8 * q + 4);
+                const int64_t row = rbase + rr;
+                const int cq = c0 + 8 * q;
+                if (row < M && cq < N) {
+                    uint4 H, Mi, L;
+                    ac::split8(v0, v1, H, Mi, L);
+                    uint16_t* dst = Cp + ac::plane_off(M, row, cq);
+                    *reinterpret_cast<uint4*>(dst) = H;              // (N % 8 == 0: checked at launch)
+                    *reinterpret_cast<uint4*>(dst + plane) = Mi;
+                    *reinterpret_cast<uint4*>(dst + 2 * plane) = L;
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
 }
 
@@ -418,6 +440,15 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     *reinterpret_cast<uint4*>(dst + 2 * plane) = L;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (workgroup id % 8), each with a private 4 MB L2.  Map the
+// hardware id to a logical tile id so that every XCD owns one CONTIGUOUS range of tiles (column tiles
+// fastest): its resident blocks then share A row-panels and sweep the W panels together, instead of every
+// XCD touching every A panel.  Bijective for any block count (the guide's q/r formula).
+__device__ __forceinline__ int xcd_tile_id(int wg, int nwg) {
+    const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+}
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
@@ -441,7 +472,8 @@ __global__ __launch_bounds__(kTileThreads, 3) void gemm_planes_nt(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (N + BN - 1) / BN;
-    const int bn = blockIdx.x % ntn, bm = blockIdx.x / ntn;
+    const int tile = AC_XCD_REMAP ? xcd_tile_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bn = tile % ntn, bm = tile / ntn;
     const int m0 = bm * BM, n0 = bn * BN;
     const int i = lane & 31, kg = lane >> 5;
 
@@ -521,8 +553,11 @@ __global__ __launch_bounds__(kTileThreads, 3) void gemm_planes_nt(
         if (!A_PLANES) store_a(cur ^ 1);
         __syncthreads();      // drains the global_load_lds queue (vmcnt(0)) and ends every read of `cur`
     }
-    if (C_PLANES) store_tile_planes<EPI, TM>(acc, reinterpret_cast<uint16_t*>(C), M, N, m0, n0, wm, wn, lane, epi);
-    else store_tile<EPI, TM>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, epi);
+    if (C_PLANES) {
+        static_assert(sizeof(lds) >= 4 * kTrFloats * sizeof(float), "transpose scratch must fit the staging buffers");
+        store_tile_planes<EPI, TM>(acc, reinterpret_cast<uint16_t*>(C), M, N, m0, n0, wm, wn, lane, epi,
+                                   reinterpret_cast<float*>(&lds[0][0][0]) + wave * kTrFloats);
+    } else store_tile<EPI, TM>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -729,8 +764,8 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
     } while (0)
         if (Cp) {
             // result emitted as planes for the next GEMM: both operands pre-split, bias (+GELU) epilogues only
-            AC_REQUIRE(planes && Ap && (cls == EPI_BIAS || cls == EPI_BIAS_GELU), AC_EUNSUPPORTED,
-                       "gemm: planes output needs pre-split operands and a bias / bias+gelu epilogue");
+            AC_REQUIRE(planes && Ap && (cls == EPI_BIAS || cls == EPI_BIAS_GELU) && (N % 8) == 0, AC_EUNSUPPORTED,
+                       "gemm: planes output needs pre-split operands, N %% 8 == 0 and a bias / bias+gelu epilogue");
             float* Cq = reinterpret_cast<float*>(Cp);
             if (cls == EPI_BIAS_GELU) {
                 if (tm == 2) hipLaunchKernelGGL((gemm_planes_nt<EPI_BIAS_GELU, 2, true, true>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, Cq, ldc, M, N, K, epi);
@@ -856,14 +891,14 @@ extern "C" int ac_split_bf16x3(const float* d_X, int64_t ldx, int64_t rows, int 
 
 extern "C" int ac_linear_bf16x3(const float* d_A, int64_t lda, const uint16_t* d_A_planes, const float* d_W,
                                 int64_t ldw, const uint16_t* d_W_planes, const float* d_bias,
-                                const float* d_residual, int64_t ldr, float* d_C, int64_t ldc, int M, int N, int K,
-                                int act, ac_stream_t stream) {
-    AC_REQUIRE(d_A && d_W && d_C, AC_EINVAL, "linear: null pointer");
+                                const float* d_residual, int64_t ldr, float* d_C, int64_t ldc,
+                                uint16_t* d_C_planes, int M, int N, int K, int act, ac_stream_t stream) {
+    AC_REQUIRE(d_A && d_W && (d_C || d_C_planes), AC_EINVAL, "linear: null pointer");
     AC_REQUIRE(M >= 0 && N >= 0 && K >= 1 && lda >= K && ldw >= K && ldc >= N, AC_EINVAL,
                "linear: bad shape M=%d N=%d K=%d", M, N, K);
     AC_REQUIRE(act >= 0 && act <= 2, AC_EINVAL, "linear: bad activation %d", act);
     AC_REQUIRE(!d_A_planes || d_W_planes, AC_EINVAL, "linear: A planes need W planes");
     return ac::linear_f32(d_A, lda, d_W, ldw, d_bias, d_residual, ldr, d_C, ldc, M, N, K, act, nullptr, 1.f,
                           (hipStream_t)stream, 0.f, 0, d_W_planes,
-                          (d_A_planes && ac::linear_takes_planes(M, N, K)) ? d_A_planes : nullptr);
+                          (d_A_planes && ac::linear_takes_planes(M, N, K)) ? d_A_planes : nullptr, d_C_planes);
 }

@@ -171,12 +171,15 @@ int ac_split_bf16x3(const float* d_X, int64_t ldx, int64_t rows, int K,
 /* ac_linear_f32 with optional pre-split operands (either may be NULL; A planes require W planes).  The
  * planes are used when the arithmetic mode is AC_GEMM_BF16X3 and the shape takes the LDS-tiled path
  * (M >= 192, K % 32 == 0); otherwise the fp32 operands are read, so both must always be valid.
- * d_W_planes is ac_split_bf16x3 of W[N, K]; d_A_planes of A[M, K]. */
+ * d_W_planes is ac_split_bf16x3 of W[N, K]; d_A_planes of A[M, K].
+ * d_C_planes (optional): emit the result as the operand planes of a following GEMM (layout of
+ * ac_split_bf16x3 of C[M, N]) INSTEAD of d_C; needs both operand planes, the pre-split path (else
+ * AC_EUNSUPPORTED), N % 8 == 0, no residual. */
 int ac_linear_bf16x3(const float* d_A, int64_t lda, const uint16_t* d_A_planes,
                      const float* d_W, int64_t ldw, const uint16_t* d_W_planes,
                      const float* d_bias, const float* d_residual, int64_t ldr,
-                     float* d_C, int64_t ldc, int M, int N, int K, int act,
-                     ac_stream_t stream);
+                     float* d_C, int64_t ldc, uint16_t* d_C_planes,
+                     int M, int N, int K, int act, ac_stream_t stream);
 
 /* Flat parameter block of an AdaptiveHead with hidden dims [H1, H2]
  * (classifier.py:1241: H1 = D, H2 = D/2).  All six tensors live in ONE

@@ -42,7 +42,7 @@ def _linear(nv, dev, A, W, b, R, act, planes=""):
         Ap = _planes(nv, dev, Ad) if "a" in planes else None
         nv.check(nv.lib().ac_linear_bf16x3(nv.ptr(Ad), K, nv.ptr(Ap) if Ap is not None else None, nv.ptr(Wd), K,
                                            nv.ptr(Wp), nv.ptr(bd), nv.ptr(Rd) if R is not None else None, N,
-                                           nv.ptr(C), N, M, N, K, act, nv.stream_ptr(dev)), "ac_linear_bf16x3")
+                                           nv.ptr(C), N, None, M, N, K, act, nv.stream_ptr(dev)), "ac_linear_bf16x3")
     return C.cpu().numpy().astype(np.float64)
 
 
@@ -150,3 +150,28 @@ def test_encoder_parity_holds_under_split_arithmetic(cuda_dev, arith):
         setattr(enc.weights, k, v)
     assert (gi - want).abs().max().item() < 1e-4
     assert (gi - gs).abs().max().item() < 5e-6
+
+
+@pytest.mark.parametrize("M,N,K,act", [(8192, 3072, 768, 2), (200, 136, 96, 0), (1024, 768, 64, 2)])
+def test_planes_output_equals_split_of_fp32_output(M, N, K, act, cuda_dev, arith):
+    """d_C_planes: the GEMM emits its result directly as the next GEMM's operand planes.  They must be
+    bit-identical to ac_split_bf16x3 of the fp32 result of the same kernel."""
+    from adaptive_classifier import _native as nv
+    rng = np.random.default_rng(N)
+    arith(BF16X3)
+    Ad = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(cuda_dev)
+    Wd = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(cuda_dev)
+    bd = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(cuda_dev)
+    Ap, Wp = _planes(nv, cuda_dev, Ad), _planes(nv, cuda_dev, Wd)
+    C = torch.empty((M, N), device=cuda_dev)
+    Cp = torch.zeros(3 * M * N, dtype=torch.int16, device=cuda_dev)
+    lib, st = nv.lib(), nv.stream_ptr(cuda_dev)
+    nv.check(lib.ac_linear_bf16x3(nv.ptr(Ad), K, nv.ptr(Ap), nv.ptr(Wd), K, nv.ptr(Wp), nv.ptr(bd), None, 0,
+                                  nv.ptr(C), N, None, M, N, K, act, st), "fp32 out")
+    nv.check(lib.ac_linear_bf16x3(nv.ptr(Ad), K, nv.ptr(Ap), nv.ptr(Wd), K, nv.ptr(Wp), nv.ptr(bd), None, 0,
+                                  None, N, nv.ptr(Cp), M, N, K, act, st), "planes out")
+    assert torch.equal(Cp, _planes(nv, cuda_dev, C))
+    # a shape that does not take the pre-split kernel must refuse planes output loudly
+    rc = lib.ac_linear_bf16x3(nv.ptr(Ad), K, nv.ptr(Ap), nv.ptr(Wd), K, nv.ptr(Wp), nv.ptr(bd), None, 0,
+                              None, N, nv.ptr(Cp), 16, N, K, act, st)
+    assert rc != 0
