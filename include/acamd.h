@@ -159,6 +159,11 @@ int ac_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
 int ac_gemm_set_arith(int mode);
 int ac_gemm_get_arith(void);
 
+/* Diagnostic: resident workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor) of the LDS-tiled
+ * GEMM kernels.  kernel: 0 = fp32-MFMA tile, 1 = bf16x3 split-in-kernel, 2 = bf16x3 planes; tm: 1 = 64-row,
+ * 2 = 128-row tile. */
+int ac_gemm_occupancy(int kernel, int tm, int* blocks_per_cu);
+
 /* Pre-split operands for AC_GEMM_BF16X3.  X[rows, K] fp32 (K % 8 == 0, 16-byte aligned rows) -> three bf16
  * planes h, m, l with X == h + m + l (to 2^-27 |x|), stored k-slot-major
  *     planes[p][k / 8][row][k % 8]        (uint16 units; 3 * rows * K in total)
