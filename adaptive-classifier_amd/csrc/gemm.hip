@@ -902,3 +902,14 @@ extern "C" int ac_linear_bf16x3(const float* d_A, int64_t lda, const uint16_t* d
                           (hipStream_t)stream, 0.f, 0, d_W_planes,
                           (d_A_planes && ac::linear_takes_planes(M, N, K)) ? d_A_planes : nullptr, d_C_planes);
 }
+
+/* diagnostic: resident blocks per CU of the LDS-tiled kernels (bias epilogue), by hipOccupancy */
+extern "C" int ac_gemm_occupancy(int kernel, int tm, int* blocks_per_cu) {
+    AC_REQUIRE(blocks_per_cu && (tm == 1 || tm == 2) && kernel >= 0 && kernel <= 2, AC_EINVAL, "occupancy: bad arguments");
+    const void* f = nullptr;
+    if (kernel == 0) f = tm == 2 ? (const void*)gemm_tile_nt<EPI_BIAS, 2> : (const void*)gemm_tile_nt<EPI_BIAS, 1>;
+    else if (kernel == 1) f = tm == 2 ? (const void*)gemm_split_nt<EPI_BIAS, 2> : (const void*)gemm_split_nt<EPI_BIAS, 1>;
+    else f = tm == 2 ? (const void*)gemm_planes_nt<EPI_BIAS, 2, true, false> : (const void*)gemm_planes_nt<EPI_BIAS, 1, true, false>;
+    AC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, kTileThreads, 0));
+    return AC_OK;
+}
