@@ -94,6 +94,8 @@ _SIGNATURES = {
     "ac_ewc_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                   c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p,
                                   c_void_p, c_void_p]),
+    "ac_blend_topk": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "ac_bert_workspace": (c_int, [ctypes.POINTER(ac_bert_config), c_int, c_int, ctypes.POINTER(c_size_t)]),
     "ac_bert_encode_cls": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,

@@ -291,10 +291,10 @@ class AdaptiveClassifier:
         return ewc
 
     # ------------------------------------------------------------------------------ prediction
-    def _device_scores(self, emb: torch.Tensor, k_proto: int):
-        """Device stage shared by predict / predict_batch: kNN scores + head probabilities.
-        One D2H at the end.  Returns numpy (proto_scores [b,kp] f32, proto_class [b,kp] i64 with -1 for
-        padding / unknown labels, head_probs [b,C] f32 or None)."""
+    def _device_stage(self, emb: torch.Tensor, k_proto: int):
+        """Device stage shared by predict / predict_batch: kNN scores + head probabilities, left on the device.
+        Returns (proto_scores [b,kp] f32, proto_class [b,kp] i64 with -1 for padding / unknown labels,
+        head_probs [b,C] f32) -- each None when that source does not exist."""
         with torch.no_grad():
             S = Cid = probs = None
             if self.memory.index.ntotal > 0 or self.memory.updates_since_rebuild >= self.config.prototype_update_frequency:
@@ -303,9 +303,71 @@ class AdaptiveClassifier:
             if self.adaptive_head is not None:
                 self.adaptive_head.eval()
                 probs = softmax_rows(self.adaptive_head.forward_native(emb))
-            out = (None if S is None else S.cpu().numpy(), None if S is None else Cid.cpu().numpy(),
-                   None if probs is None else probs.cpu().numpy())
-        return out
+        return S, Cid, probs
+
+    def _device_scores(self, emb: torch.Tensor, k_proto: int):
+        """_device_stage copied to the host as numpy (the inputs of the numpy formula `_blend`)."""
+        S, Cid, probs = self._device_stage(emb, k_proto)
+        return (None if S is None else S.cpu().numpy(), None if S is None else Cid.cpu().numpy(),
+                None if probs is None else probs.cpu().numpy())
+
+    _BLEND_DEVICE_MAX_CLASSES = 2048
+
+    def _blend_weights(self, regular: bool):
+        """Per-class (prototype, head) weights as fp64 device vectors: 0.7 / 0.3 for predict_batch (:1359-1384);
+        by training history for predict (:447-480: < 10 examples -> 0.3 / 0.7)."""
+        C = len(self.id_to_label)
+        if regular:
+            hist = [self.training_history.get(self.id_to_label[c], 0) for c in range(C)]
+            key = ("r", tuple(h < 10 for h in hist))
+        else:
+            key = ("b", C)
+        cached = getattr(self, "_blend_w_cache", None)
+        if cached is None or cached[0] != key:
+            if regular:
+                wp = [0.3 if h < 10 else 0.7 for h in hist]
+                wh = [0.7 if h < 10 else 0.3 for h in hist]
+            else:
+                wp, wh = [0.7] * C, [0.3] * C
+            w = torch.tensor([wp, wh], dtype=torch.float64, device=self.device)
+            self._blend_w_cache = cached = (key, w)
+        return cached[1]
+
+    def _finish(self, S, Cid, P, k: int, regular: bool, b: int = 0):
+        """Blend + normalise + top-k of one device stage -> the reference's list of (label, score) per query.
+        On the device (ac_blend_topk, one packed D2H) for up to 2048 classes; the numpy formula beyond."""
+        C = len(self.id_to_label)
+        if S is None and P is None:
+            return [[] for _ in range(b)]
+        if C < 1 or C > self._BLEND_DEVICE_MAX_CLASSES:
+            return self._blend(None if S is None else S.cpu().numpy(), None if S is None else Cid.cpu().numpy(),
+                               None if P is None else P.cpu().numpy(), k, regular)
+        b = (S if S is not None else P).shape[0]
+        kp = 0 if S is None else S.shape[1]
+        kk = max(1, min(k, C))
+        w = self._blend_weights(regular)
+        ncls = C if regular else min(k, C)
+        # packed result: n[b] i32 | class[b,kk] i32 | score[b,kk] f64 (8-byte aligned), one D2H
+        off_cls = 4 * b
+        off_val = (off_cls + 4 * b * kk + 7) // 8 * 8
+        out = torch.empty(off_val + 8 * b * kk, dtype=torch.uint8, device=self.device)
+        base = out.data_ptr()
+        if S is not None:
+            S, Cid = S.contiguous(), Cid.contiguous()
+        if P is not None:
+            P = P.contiguous()
+        nv.check(nv.lib().ac_blend_topk(None if S is None else S.data_ptr(), None if S is None else Cid.data_ptr(), kp,
+                                        None if P is None else P.data_ptr(), C, w[0].data_ptr(), w[1].data_ptr(),
+                                        ncls, kk, b, base, base + off_cls, base + off_val,
+                                        nv.stream_ptr(self.device)), "ac_blend_topk")
+        host = out.cpu().numpy()
+        n = host[:off_cls].view(np.int32).tolist()
+        cls = host[off_cls:off_cls + 4 * b * kk].view(np.int32).reshape(b, kk)
+        val = host[off_val:].view(np.float64).reshape(b, kk).tolist()
+        names = np.array([self.id_to_label[c] for c in range(C)], dtype=object)
+        labs = names[np.clip(cls, 0, C - 1)].tolist()
+        kcap = k if k >= 0 else 0
+        return [list(zip(labs[q][:min(n[q], kcap)], val[q][:min(n[q], kcap)])) for q in range(b)]
 
     def predict(self, text: str, k: int = 5) -> List[Tuple[str, float]]:
         if not text:
@@ -317,8 +379,8 @@ class AdaptiveClassifier:
         history-keyed weights (0.3/0.7 vs 0.7/0.3), stable sort, normalise, top-k."""
         emb = self._embed_device([text])
         max_classes = len(self.id_to_label) if self.id_to_label else k
-        S, I, P = self._device_scores(emb, max_classes)
-        return self._blend(S, I, P, k, regular=True)[0]
+        S, I, P = self._device_stage(emb, max_classes)
+        return self._finish(S, I, P, k, regular=True, b=1)[0]
 
     def predict_batch(self, texts: List[str], k: int = 5, batch_size: int = 32) -> List[List[Tuple[str, float]]]:
         """classifier.py:1308-1388: top-k prototypes + top-k head classes, fixed 0.7/0.3 weights."""
@@ -332,8 +394,8 @@ class AdaptiveClassifier:
 
     def predict_embeddings(self, emb: torch.Tensor, k: int = 5) -> List[List[Tuple[str, float]]]:
         """predict_batch() after the encoder: device kNN + head, then the blend of :1359-1384."""
-        S, I, P = self._device_scores(emb, k)
-        return self._blend(S, I, P, k, regular=False)
+        S, I, P = self._device_stage(emb, k)
+        return self._finish(S, I, P, k, regular=False, b=emb.shape[0])
 
     def _blend(self, S, Cid, P, k, regular):
         """The two score-combination formulas of the reference, evaluated in fp64 like its Python floats,

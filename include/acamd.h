@@ -337,6 +337,24 @@ typedef struct {
     const uint16_t* const* ff2_w3;
 } ac_bert_weights;
 
+/*
+ * classifier.py:447-480 (predict) and :1359-1384 (predict_batch): blend prototype scores with head
+ * probabilities, normalise, stable-sort, keep the top k -- on the device, in fp64 like the reference's
+ * Python floats.  d_scores / d_hit_class [b, kp]: ac_proto_scores output and the class id of every hit
+ * (-1 = padding / unknown label; both NULL when there is no prototype store); d_head_probs [b, C] or NULL;
+ * d_w_proto / d_w_head [C] fp64 per-class weights (0.7/0.3 for predict_batch; by training history for
+ * predict); ncls_head = how many of the head's top classes vote (C for predict, min(k, C) for
+ * predict_batch).  Output per query: n = min(k, classes present), then class ids and normalised scores in
+ * descending order (ties: hits in distance order first, then head classes by probability).
+ * C <= 2048 (AC_EUNSUPPORTED beyond: the host formula in classifier.py::_blend covers that).
+ */
+int ac_blend_topk(const float* d_scores, const int64_t* d_hit_class, int kp,
+                  const float* d_head_probs, int C,
+                  const double* d_w_proto, const double* d_w_head,
+                  int ncls_head, int k, int b,
+                  int32_t* d_out_n, int32_t* d_out_class, double* d_out_score,
+                  ac_stream_t stream);
+
 int ac_bert_workspace(const ac_bert_config* cfg, int b, int S, size_t* bytes);
 
 /*

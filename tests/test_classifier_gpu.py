@@ -288,3 +288,38 @@ def test_load_classmethod_and_legacy_layout(clf, tmp_path, cuda_dev):
             got = other.predict_batch([t], k=3)[0]        # predict_batch weights do not depend on history
             assert [l for l, _ in got] == [l for l, _ in want]
             assert np.allclose([s for _, s in got], [s for _, s in want], atol=1e-6)
+
+
+@pytest.mark.parametrize("C,kp,k,regular", [(4, 4, 3, False), (4, 4, 3, True), (3, 16, 5, False), (37, 16, 5, False),
+                                            (37, 37, 37, True), (300, 24, 7, False), (2048, 8, 4, True)])
+def test_device_blend_equals_numpy_formula(C, kp, k, regular, cuda_dev):
+    """ac_blend_topk (device, fp64) against AdaptiveClassifier._blend (the numpy statement of classifier.py:447-480
+    / :1359-1384 pinned on the reference's outputs in test_host_logic): same labels in the same order, scores to
+    1e-12, on random inputs with several hits per class, padding ids, ties and exact duplicates."""
+    from adaptive_classifier import AdaptiveClassifier
+    from adaptive_classifier.encoder import HipBertEncoder
+    enc = HipBertEncoder(small_bert(), device=cuda_dev)
+    c = AdaptiveClassifier("synthetic-bert-tiny", device="cuda:0", encoder=enc, tokenizer=HashTokenizer())
+    c.id_to_label = {i: f"class{i:04d}" for i in range(C)}
+    c.label_to_id = {v: i for i, v in c.id_to_label.items()}
+    rng = np.random.default_rng(C * 1000 + kp)
+    c.training_history = {c.id_to_label[i]: int(rng.integers(0, 20)) for i in range(C)}
+    b = 33
+    S = rng.random((b, kp)).astype(np.float32)
+    S[:, 1:] = np.minimum.accumulate(S, axis=1)[:, 1:]                  # descending like real hits
+    Cid = rng.integers(-1, C, (b, kp)).astype(np.int64)                  # -1 = padding; repeats = several rows per class
+    P = rng.random((b, C)).astype(np.float32)
+    P /= P.sum(1, keepdims=True)
+    P[3, :] = 1.0 / C                                                    # all head probabilities tied
+    S[5, :] = 0.25                                                       # all hit scores tied
+    if C > 2:
+        P[7, 1] = P[7, 2]                                                # an exact duplicate pair
+    for use_s, use_p in ((True, True), (True, False), (False, True)):
+        Sn, Cn, Pn = (S if use_s else None), (Cid if use_s else None), (P if use_p else None)
+        want = c._blend(Sn, Cn, Pn, k, regular)
+        dev = lambda a: None if a is None else torch.from_numpy(a).to(cuda_dev)
+        got = c._finish(dev(Sn), dev(Cn), dev(Pn), k, regular, b=b)
+        assert len(got) == b
+        for q, (g, w) in enumerate(zip(got, want)):
+            assert [l for l, _ in g] == [l for l, _ in w], (q, use_s, use_p, g, w)
+            assert np.allclose([s for _, s in g], [s for _, s in w], rtol=0, atol=1e-12), (q, g, w)
