@@ -87,6 +87,11 @@ _SIGNATURES = {
                                    c_void_p, c_void_p,
                                    c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ac_head_train_epoch": (c_int, [ctypes.POINTER(ac_head_dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_float,
+                                    c_uint64, c_void_p, c_void_p,
+                                    c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_int), c_void_p]),
     "ac_softmax_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ac_l2_normalize_rows": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "ac_fisher_accumulate": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),

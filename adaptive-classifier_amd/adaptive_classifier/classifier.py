@@ -186,19 +186,15 @@ class AdaptiveClassifier:
             # one H2D of the epoch's batch order (same order as the reference's seeded DataLoader)
             batches = [idx for (idx,) in loader]
             order = torch.cat(batches).to(X.device)
-            off = 0
-            for idx in batches:
-                nb = idx.numel()
-                index = order[off: off + nb]
-                off += nb
-                if ewc is not None:
-                    trainer.fused_step(X, y, index, AdaptiveHead.DROPOUT_P, base_seed + steps, fisher=ewc.fisher_flat,
-                                       old_params=ewc.old_flat, lambda_over_B=lambda_B / nb, loss_kind=loss_kind,
-                                       targets_all=targets)
-                else:
-                    trainer.fused_step(X, y, index, AdaptiveHead.DROPOUT_P, base_seed + steps, loss_kind=loss_kind,
-                                       targets_all=targets)
-                steps += 1
+            # every batch but the last has batch_size rows (DataLoader, drop_last=False): one native call
+            # runs the whole epoch (ac_head_train_epoch) -- no per-step Python / ctypes work
+            nb0 = batches[0].numel()
+            assert all(b.numel() == nb0 for b in batches[:-1]) and batches[-1].numel() <= nb0
+            steps += trainer.fused_epoch(X, y, order, nb0, AdaptiveHead.DROPOUT_P, base_seed + steps,
+                                         fisher=None if ewc is None else ewc.fisher_flat,
+                                         old_params=None if ewc is None else ewc.old_flat,
+                                         lambda_B=0.0 if ewc is None else lambda_B, loss_kind=loss_kind,
+                                         targets_all=targets)
             total = trainer.loss_accum
             avg_loss = float(total.item()) / len(loader)         # the only host sync of the epoch
             if sched is not None:

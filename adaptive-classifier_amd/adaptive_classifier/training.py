@@ -119,3 +119,23 @@ class HeadTrainer:
                 self.betas[1], self.eps, self.weight_decay, self.t, nv.ptr(self.out3), nv.ptr(self.loss_accum),
                 nv.ptr(ws), ws.numel(), nv.stream_ptr(self.device)), "ac_head_train_step")
         return self.out3
+
+    def fused_epoch(self, X_all, y_all, order, batch, dropout_p=0.1, seed0=0, fisher=None, old_params=None,
+                    lambda_B=0.0, loss_kind=LOSS_CE, targets_all=None):
+        """One call = one epoch of fused steps over consecutive `batch`-row slices of `order`
+        (`ac_head_train_epoch`): step i uses dropout seed seed0 + i; EWC weight lambda_B / rows_i.
+        Returns the number of steps taken."""
+        n_total = int(order.numel())
+        ws = self._workspace(min(batch, max(n_total, 1)))
+        done = ctypes.c_int(0)
+        with torch.cuda.device(self.device):
+            nv.check(nv.lib().ac_head_train_epoch(
+                ctypes.byref(self.dims), nv.ptr(self.flat), nv.ptr(self.m), nv.ptr(self.v), nv.ptr(self.grads),
+                nv.ptr(X_all), X_all.stride(0), nv.ptr(y_all), nv.ptr(targets_all),
+                0 if targets_all is None else targets_all.stride(0), loss_kind, nv.ptr(order), n_total, batch,
+                dropout_p, seed0, nv.ptr(fisher), nv.ptr(old_params), lambda_B, self.max_grad_norm, self.lr,
+                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t + 1, nv.ptr(self.out3),
+                nv.ptr(self.loss_accum), nv.ptr(ws), ws.numel(), ctypes.byref(done),
+                nv.stream_ptr(self.device)), "ac_head_train_epoch")
+        self.t += done.value
+        return done.value

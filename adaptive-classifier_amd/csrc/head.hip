@@ -537,3 +537,28 @@ extern "C" int ac_ewc_adamw_step(float* d_params, const float* d_grads, float* d
     return adamw_launch(d_params, d_grads, d_m, d_v, d_fisher, d_old, n, lambda_over_B, max_grad_norm, lr, beta1, beta2,
                         eps, weight_decay, step, d_out, (float*)d_scratch, nullptr, nullptr, (hipStream_t)stream_);
 }
+
+// One whole epoch of the loop at classifier.py:1485-1507 / :329-353 in ONE call: the batches are consecutive
+// slices of d_order (the seeded DataLoader's order for this epoch, uploaded once), step i uses dropout seed
+// seed0 + i and AdamW step step0 + i, the EWC weight is lambda_B / (rows of that batch) as `ewc_loss / batch`
+// in the reference.  Only launches -- the host-side per-step cost is the kernel enqueues themselves.
+extern "C" int ac_head_train_epoch(const ac_head_dims* dims, float* d_params, float* d_m, float* d_v, float* d_grads,
+                                   const float* d_X, int64_t ldx, const int64_t* d_y, const float* d_targets,
+                                   int64_t ldt, int loss_kind, const int64_t* d_order, int64_t n_total, int batch,
+                                   float dropout_p, uint64_t seed0, const float* d_fisher, const float* d_old,
+                                   float lambda_B, float max_grad_norm, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, int step0, float* d_out, float* d_loss_accum, void* d_ws,
+                                   size_t ws_bytes, int* steps_done, ac_stream_t stream) {
+    AC_REQUIRE(d_order && n_total >= 0 && batch >= 1 && step0 >= 1, AC_EINVAL, "head_train_epoch: bad arguments");
+    int n = 0;
+    for (int64_t off = 0; off < n_total; off += batch, ++n) {
+        const int nb = (int)((n_total - off) < batch ? (n_total - off) : batch);
+        const int rc = ac_head_train_step(dims, d_params, d_m, d_v, d_grads, d_X, ldx, d_y, d_targets, ldt, loss_kind,
+                                          d_order + off, nb, dropout_p, seed0 + (uint64_t)n, d_fisher, d_old,
+                                          d_fisher ? (float)((double)lambda_B / nb) : 0.f, max_grad_norm, lr, beta1, beta2, eps,
+                                          weight_decay, step0 + n, d_out, d_loss_accum, d_ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    if (steps_done) *steps_done = n;
+    return AC_OK;
+}

@@ -257,6 +257,23 @@ int ac_head_train_step(const ac_head_dims* dims, float* d_params, float* d_m,
                        int step, float* d_out, float* d_loss_accum,
                        void* d_ws, size_t ws_bytes, ac_stream_t stream);
 
+/*
+ * One EPOCH of that loop in one call (classifier.py:1485-1507 / :329-353): batches are consecutive
+ * `batch`-row slices of d_order [n_total] (the epoch's DataLoader order; the last one may be short), step i
+ * uses dropout seed seed0 + i, AdamW step step0 + i (step0 >= 1) and EWC weight lambda_B / rows_i.  Same
+ * kernels as ac_head_train_step; the workspace must cover `batch` rows.  *steps_done = ceil(n_total/batch).
+ */
+int ac_head_train_epoch(const ac_head_dims* dims, float* d_params, float* d_m,
+                        float* d_v, float* d_grads, const float* d_X, int64_t ldx,
+                        const int64_t* d_y, const float* d_targets, int64_t ldt,
+                        int loss_kind, const int64_t* d_order, int64_t n_total, int batch,
+                        float dropout_p, uint64_t seed0,
+                        const float* d_fisher, const float* d_old, float lambda_B,
+                        float max_grad_norm, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int step0,
+                        float* d_out, float* d_loss_accum,
+                        void* d_ws, size_t ws_bytes, int* steps_done, ac_stream_t stream);
+
 /* F.softmax(logits, dim=1) over [B, C] rows (classifier.py:435,1345). */
 int ac_softmax_rows(const float* d_in, int B, int C, float* d_out,
                     ac_stream_t stream);

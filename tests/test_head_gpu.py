@@ -235,6 +235,42 @@ def test_fused_train_step_with_in_kernel_dropout_and_gather(cuda_dev):
     assert abs(_dropout_keep_np(1, 512, 768, 0.1).mean() - 0.9) < 0.005
 
 
+@pytest.mark.parametrize("with_ewc", [False, True])
+def test_fused_epoch_equals_the_step_loop(with_ewc, cuda_dev):
+    """ac_head_train_epoch (one call per epoch) is bit-identical to the per-step calls it replaces: same batches
+    (consecutive slices of the epoch order, short last batch), seeds seed0 + i, AdamW steps t0 + i, and the EWC
+    weight lambda_B / rows_i."""
+    D, C, B, n = 768, 4, 32, 77          # 77 = 2 full batches + one of 13
+    _, _, head_a, tr_a = _make_pair(D, C, cuda_dev)
+    _, _, head_b, tr_b = _make_pair(D, C, cuda_dev)
+    assert torch.equal(tr_a.flat, tr_b.flat)
+    Xall, yall = _data(n, D, C, seed=21)
+    Xd, yd = Xall.to(cuda_dev), yall.to(cuda_dev)
+    fisher = old = None
+    if with_ewc:
+        g = torch.Generator().manual_seed(5)
+        fisher = torch.rand(tr_a.flat.numel(), generator=g).to(cuda_dev)
+        old = (tr_a.flat + 0.01 * torch.randn(tr_a.flat.numel(), generator=g).to(cuda_dev)).contiguous()
+    order = torch.randperm(n, generator=torch.Generator().manual_seed(9)).to(cuda_dev)
+    for tr in (tr_a, tr_b):
+        tr.loss_accum.zero_()
+    for epoch in range(2):
+        seed0 = 777 + 10 * epoch
+        off = i = 0
+        while off < n:
+            nb = min(B, n - off)
+            tr_a.fused_step(Xd, yd, order[off:off + nb], 0.1, seed0 + i, fisher=fisher, old_params=old,
+                            lambda_over_B=(5.0 / nb) if with_ewc else 0.0)
+            off += nb
+            i += 1
+        done = tr_b.fused_epoch(Xd, yd, order, B, 0.1, seed0, fisher=fisher, old_params=old,
+                                lambda_B=5.0 if with_ewc else 0.0)
+        assert done == i == 3 and tr_a.t == tr_b.t
+        assert torch.equal(tr_a.flat, tr_b.flat) and torch.equal(tr_a.m, tr_b.m) and torch.equal(tr_a.v, tr_b.v)
+        assert tr_a.loss_accum.item() == tr_b.loss_accum.item()
+        assert torch.equal(tr_a.out3, tr_b.out3)
+
+
 def test_linear_randomised_shapes(cuda_dev):
     """Random (M, N, K, act, residual) through ac_linear_f32: exercises the small-M weight-streaming kernel,
     the direct kernel and both LDS tile heights, with ragged edges."""
