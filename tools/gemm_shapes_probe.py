@@ -15,7 +15,7 @@ for (M, N, K) in ((8192, 2304, 768), (8192, 768, 768), (8192, 3072, 768), (8192,
     lib.ac_split_bf16x3(nv.ptr(W), K, N, K, nv.ptr(Wp), nv.stream_ptr(dev)); lib.ac_split_bf16x3(nv.ptr(A), K, M, K, nv.ptr(Ap), nv.stream_ptr(dev))
     def go():
         if not mode:
-            nv.check(lib.ac_linear_f32(nv.ptr(A), K, nv.ptr(W), K, nv.ptr(b), None, N, nv.ptr(C), N, None, M, N, K, 0, nv.stream_ptr(dev)), "lin")
+            nv.check(lib.ac_linear_f32(nv.ptr(A), K, nv.ptr(W), K, nv.ptr(b), None, N, nv.ptr(C), N, M, N, K, 0, nv.stream_ptr(dev)), "lin")
         else:
             nv.check(lib.ac_linear_bf16x3(nv.ptr(A), K, nv.ptr(Ap) if "a" in mode else None, nv.ptr(W), K, nv.ptr(Wp), nv.ptr(b), None, N,
                                           nv.ptr(C), N, None, M, N, K, 0, nv.stream_ptr(dev)), "lin")
