@@ -40,6 +40,19 @@ class ac_bert_config(ctypes.Structure):
                 ("vocab", c_int), ("max_pos", c_int), ("type_vocab", c_int), ("ln_eps", c_float)]
 
 
+class ac_modernbert_config(ctypes.Structure):
+    _fields_ = [("hidden", c_int), ("layers", c_int), ("heads", c_int), ("intermediate", c_int), ("vocab", c_int),
+                ("max_pos", c_int), ("global_every", c_int), ("local_window", c_int), ("norm_eps", c_float)]
+
+
+class ac_modernbert_weights(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "tok_emb", "emb_norm_g", "emb_norm_b", "final_norm_g", "final_norm_b",
+        "rope_cos_global", "rope_sin_global", "rope_cos_local", "rope_sin_local",
+        "attn_norm_g", "attn_norm_b", "wqkv", "wqkv_b", "wo", "wo_b", "mlp_norm_g", "mlp_norm_b",
+        "wi", "wi_b", "wo2", "wo2_b", "zero_bias", "wqkv3", "wo3", "wi3", "wo23")]
+
+
 class ac_bert_weights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b",
@@ -101,6 +114,10 @@ _SIGNATURES = {
                                   c_void_p, c_void_p]),
     "ac_blend_topk": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ac_modernbert_workspace": (c_int, [ctypes.POINTER(ac_modernbert_config), c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "ac_modernbert_encode_cls": (c_int, [ctypes.POINTER(ac_modernbert_config), ctypes.POINTER(ac_modernbert_weights),
+                                         c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
+                                         c_void_p]),
     "ac_bert_workspace": (c_int, [ctypes.POINTER(ac_bert_config), c_int, c_int, ctypes.POINTER(c_size_t)]),
     "ac_bert_encode_cls": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,

@@ -11,7 +11,7 @@ Out of scope here and rejected loudly: ONNX runtime/export (:59-81,1031-1104), s
 (:482-522,1594-1823), Hub upload / model card (:917-1183).
 
 What changed underneath:
-  * the encoder is `HipBertEncoder` (one native call -> unit-norm CLS rows that stay in HBM);
+  * the encoder is `HipBertEncoder` / `HipModernBertEncoder` (one native call -> unit-norm CLS rows that stay in HBM);
   * kNN + exp/softmax scoring run on device for the whole batch (`PrototypeMemory.search_batch`);
   * the head forward is one native call for the whole batch; the blend arithmetic keeps the
     reference's Python-float (fp64) semantics but is vectorised;
@@ -59,9 +59,9 @@ class AdaptiveClassifier:
         self.model_name = model_name
         if encoder is None:
             from transformers import AutoModel, AutoTokenizer
-            from .encoder import HipBertEncoder
+            from .encoder import make_encoder
             hf = AutoModel.from_pretrained(model_name, trust_remote_code=trust_remote_code)
-            encoder = HipBertEncoder(hf.eval(), device=self.device)
+            encoder = make_encoder(hf.eval(), device=self.device)
             encoder.config._name_or_path = model_name
             if tokenizer is None:
                 tokenizer = AutoTokenizer.from_pretrained(model_name, trust_remote_code=trust_remote_code)

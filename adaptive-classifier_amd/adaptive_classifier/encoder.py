@@ -7,8 +7,10 @@ and DistilBERT checkpoints (bert-base-uncased, bert-large, e5-large-v2, bert-tin
 kNN query block (no device->host copy, cf. classifier.py:1282).
 
 Weights are taken from a transformers `BertModel` (pretrained or randomly initialised); Q/K/V
-projections are fused into one [3H, H] matrix.  Other architectures are not covered by the HIP
-encoder and raise.
+projections are fused into one [3H, H] matrix.  `HipModernBertEncoder` covers ModernBERT
+(answerdotai/ModernBERT-base: RoPE, alternating global / sliding-window attention, pre-norm, GeGLU) through
+`ac_modernbert_encode_cls`; `make_encoder` picks by `config.model_type`.  Other architectures are not
+covered by the HIP encoders and raise.
 """
 import ctypes
 
@@ -167,3 +169,147 @@ class HipBertEncoder:
             return per_tok * T * L + attn_layer * L
         last = 2.0 * T * 3.0 * H * H + 2.0 * b * (H * H + 2.0 * H * I) + attn_layer / S
         return per_tok * T * (L - 1) + attn_layer * (L - 1) + last
+
+
+def _split_planes(t, device):
+    """ac_split_bf16x3 of one [rows, K] fp32 weight (operand planes for AC_GEMM_BF16X3)."""
+    rows, K = t.shape
+    pl = torch.empty(3 * rows * K, dtype=torch.int16, device=device)
+    nv.check(nv.lib().ac_split_bf16x3(t.data_ptr(), K, rows, K, pl.data_ptr(), nv.stream_ptr(device)), "ac_split_bf16x3")
+    return pl
+
+
+class HipModernBertEncoder:
+    """ModernBERT (transformers modeling_modernbert.py) behind the same surface as HipBertEncoder."""
+
+    def __init__(self, hf_model, device=None):
+        nv.require_gpu()
+        cfg = hf_model.config
+        if getattr(cfg, "model_type", "") != "modernbert":
+            raise nv.NativeError(f"HipModernBertEncoder needs a ModernBERT model, got {getattr(cfg, 'model_type', None)!r}")
+        if cfg.hidden_activation != "gelu":
+            raise nv.NativeError(f"HipModernBertEncoder: activation {cfg.hidden_activation!r} unsupported (erf-GELU only)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        H, L, A, I = cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.intermediate_size
+        types = list(cfg.layer_types)
+        every = int(cfg.global_attn_every_n_layers)
+        if any((t == "full_attention") != (l % every == 0) for l, t in enumerate(types)):
+            raise nv.NativeError("HipModernBertEncoder: layer_types must be global every global_attn_every_n_layers")
+        self.config = _Cfg(H, getattr(cfg, "_name_or_path", ""))
+        self.training = False
+        self.ccfg = nv.ac_modernbert_config(H, L, A, I, cfg.vocab_size, cfg.max_position_embeddings, every,
+                                            int(cfg.sliding_window), float(cfg.norm_eps))
+        sd = {k: v.detach() for k, v in hf_model.state_dict().items()}
+        self._keep, self._arrays = [], {}
+
+        def own(t):
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return t
+
+        w = nv.ac_modernbert_weights()
+        w.tok_emb = own(sd["embeddings.tok_embeddings.weight"]).data_ptr()
+        w.emb_norm_g = own(sd["embeddings.norm.weight"]).data_ptr()
+        w.emb_norm_b = own(sd["embeddings.norm.bias"]).data_ptr() if "embeddings.norm.bias" in sd else None
+        w.final_norm_g = own(sd["final_norm.weight"]).data_ptr()
+        w.final_norm_b = own(sd["final_norm.bias"]).data_ptr() if "final_norm.bias" in sd else None
+        w.zero_bias = own(torch.zeros(max(3 * H, 2 * I))).data_ptr()
+        # RoPE tables exactly as ModernBertRotaryEmbedding builds them: fp32 inv_freq, fp32 outer product, cos / sin
+        dh = H // A
+        pos = torch.arange(cfg.max_position_embeddings, dtype=torch.float32)
+        for kind, key in (("global", "full_attention"), ("local", "sliding_attention")):
+            theta = float(cfg.rope_parameters[key]["rope_theta"])
+            inv_freq = 1.0 / (theta ** (torch.arange(0, dh, 2, dtype=torch.int64).to(dtype=torch.float) / dh))
+            freqs = (inv_freq[:, None].float() @ pos[None, :]).transpose(0, 1)          # [max_pos, dh/2]
+            setattr(w, f"rope_cos_{kind}", own(freqs.cos()).data_ptr())
+            setattr(w, f"rope_sin_{kind}", own(freqs.sin()).data_ptr())
+
+        def per_layer(field, name, optional=False):
+            ts = []
+            for l in range(L):
+                k = f"layers.{l}.{name}"
+                ts.append(own(sd[k]) if k in sd else None)
+            if all(t is None for t in ts):
+                if not optional:
+                    raise nv.NativeError(f"HipModernBertEncoder: {name} missing from the checkpoint")
+                setattr(w, field, None)
+                return ts
+            arr = (ctypes.c_void_p * L)(*[None if t is None else t.data_ptr() for t in ts])
+            self._arrays[field] = arr
+            setattr(w, field, ctypes.cast(arr, ctypes.c_void_p).value)
+            return ts
+
+        per_layer("attn_norm_g", "attn_norm.weight")            # layer 0: Identity -> NULL entry
+        per_layer("attn_norm_b", "attn_norm.bias", optional=True)
+        mats = {"wqkv": per_layer("wqkv", "attn.Wqkv.weight"), "wo": per_layer("wo", "attn.Wo.weight"),
+                "wi": per_layer("wi", "mlp.Wi.weight"), "wo2": per_layer("wo2", "mlp.Wo.weight")}
+        per_layer("wqkv_b", "attn.Wqkv.bias", optional=True)
+        per_layer("wo_b", "attn.Wo.bias", optional=True)
+        per_layer("mlp_norm_g", "mlp_norm.weight")
+        per_layer("mlp_norm_b", "mlp_norm.bias", optional=True)
+        per_layer("wi_b", "mlp.Wi.bias", optional=True)
+        per_layer("wo2_b", "mlp.Wo.bias", optional=True)
+        self._planes = []
+        for field, key in (("wqkv3", "wqkv"), ("wo3", "wo"), ("wi3", "wi"), ("wo23", "wo2")):
+            planes = [_split_planes(t, self.device) for t in mats[key]]
+            self._planes.extend(planes)
+            arr = (ctypes.c_void_p * L)(*[t.data_ptr() for t in planes])
+            self._arrays[field] = arr
+            setattr(w, field, ctypes.cast(arr, ctypes.c_void_p).value)
+        self.weights = w
+        self._ws = None
+        self.num_params = sum(t.numel() for t in self._keep)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        self.training = False
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise nv.NativeError("HipModernBertEncoder is bound to its GPU; build a new one for another device")
+        return self
+
+    def workspace_bytes(self, b, S):
+        need = ctypes.c_size_t(0)
+        nv.check(nv.lib().ac_modernbert_workspace(ctypes.byref(self.ccfg), b, S, ctypes.byref(need)),
+                 "ac_modernbert_workspace")
+        return need.value
+
+    def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None):
+        """int64 [b, S] ids (+ optional mask; token types do not exist in ModernBERT) -> unit-norm CLS [b, H]."""
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        b, S = ids.shape
+        mk = None if attention_mask is None else attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        H = self.ccfg.hidden
+        if out is None:
+            out = torch.empty((b, H), dtype=torch.float32, device=self.device)
+        need = self.workspace_bytes(b, S)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            nv.check(nv.lib().ac_modernbert_encode_cls(
+                ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids), nv.ptr(mk), b, S, nv.ptr(out),
+                out.stride(0), nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
+                "ac_modernbert_encode_cls")
+        return out
+
+    def flops(self, b, S, executed=True):
+        c = self.ccfg
+        H, I, L = c.hidden, c.intermediate, c.layers
+        n_glob = sum(1 for l in range(L) if l % c.global_every == 0)
+        keys_local = min(S, 2 * c.local_window + 1)
+        attn = 4.0 * b * c.heads * S * (H // c.heads) * (n_glob * S + (L - n_glob) * keys_local)
+        return 2.0 * b * S * L * (4.0 * H * H + 3.0 * H * I) + attn
+
+
+def make_encoder(hf_model, device=None):
+    """The native encoder for a transformers model: BERT / DistilBERT -> HipBertEncoder, ModernBERT ->
+    HipModernBertEncoder; anything else raises (there is no eager fallback)."""
+    mtype = getattr(hf_model.config, "model_type", "bert")
+    if mtype == "modernbert":
+        return HipModernBertEncoder(hf_model, device=device)
+    return HipBertEncoder(hf_model, device=device)

@@ -88,16 +88,20 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const
         const int c4 = lane + 64 * e;
         if (c4 < nv) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(word + id * H + 4 * c4);
-            const f32x4 ty = *reinterpret_cast<const f32x4*>(type + tt * H + 4 * c4);
-            const f32x4 po = *reinterpret_cast<const f32x4*>(pos + (int64_t)p * H + 4 * c4);
-            x[e] = (w + ty) + po;     // inputs_embeds + token_type_embeddings, then + position
+            if (type) {               // BERT: inputs_embeds + token_type_embeddings, then + position
+                const f32x4 ty = *reinterpret_cast<const f32x4*>(type + tt * H + 4 * c4);
+                const f32x4 po = *reinterpret_cast<const f32x4*>(pos + (int64_t)p * H + 4 * c4);
+                x[e] = (w + ty) + po;
+            } else {
+                x[e] = w;             // ModernBERT: token embeddings only (positions enter through RoPE)
+            }
         }
     }
     layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t);
 }
 
 __global__ __launch_bounds__(256) void ln_kernel(const float* in, int T, int H, const float* g, const float* b,
-                                                 float eps, float* out, uint16_t* planes) {
+                                                 float eps, float* out, uint16_t* planes, int64_t in_stride) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* in, int T, int H, 
 #pragma unroll
     for (int e = 0; e < kMaxVec; ++e) {
         const int c4 = lane + 64 * e;
-        if (c4 < nv) x[e] = *reinterpret_cast<const f32x4*>(in + (int64_t)t * H + 4 * c4);
+        if (c4 < nv) x[e] = *reinterpret_cast<const f32x4*>(in + (int64_t)t * in_stride + 4 * c4);
     }
     layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t);
 }
@@ -146,8 +150,27 @@ __device__ __forceinline__ int crow32(int r, int h) { return (r & 3) + 8 * (r >>
 
 // ctx_planes (optional): emit the context as bf16x3 operand planes of the [batch*S, H] output-projection input
 // instead of fp32 rows.
+__device__ __forceinline__ void rope_rotate(f32x4 (&x)[8], const float* cs, const float* sn, int pos, int h) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(cs + (int64_t)pos * 32 + 8 * kb + 4 * h);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(sn + (int64_t)pos * 32 + 8 * kb + 4 * h);
+        const f32x4 lo = x[kb], hi = x[kb + 4];
+        x[kb] = lo * c + (-hi) * s;          // q * cos + rotate_half(q) * sin, two roundings per term like torch
+        x[kb + 4] = hi * c + lo * s;
+    }
+}
+
+// ROPE (ModernBERT, modeling_modernbert.py:188-219): q, k rotated by the position's angle before the scores,
+//   x'[d] = x[d] cos[d] - x[d+32] sin[d],  x'[d+32] = x[d+32] cos[d] + x[d] sin[d]   (d < 32; cos/sin tables
+//   [position][32] computed on the host exactly as transformers does).  Both halves of a pair sit in the same
+//   lane (fragment k-blocks kb and kb + 4), so the rotation is register-local.
+// window >= 0 (sliding-window layers, masking_utils.py:141-151): key k is visible to query q iff |q - k| <= window.
+template <bool ROPE>
 __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, const int64_t* mask, int S, int H,
-                                                            float scale, float* ctx, uint16_t* ctx_planes) {
+                                                            float scale, float* ctx, uint16_t* ctx_planes,
+                                                            const float* rope_cos, const float* rope_sin,
+                                                            int window) {
     const int lane = threadIdx.x;
     const int qt = blockIdx.x, head = blockIdx.y, bi = blockIdx.z;
     const int64_t ld = 3 * (int64_t)H;
@@ -160,7 +183,10 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
     {
         const float* qp = base + (int64_t)(qvalid ? qi : S - 1) * ld + 4 * h;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) Qf[kb] = *reinterpret_cast<const f32x4*>(qp + 8 * kb) * scale;
+        for (int kb = 0; kb < 8; ++kb) Qf[kb] = *reinterpret_cast<const f32x4*>(qp + 8 * kb);
+        if (ROPE) rope_rotate(Qf, rope_cos, rope_sin, qvalid ? qi : S - 1, h);
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) Qf[kb] = Qf[kb] * scale;
     }
     f32x16 o0, o1;
 #pragma unroll
@@ -175,9 +201,17 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
         const float* kp = base + (int64_t)kr * ld + H + 4 * h;
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) Kf[kb] = *reinterpret_cast<const f32x4*>(kp + 8 * kb);
+        if (ROPE) rope_rotate(Kf, rope_cos, rope_sin, kr, h);
     };
-    load_k(0);
-    for (int k0 = 0; k0 < S; k0 += 32) {
+    // key tiles that can hold a visible key for any of this tile's 32 queries (wave-uniform bounds)
+    int kbeg = 0, kend = S;
+    if (window >= 0) {
+        kbeg = qt * 32 - window; kbeg = kbeg < 0 ? 0 : (kbeg / 32) * 32;
+        const int last = qt * 32 + 31 + window;
+        if (last + 1 < kend) kend = last + 1;
+    }
+    load_k(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
         // key validity as a 32-bit mask shared by the wave
         const int kj = k0 + j;
         const bool kv = kj < S && (!mask || mask[(int64_t)bi * S + kj] != 0);
@@ -196,17 +230,20 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
         float cmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool ok = (vmask >> crow32(r, h)) & 1u;
+            bool ok = (vmask >> crow32(r, h)) & 1u;
+            if (window >= 0) { const int dk = qi - (k0 + crow32(r, h)); ok = ok && dk <= window && -dk <= window; }
             st[r] = ok ? st[r] : -INFINITY;
             cmax = fmaxf(cmax, st[r]);
         }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const float m_new = fmaxf(m, cmax);                          // finite: the tile has a valid key
-        const float corr = expf(m - m_new);                         // m = -inf -> 0
+        const float m_new = fmaxf(m, cmax);
+        // with a window a tile may hold no visible key for THIS query: nothing accumulated yet -> keep zeros
+        const bool none = m_new == -INFINITY;
+        const float corr = none ? 1.f : expf(m - m_new);            // m = -inf -> 0
         float psum = 0.f;
         float p[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = expf(st[r] - m_new); psum += p[r]; }
+        for (int r = 0; r < 16; ++r) { p[r] = none ? 0.f : expf(st[r] - m_new); psum += p[r]; }
         psum += __shfl_xor(psum, 32);
         l = l * corr + psum;
         m = m_new;
@@ -309,6 +346,36 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
     ctx_cls[(int64_t)bi * H + head * DH + lane] = l > 0.f ? o / l : 0.f;
 }
 
+// ModernBERT MLP gate (modeling_modernbert.py:89-91): u = Wi x is [T, 2I]; g = gelu(u[:, :I]) * u[:, I:]
+// (erf GELU), written as fp32 rows and, optionally, as the operand planes of the following Wo GEMM.
+__global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ u, int64_t T, int I, float* __restrict__ g,
+                                                    uint16_t* __restrict__ planes) {
+    const int nq = I >> 3;                                     // 8 outputs per thread = one k-slot
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * nq) return;
+    const int64_t row = idx / nq;
+    const int q = (int)(idx - row * nq);
+    const float* a = u + row * 2 * (int64_t)I + 8 * q;
+    f32x4 o[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + 4 * e);
+        const f32x4 gate = *reinterpret_cast<const f32x4*>(a + I + 4 * e);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[e][c] = 0.5f * x[c] * (1.f + erff(x[c] * 0.70710678118654752440f)) * gate[c];
+        *reinterpret_cast<f32x4*>(g + row * I + 8 * q + 4 * e) = o[e];
+    }
+    if (planes) {
+        uint4 Hh, Mm, Ll;
+        ac::split8(o[0], o[1], Hh, Mm, Ll);
+        uint16_t* p = planes + ac::plane_off(T, row, 8 * q);
+        const int64_t plane = T * (int64_t)I;
+        *reinterpret_cast<uint4*>(p) = Hh;
+        *reinterpret_cast<uint4*>(p + plane) = Mm;
+        *reinterpret_cast<uint4*>(p + 2 * plane) = Ll;
+    }
+}
+
 struct BertWs {
     size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
 };
@@ -405,8 +472,8 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
         if (last) {
             hipLaunchKernelGGL(attention_cls_kernel, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale, ctx);
         } else {
-            hipLaunchKernelGGL(attention_mfma_kernel, dim3((S + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv, d_mask,
-                               S, H, scale, ctx, lp ? ctxp : nullptr);
+            hipLaunchKernelGGL(attention_mfma_kernel<false>, dim3((S + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv,
+                               d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1);
         }
         AC_LAUNCH_CHECK();
         const int lblocks = (Ml + 3) / 4;
@@ -415,7 +482,7 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
         if (rc) return rc;
         // (last layer: x is overwritten with b compact rows; its old contents are no longer needed)
         hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln1_g[l], w->ln1_b[l],
-                           c.ln_eps, last ? ctx : x, lp ? xp : nullptr);
+                           c.ln_eps, last ? ctx : x, lp ? xp : nullptr, (int64_t)H);
         AC_LAUNCH_CHECK();
         float* x1 = last ? ctx : x;                    // ctx is free again after the AO projection
         rc = ac::linear_f32(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, nullptr, 1.f, stream,
@@ -426,11 +493,142 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
         if (rc) return rc;
         // the next layer's QKV GEMM reads x as planes; the last layer's output (b compact rows) stays fp32
         hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln2_g[l], w->ln2_b[l],
-                           c.ln_eps, x, lp ? xp : nullptr);
+                           c.ln_eps, x, lp ? xp : nullptr, (int64_t)H);
         AC_LAUNCH_CHECK();
     }
     // after the CLS-only last layer x holds b compact rows (sequence stride 1)
     hipLaunchKernelGGL(cls_normalize_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, b, 1, H, d_out, ldo);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ModernBERT
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct MbWs {
+    size_t x, y, xn, qkv, ctx, u, g, xnp, ctxp, gp, total;
+};
+MbWs mb_ws(const ac_modernbert_config& c, int b, int S) {
+    MbWs w;
+    const size_t T = (size_t)b * S, H = c.hidden, I = c.intermediate;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += ac::align_up(n * sizeof(float), 256); return o; };
+    auto take16 = [&](size_t n) { size_t o = off; off += ac::align_up(n * sizeof(uint16_t), 256); return o; };
+    w.x = take(T * H); w.y = take(T * H); w.xn = take(T * H);
+    w.qkv = take(T * 3 * H); w.ctx = take(T * H);
+    w.u = take(T * 2 * I); w.g = take(T * I);
+    w.xnp = take16(3 * T * H); w.ctxp = take16(3 * T * H); w.gp = take16(3 * T * I);
+    w.total = off;
+    return w;
+}
+
+int check_mb(const ac_modernbert_config* c) {
+    AC_REQUIRE(c != nullptr, AC_EINVAL, "modernbert: config is NULL");
+    AC_REQUIRE(c->hidden >= 64 && c->layers >= 1 && c->heads >= 1 && c->intermediate >= 8 && c->global_every >= 1 &&
+                   c->local_window >= 0 && c->max_pos >= 1,
+               AC_EINVAL, "modernbert: bad config");
+    AC_REQUIRE(c->hidden % 4 == 0 && c->hidden <= 64 * 4 * kMaxVec && c->intermediate % 8 == 0, AC_EUNSUPPORTED,
+               "modernbert: hidden=%d / intermediate=%d unsupported", c->hidden, c->intermediate);
+    AC_REQUIRE(c->hidden == c->heads * DH, AC_EUNSUPPORTED, "modernbert: head dim %d unsupported (only %d)",
+               c->hidden / c->heads, DH);
+    return AC_OK;
+}
+
+}  // namespace
+
+extern "C" int ac_modernbert_workspace(const ac_modernbert_config* cfg, int b, int S, size_t* bytes) {
+    int rc = check_mb(cfg);
+    if (rc) return rc;
+    AC_REQUIRE(bytes && b >= 0 && S >= 1, AC_EINVAL, "modernbert workspace: bad arguments");
+    *bytes = mb_ws(*cfg, b > 0 ? b : 1, S).total;
+    return AC_OK;
+}
+
+extern "C" int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const ac_modernbert_weights* w,
+                                        const int64_t* d_ids, const int64_t* d_mask, int b, int S, float* d_out,
+                                        int64_t ldo, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    int rc = check_mb(cfg);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (b == 0) return AC_OK;
+    AC_REQUIRE(w && d_ids && d_out && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden, AC_EINVAL,
+               "modernbert_encode_cls: bad arguments (b=%d S=%d max_pos=%d)", b, S, cfg->max_pos);
+    AC_REQUIRE(w->tok_emb && w->emb_norm_g && w->final_norm_g && w->zero_bias && w->rope_cos_global &&
+                   w->rope_sin_global && w->rope_cos_local && w->rope_sin_local && w->attn_norm_g && w->wqkv && w->wo &&
+                   w->mlp_norm_g && w->wi && w->wo2,
+               AC_EINVAL, "modernbert_encode_cls: missing weights");
+    const ac_modernbert_config& c = *cfg;
+    const MbWs ws = mb_ws(c, b, S);
+    AC_REQUIRE(d_ws && ws_bytes >= ws.total, AC_EWORKSPACE, "modernbert_encode_cls: workspace %zu < %zu", ws_bytes, ws.total);
+    char* base = (char*)d_ws;
+    float* x = (float*)(base + ws.x);      // residual stream (ping-pongs with y)
+    float* y = (float*)(base + ws.y);
+    float* xn = (float*)(base + ws.xn);    // normed input of the current GEMM
+    float* qkv = (float*)(base + ws.qkv);
+    float* ctx = (float*)(base + ws.ctx);
+    float* u = (float*)(base + ws.u);
+    float* g = (float*)(base + ws.g);
+    uint16_t* xnp = (uint16_t*)(base + ws.xnp);
+    uint16_t* ctxp = (uint16_t*)(base + ws.ctxp);
+    uint16_t* gp = (uint16_t*)(base + ws.gp);
+    const int T = b * S, H = c.hidden, I = c.intermediate;
+    const int tok_blocks = (T + 3) / 4;
+    const float* zb = w->zero_bias;
+    auto opt = [&](const float* const* arr, int l) -> const float* { return (arr && arr[l]) ? arr[l] : zb; };
+    const bool wplanes = w->wqkv3 && w->wo3 && w->wi3 && w->wo23;
+    const bool pl = wplanes && ac::linear_takes_planes(T, H, H) && ac::linear_takes_planes(T, H, I) && (H % 8) == 0;
+
+    // embeddings -> LayerNorm: this IS the input of layer 0's attention (attn_norm = Identity there)
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, d_ids, (const int64_t*)nullptr, T, S, H,
+                       w->tok_emb, (const float*)nullptr, (const float*)nullptr, w->emb_norm_g,
+                       w->emb_norm_b ? w->emb_norm_b : zb, c.norm_eps, x, pl ? xnp : nullptr);
+    AC_LAUNCH_CHECK();
+    const float scale = 1.0f / sqrtf((float)DH);
+    for (int l = 0; l < c.layers; ++l) {
+        const float* a_in = x;             // attention input rows (fp32) -- x itself for layer 0
+        if (l > 0) {
+            AC_REQUIRE(w->attn_norm_g[l] != nullptr, AC_EINVAL, "modernbert: attn_norm weight of layer %d is NULL", l);
+            hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, x, T, H, w->attn_norm_g[l],
+                               opt(w->attn_norm_b, l), c.norm_eps, xn, pl ? xnp : nullptr, (int64_t)H);
+            AC_LAUNCH_CHECK();
+            a_in = xn;
+        }
+        rc = ac::linear_f32(a_in, H, w->wqkv[l], H, opt(w->wqkv_b, l), nullptr, 0, qkv, 3 * H, T, 3 * H, H, 0, nullptr,
+                            1.f, stream, 0.f, 0, wplanes ? w->wqkv3[l] : nullptr, pl ? xnp : nullptr);
+        if (rc) return rc;
+        const bool global = (l % c.global_every) == 0;
+        hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((S + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv, d_mask,
+                           S, H, scale, ctx, pl ? ctxp : nullptr, global ? w->rope_cos_global : w->rope_cos_local,
+                           global ? w->rope_sin_global : w->rope_sin_local, global ? -1 : c.local_window);
+        AC_LAUNCH_CHECK();
+        // y = x + ctx Wo^T
+        rc = ac::linear_f32(ctx, H, w->wo[l], H, opt(w->wo_b, l), x, H, y, H, T, H, H, 0, nullptr, 1.f, stream, 0.f, 0,
+                            wplanes ? w->wo3[l] : nullptr, pl ? ctxp : nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, y, T, H, w->mlp_norm_g[l],
+                           opt(w->mlp_norm_b, l), c.norm_eps, xn, pl ? xnp : nullptr, (int64_t)H);
+        AC_LAUNCH_CHECK();
+        rc = ac::linear_f32(xn, H, w->wi[l], H, opt(w->wi_b, l), nullptr, 0, u, 2 * I, T, 2 * I, H, 0, nullptr, 1.f,
+                            stream, 0.f, 0, wplanes ? w->wi3[l] : nullptr, pl ? xnp : nullptr);
+        if (rc) return rc;
+        {
+            const int64_t units = (int64_t)T * (I / 8);
+            hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, u, (int64_t)T, I, g,
+                               pl ? gp : nullptr);
+            AC_LAUNCH_CHECK();
+        }
+        // x = y + g Wo2^T
+        rc = ac::linear_f32(g, I, w->wo2[l], I, opt(w->wo2_b, l), y, H, x, H, T, H, I, 0, nullptr, 1.f, stream, 0.f, 0,
+                            wplanes ? w->wo23[l] : nullptr, pl ? gp : nullptr);
+        if (rc) return rc;
+    }
+    // final LayerNorm on the CLS rows only (stride S*H), compact into xn, then L2-normalise
+    hipLaunchKernelGGL(ln_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, b, H, w->final_norm_g,
+                       w->final_norm_b ? w->final_norm_b : zb, c.norm_eps, xn, (uint16_t*)nullptr, (int64_t)S * H);
+    AC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cls_normalize_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, xn, b, 1, H, d_out, ldo);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

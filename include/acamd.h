@@ -387,6 +387,60 @@ int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weights* w,
                        float* d_out_unit_cls, int64_t ldo,
                        void* d_ws, size_t ws_bytes, ac_stream_t stream);
 
+/* ---- ModernBERT encoder ("answerdotai/ModernBERT-base", the reference's other default) ----
+ * transformers modeling_modernbert.py: token embeddings -> LayerNorm; `layers` pre-norm blocks
+ *   x += Wo attn(rope(Wqkv norm(x)))        (layer 0 has no attn norm; layer l attends globally when
+ *                                            l % global_every == 0, else within |q - k| <= local_window)
+ *   x += Wo2 (gelu(u[:, :I]) * u[:, I:]),  u = Wi norm(x)                       (GeGLU, erf GELU)
+ * then final LayerNorm; classifier.py:1272-1275 takes [:, 0, :] and L2-normalises.  Head dim 64.
+ * Biases are optional everywhere (NULL = absent, ModernBERT's default). */
+typedef struct {
+    int hidden, layers, heads, intermediate;
+    int vocab, max_pos;
+    int global_every;     /* global_attn_every_n_layers (3) */
+    int local_window;     /* config.sliding_window = local_attention / 2 (64): |q - k| <= local_window */
+    float norm_eps;       /* 1e-5 */
+} ac_modernbert_config;
+
+typedef struct {
+    const float* tok_emb;            /* [vocab, H] */
+    const float* emb_norm_g;         /* [H] */
+    const float* emb_norm_b;         /* [H] or NULL */
+    const float* final_norm_g;
+    const float* final_norm_b;
+    /* RoPE tables [max_pos, 32] fp32: cos / sin of position * inv_freq, computed by the host exactly as
+     * ModernBertRotaryEmbedding does (theta 160000 for global layers, 10000 for local ones) */
+    const float* rope_cos_global; const float* rope_sin_global;
+    const float* rope_cos_local;  const float* rope_sin_local;
+    /* per-layer host arrays of device pointers (entries may be NULL where noted) */
+    const float* const* attn_norm_g; /* [H]; NULL for layer 0 (Identity) */
+    const float* const* attn_norm_b; /* NULL array or NULL entries = no bias */
+    const float* const* wqkv;        /* [3H, H] rows q | k | v */
+    const float* const* wqkv_b;
+    const float* const* wo;          /* [H, H] */
+    const float* const* wo_b;
+    const float* const* mlp_norm_g;
+    const float* const* mlp_norm_b;
+    const float* const* wi;          /* [2I, H] rows input | gate */
+    const float* const* wi_b;
+    const float* const* wo2;         /* [H, I] */
+    const float* const* wo2_b;
+    const float* zero_bias;          /* max(3H, 2I) zeros: stands in for absent biases */
+    /* optional bf16x3 planes of the four weight matrices (ac_split_bf16x3), all or none */
+    const uint16_t* const* wqkv3;
+    const uint16_t* const* wo3;
+    const uint16_t* const* wi3;
+    const uint16_t* const* wo23;
+} ac_modernbert_weights;
+
+int ac_modernbert_workspace(const ac_modernbert_config* cfg, int b, int S, size_t* bytes);
+
+/* ids / mask int64 [b, S] (mask NULL = all ones) -> unit-norm CLS embeddings d_out_unit_cls [b, ldo]. */
+int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const ac_modernbert_weights* w,
+                             const int64_t* d_ids, const int64_t* d_mask, int b, int S,
+                             float* d_out_unit_cls, int64_t ldo,
+                             void* d_ws, size_t ws_bytes, ac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

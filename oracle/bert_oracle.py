@@ -44,3 +44,33 @@ def encode_cls(model, ids, types, mask):
     out = model(input_ids=ids, token_type_ids=types, attention_mask=mask)
     emb = out.last_hidden_state[:, 0, :]            # classifier.py:1272
     return F.normalize(emb, p=2, dim=1)             # classifier.py:1275
+
+
+def make_modernbert(hidden=768, layers=22, heads=12, intermediate=1152, vocab=50368, max_pos=8192, local_attention=128,
+                    global_every=3, seed=0, init_scale=1.0):
+    """transformers ModernBertModel (modeling_modernbert.py), fp32 / eval / eager attention, random init.
+    init_scale > 1 widens the Linear weights so the attention logits are not all ~0 (a uniform softmax would
+    hide RoPE / window mistakes)."""
+    from transformers import ModernBertConfig, ModernBertModel
+    cfg = ModernBertConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=intermediate,
+                           num_hidden_layers=layers, num_attention_heads=heads, max_position_embeddings=max_pos,
+                           local_attention=local_attention, global_attn_every_n_layers=global_every,
+                           pad_token_id=0, bos_token_id=1, eos_token_id=2, cls_token_id=1, sep_token_id=2)
+    try:
+        cfg._attn_implementation = "eager"
+    except Exception:
+        pass
+    torch.manual_seed(seed)
+    model = ModernBertModel(cfg).eval()
+    if init_scale != 1.0:
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if name.endswith("Wqkv.weight") or name.endswith("Wi.weight") or name.endswith("Wo.weight"):
+                    p.mul_(init_scale)
+    return model
+
+
+@torch.no_grad()
+def encode_cls_modernbert(model, ids, mask):
+    out = model(input_ids=ids, attention_mask=mask)
+    return F.normalize(out.last_hidden_state[:, 0, :], p=2, dim=1)

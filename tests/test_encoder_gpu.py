@@ -61,3 +61,31 @@ def test_distilbert_encoder_matches_transformers(cuda_dev):
     enc = HipBertEncoder(model, device=cuda_dev)
     got = enc.encode_cls(ids, types, mask).cpu()          # token_type_ids ignored for DistilBERT
     assert (got - want).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("hidden,layers,heads,inter,local,b,S", [
+    (128, 4, 2, 192, 16, 7, 40),          # T = 280: pre-split operand planes; windows of +-8 inside S = 40
+    (128, 4, 2, 192, 16, 2, 20),          # T = 40: small-M GEMM path, fp32 activations
+    (768, 5, 12, 1152, 128, 2, 200),      # ModernBERT-base width; +-64 windows cut inside S = 200; 7 key tiles
+    (768, 2, 12, 1152, 128, 3, 33),       # one key past a tile boundary
+])
+def test_modernbert_encoder_matches_transformers(hidden, layers, heads, inter, local, b, S, cuda_dev):
+    """N4: ModernBERT (RoPE, alternating global / sliding-window attention, pre-norm, GeGLU, bias-free) against
+    transformers ModernBertModel fp32 eager on CPU; SURVEY 8c bar: 1e-4 max-abs on the unit-norm CLS vector."""
+    from adaptive_classifier.encoder import make_encoder, HipModernBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_modernbert(hidden, layers, heads, inter, vocab=2000, max_pos=512, local_attention=local,
+                                        seed=3, init_scale=4.0)
+    ids, _, mask = bert_oracle.synthetic_batch(b, S, vocab=2000, seed=77, ragged=True)
+    ids[:, 0] = 1
+    want = bert_oracle.encode_cls_modernbert(model, ids, mask)
+    enc = make_encoder(model, device=cuda_dev)
+    assert isinstance(enc, HipModernBertEncoder)
+    got = enc.encode_cls(ids, None, mask).cpu()
+    err = (got - want).abs().max().item()
+    assert err < 1e-4, err
+    assert abs(got.norm(dim=1) - 1).max().item() < 1e-5
+    # the sliding window and RoPE matter in this configuration: a global-only / position-free variant is far off
+    if S > 2 * (local // 2) + 1:
+        model.config.sliding_window = 10 ** 6
+        assert (bert_oracle.encode_cls_modernbert(model, ids, mask) - want).abs().max().item() > 1e-3
