@@ -50,7 +50,7 @@ class ac_modernbert_weights(ctypes.Structure):
         "tok_emb", "emb_norm_g", "emb_norm_b", "final_norm_g", "final_norm_b",
         "rope_cos_global", "rope_sin_global", "rope_cos_local", "rope_sin_local",
         "attn_norm_g", "attn_norm_b", "wqkv", "wqkv_b", "wo", "wo_b", "mlp_norm_g", "mlp_norm_b",
-        "wi", "wi_b", "wo2", "wo2_b", "zero_bias", "wqkv3", "wo3", "wi3", "wo23")]
+        "wi", "wi_b", "wo2", "wo2_b", "zero_bias", "wqkv3", "wo3", "wi3", "wo23")] + [("wi_interleaved32", c_int)]
 
 
 class ac_bert_weights(ctypes.Structure):

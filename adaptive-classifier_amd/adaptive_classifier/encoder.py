@@ -224,11 +224,22 @@ class HipModernBertEncoder:
             setattr(w, f"rope_cos_{kind}", own(freqs.cos()).data_ptr())
             setattr(w, f"rope_sin_{kind}", own(freqs.sin()).data_ptr())
 
+        # Wi rows (and bias) interleaved in blocks of 32 inputs + their 32 gates: the GeGLU then fuses into the
+        # GEMM epilogue (EPI_GEGLU32), because a wave's two 32-column tiles hold input_j / gate_j in the same lane
+        inter = I % 32 == 0
+        if inter:
+            t = torch.arange(I // 32)[:, None] * 32 + torch.arange(32)[None, :]            # [I/32, 32] input rows
+            perm = torch.cat([t, t + I], dim=1).reshape(-1)                               # in-block, then gate-block
+        w.wi_interleaved32 = 1 if inter else 0
+
         def per_layer(field, name, optional=False):
             ts = []
             for l in range(L):
                 k = f"layers.{l}.{name}"
-                ts.append(own(sd[k]) if k in sd else None)
+                v = sd.get(k)
+                if v is not None and inter and name in ("mlp.Wi.weight", "mlp.Wi.bias"):
+                    v = v[perm]
+                ts.append(own(v) if v is not None else None)
             if all(t is None for t in ts):
                 if not optional:
                     raise nv.NativeError(f"HipModernBertEncoder: {name} missing from the checkpoint")

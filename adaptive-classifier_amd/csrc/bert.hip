@@ -348,19 +348,23 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
 
 // ModernBERT MLP gate (modeling_modernbert.py:89-91): u = Wi x is [T, 2I]; g = gelu(u[:, :I]) * u[:, I:]
 // (erf GELU), written as fp32 rows and, optionally, as the operand planes of the following Wo GEMM.
+// interleaved32: the columns of u come in blocks of 64 = 32 inputs then their 32 gates (the weight rows were
+// permuted at load for the fused GEMM epilogue EPI_GEGLU32); otherwise all inputs then all gates.
 __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ u, int64_t T, int I, float* __restrict__ g,
-                                                    uint16_t* __restrict__ planes) {
+                                                    uint16_t* __restrict__ planes, int interleaved32) {
     const int nq = I >> 3;                                     // 8 outputs per thread = one k-slot
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= T * nq) return;
     const int64_t row = idx / nq;
     const int q = (int)(idx - row * nq);
-    const float* a = u + row * 2 * (int64_t)I + 8 * q;
+    const int c = 8 * q;                                       // first output column
+    const float* a = u + row * 2 * (int64_t)I + (interleaved32 ? (c >> 5) * 64 + (c & 31) : c);
+    const int goff = interleaved32 ? 32 : I;                   // distance from an input to its gate
     f32x4 o[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(a + 4 * e);
-        const f32x4 gate = *reinterpret_cast<const f32x4*>(a + I + 4 * e);
+        const f32x4 gate = *reinterpret_cast<const f32x4*>(a + goff + 4 * e);
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[e][c] = 0.5f * x[c] * (1.f + erff(x[c] * 0.70710678118654752440f)) * gate[c];
         *reinterpret_cast<f32x4*>(g + row * I + 8 * q + 4 * e) = o[e];
@@ -610,13 +614,18 @@ extern "C" int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const a
         hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, y, T, H, w->mlp_norm_g[l],
                            opt(w->mlp_norm_b, l), c.norm_eps, xn, pl ? xnp : nullptr, (int64_t)H);
         AC_LAUNCH_CHECK();
-        rc = ac::linear_f32(xn, H, w->wi[l], H, opt(w->wi_b, l), nullptr, 0, u, 2 * I, T, 2 * I, H, 0, nullptr, 1.f,
-                            stream, 0.f, 0, wplanes ? w->wi3[l] : nullptr, pl ? xnp : nullptr);
-        if (rc) return rc;
-        {
+        if (pl && w->wi_interleaved32) {
+            // GeGLU fused into the Wi GEMM's epilogue, result straight into the operand planes of the Wo2 GEMM
+            rc = ac::linear_f32(xn, H, w->wi[l], H, opt(w->wi_b, l), nullptr, 0, nullptr, I, T, 2 * I, H, 3, nullptr, 1.f,
+                                stream, 0.f, 0, w->wi3[l], xnp, gp);
+            if (rc) return rc;
+        } else {
+            rc = ac::linear_f32(xn, H, w->wi[l], H, opt(w->wi_b, l), nullptr, 0, u, 2 * I, T, 2 * I, H, 0, nullptr, 1.f,
+                                stream, 0.f, 0, wplanes ? w->wi3[l] : nullptr, pl ? xnp : nullptr);
+            if (rc) return rc;
             const int64_t units = (int64_t)T * (I / 8);
             hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, u, (int64_t)T, I, g,
-                               pl ? gp : nullptr);
+                               pl ? gp : nullptr, w->wi_interleaved32);
             AC_LAUNCH_CHECK();
         }
         // x = y + g Wo2^T

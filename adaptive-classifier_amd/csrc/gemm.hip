@@ -28,7 +28,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_GEGLU32 = 3 };
 
 struct Epilogue {
     const float* bias;      // [N] or null
@@ -65,7 +65,10 @@ __device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, in
 }
 
 // compile-time epilogue classes for the hot encoder/head shapes; EPI_GENERIC keeps the runtime flags
-enum { EPI_GENERIC = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RES = 3, EPI_BIAS_RELU = 4 };
+enum { EPI_GENERIC = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RES = 3, EPI_BIAS_RELU = 4,
+       // GeGLU over 32-column blocks: output columns [64t, 64t+32) are the inputs and [64t+32, 64t+64) the gates of
+       // result columns [32t, 32t+32) -- a wave's two 32x32 tiles hold input_j and gate_j in the same lane/register
+       EPI_GEGLU32 = 5 };
 
 template <int EPI>
 __device__ __forceinline__ float fast_epilogue(float acc, float bias, float res) {
@@ -136,18 +139,29 @@ template <int EPI, int TM>
 __device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][2], uint16_t* __restrict__ Cp, int M, int N,
                                                   int m0, int n0, int wm, int wn, int lane, const Epilogue& epi,
                                                   float* scratch /* this wave's kTrFloats floats of LDS */) {
-    const int64_t plane = (int64_t)M * N;
+    constexpr bool GLU = EPI == EPI_GEGLU32;
+    const int NO = GLU ? N / 2 : N;                                  // result columns
+    const int64_t plane = (int64_t)M * NO;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int c0 = n0 + wn * 64 + ni * 32;
-            const int col = c0 + (lane & 31);
+        for (int ni = 0; ni < (GLU ? 1 : 2); ++ni) {
+            const int c0 = GLU ? n0 / 2 + wn * 32 : n0 + wn * 64 + ni * 32;      // first result column of the tile
+            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);                  // GEMM column of acc[mi][ni]
             const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
             const float bias = col < N ? epi.bias[col] : 0.f;
+            const float bias_g = (GLU && col + 32 < N) ? epi.bias[col + 32] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                scratch[acc_row32(r, lane) * kTrLd + (lane & 31)] = fast_epilogue<EPI>(acc[mi][ni][r], bias, 0.f);
+            for (int r = 0; r < 16; ++r) {
+                float v;
+                if (GLU) {
+                    const float x = acc[mi][0][r] + bias;
+                    v = 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)) * (acc[mi][1][r] + bias_g);
+                } else {
+                    v = fast_epilogue<EPI>(acc[mi][ni][r], bias, 0.f);
+                }
+                scratch[acc_row32(r, lane) * kTrLd + (lane & 31)] = v;
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -157,7 +171,7 @@ __device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][2], uint16_t
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(scratch + rr * kTrLd + 8 * q + 4);
                 const int64_t row = rbase + rr;
                 const int cq = c0 + 8 * q;
-                if (row < M && cq < N) {
+                if (row < M && cq < NO) {
                     uint4 H, Mi, L;
                     ac::split8(v0, v1, H, Mi, L);
                     uint16_t* dst = Cp + ac::plane_off(M, row, cq);
@@ -721,6 +735,7 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
     if (M <= 0 || N <= 0) return AC_OK;
     const bool aligned = ((lda & 3) == 0) && ((ldb & 3) == 0) && ((((uintptr_t)A) & 15) == 0) &&
                          ((((uintptr_t)B) & 15) == 0);
+    AC_REQUIRE(epi.act != ACT_GEGLU32 || (Cp && Ap), AC_EUNSUPPORTED, "gemm: fused GeGLU needs the pre-split kernel");
     AC_REQUIRE((!Ap && !Cp) || (a_kmaj && b_kmaj && aligned && ac::linear_takes_planes(M, N, K) && Bp),
                AC_EUNSUPPORTED, "gemm: operand / result planes given for a shape that does not take the pre-split kernel");
     if (a_kmaj && b_kmaj && aligned && M <= 64 && K >= 8 && (K % 4) == 0 && N >= 16) {
@@ -747,6 +762,9 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         else if (plain && !epi.residual && epi.act == ACT_GELU) cls = EPI_BIAS_GELU;
         else if (plain && !epi.residual && epi.act == ACT_RELU) cls = EPI_BIAS_RELU;
         else if (plain && epi.residual && epi.act == ACT_NONE) cls = EPI_BIAS_RES;
+        else if (plain && !epi.residual && epi.act == ACT_GEGLU32) cls = EPI_GEGLU32;
+        AC_REQUIRE(epi.act != ACT_GEGLU32 || (cls == EPI_GEGLU32 && Cp && (N % 64) == 0), AC_EUNSUPPORTED,
+                   "gemm: the fused GeGLU epilogue needs planes output, a bias vector and N %% 64 == 0");
         const dim3 grid((unsigned)nblk), block(kTileThreads);
         const bool split = ac::gemm_arith() == AC_GEMM_BF16X3;
         const bool planes = split && Bp != nullptr;      // (K % 32 == 0 here, so K % SBK == 0)
@@ -764,10 +782,13 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
     } while (0)
         if (Cp) {
             // result emitted as planes for the next GEMM: both operands pre-split, bias (+GELU) epilogues only
-            AC_REQUIRE(planes && Ap && (cls == EPI_BIAS || cls == EPI_BIAS_GELU) && (N % 8) == 0, AC_EUNSUPPORTED,
+            AC_REQUIRE(planes && Ap && (cls == EPI_BIAS || cls == EPI_BIAS_GELU || cls == EPI_GEGLU32) && (N % 8) == 0, AC_EUNSUPPORTED,
                        "gemm: planes output needs pre-split operands, N %% 8 == 0 and a bias / bias+gelu epilogue");
             float* Cq = reinterpret_cast<float*>(Cp);
-            if (cls == EPI_BIAS_GELU) {
+            if (cls == EPI_GEGLU32) {
+                if (tm == 2) hipLaunchKernelGGL((gemm_planes_nt<EPI_GEGLU32, 2, true, true>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, Cq, ldc, M, N, K, epi);
+                else hipLaunchKernelGGL((gemm_planes_nt<EPI_GEGLU32, 1, true, true>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, Cq, ldc, M, N, K, epi);
+            } else if (cls == EPI_BIAS_GELU) {
                 if (tm == 2) hipLaunchKernelGGL((gemm_planes_nt<EPI_BIAS_GELU, 2, true, true>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, Cq, ldc, M, N, K, epi);
                 else hipLaunchKernelGGL((gemm_planes_nt<EPI_BIAS_GELU, 1, true, true>), grid, block, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, Cq, ldc, M, N, K, epi);
             } else {
@@ -894,9 +915,9 @@ extern "C" int ac_linear_bf16x3(const float* d_A, int64_t lda, const uint16_t* d
                                 const float* d_residual, int64_t ldr, float* d_C, int64_t ldc,
                                 uint16_t* d_C_planes, int M, int N, int K, int act, ac_stream_t stream) {
     AC_REQUIRE(d_A && d_W && (d_C || d_C_planes), AC_EINVAL, "linear: null pointer");
-    AC_REQUIRE(M >= 0 && N >= 0 && K >= 1 && lda >= K && ldw >= K && ldc >= N, AC_EINVAL,
+    AC_REQUIRE(M >= 0 && N >= 0 && K >= 1 && lda >= K && ldw >= K && (d_C_planes || ldc >= N), AC_EINVAL,
                "linear: bad shape M=%d N=%d K=%d", M, N, K);
-    AC_REQUIRE(act >= 0 && act <= 2, AC_EINVAL, "linear: bad activation %d", act);
+    AC_REQUIRE(act >= 0 && act <= 3 && (act != 3 || d_C_planes), AC_EINVAL, "linear: bad activation %d", act);
     AC_REQUIRE(!d_A_planes || d_W_planes, AC_EINVAL, "linear: A planes need W planes");
     return ac::linear_f32(d_A, lda, d_W, ldw, d_bias, d_residual, ldr, d_C, ldc, M, N, K, act, nullptr, 1.f,
                           (hipStream_t)stream, 0.f, 0, d_W_planes,

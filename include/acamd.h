@@ -179,7 +179,10 @@ int ac_split_bf16x3(const float* d_X, int64_t ldx, int64_t rows, int K,
  * d_W_planes is ac_split_bf16x3 of W[N, K]; d_A_planes of A[M, K].
  * d_C_planes (optional): emit the result as the operand planes of a following GEMM (layout of
  * ac_split_bf16x3 of C[M, N]) INSTEAD of d_C; needs both operand planes, the pre-split path (else
- * AC_EUNSUPPORTED), N % 8 == 0, no residual. */
+ * AC_EUNSUPPORTED), N % 8 == 0, no residual.
+ * act: 0 none, 1 relu, 2 erf-gelu, 3 = GeGLU over 32-column blocks (planes output only): GEMM columns
+ * [64t, 64t+32) are inputs, [64t+32, 64t+64) their gates; the result has N / 2 columns,
+ * out[:, 32t + j] = gelu(in_j) * gate_j. */
 int ac_linear_bf16x3(const float* d_A, int64_t lda, const uint16_t* d_A_planes,
                      const float* d_W, int64_t ldw, const uint16_t* d_W_planes,
                      const float* d_bias, const float* d_residual, int64_t ldr,
@@ -421,7 +424,9 @@ typedef struct {
     const float* const* wo_b;
     const float* const* mlp_norm_g;
     const float* const* mlp_norm_b;
-    const float* const* wi;          /* [2I, H] rows input | gate */
+    const float* const* wi;          /* [2I, H] rows input | gate -- or, when wi_interleaved32 != 0, permuted in
+                                      * blocks of 64 = 32 input rows then their 32 gate rows (I % 32 == 0), which
+                                      * lets the GeGLU fuse into the GEMM epilogue; wi_b permuted alike */
     const float* const* wi_b;
     const float* const* wo2;         /* [H, I] */
     const float* const* wo2_b;
@@ -431,6 +436,7 @@ typedef struct {
     const uint16_t* const* wo3;
     const uint16_t* const* wi3;
     const uint16_t* const* wo23;
+    int wi_interleaved32;
 } ac_modernbert_weights;
 
 int ac_modernbert_workspace(const ac_modernbert_config* cfg, int b, int S, size_t* bytes);

@@ -175,3 +175,33 @@ def test_planes_output_equals_split_of_fp32_output(M, N, K, act, cuda_dev, arith
     rc = lib.ac_linear_bf16x3(nv.ptr(Ad), K, nv.ptr(Ap), nv.ptr(Wd), K, nv.ptr(Wp), nv.ptr(bd), None, 0,
                               None, N, nv.ptr(Cp), 16, N, K, act, st)
     assert rc != 0
+
+
+def test_fused_geglu_epilogue(cuda_dev, arith):
+    """act = 3: GeGLU over 32-column blocks fused into the planes-output epilogue equals gelu(in) * gate computed
+    from the fp32 GEMM output of the same kernel, split into planes."""
+    from adaptive_classifier import _native as nv
+    arith(BF16X3)
+    rng = np.random.default_rng(11)
+    M, I, K = 520, 192, 128
+    N = 2 * I
+    Ad = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(cuda_dev)
+    Wd = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(cuda_dev)
+    bd = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(cuda_dev)
+    Ap, Wp = _planes(nv, cuda_dev, Ad), _planes(nv, cuda_dev, Wd)
+    U = torch.empty((M, N), device=cuda_dev)
+    Gp = torch.zeros(3 * M * I, dtype=torch.int16, device=cuda_dev)
+    lib, st = nv.lib(), nv.stream_ptr(cuda_dev)
+    nv.check(lib.ac_linear_bf16x3(nv.ptr(Ad), K, nv.ptr(Ap), nv.ptr(Wd), K, nv.ptr(Wp), nv.ptr(bd), None, 0,
+                                  nv.ptr(U), N, None, M, N, K, 0, st), "fp32 out")
+    nv.check(lib.ac_linear_bf16x3(nv.ptr(Ad), K, nv.ptr(Ap), nv.ptr(Wd), K, nv.ptr(Wp), nv.ptr(bd), None, 0,
+                                  None, I, nv.ptr(Gp), M, N, K, 3, st), "geglu planes out")
+    u = U.view(M, I // 32, 2, 32)
+    x, gate = u[:, :, 0, :], u[:, :, 1, :]
+    want = (0.5 * x * (1 + torch.erf(x * 0.70710678118654752440)) * gate).reshape(M, I).contiguous()
+    got = Gp.cpu().numpy().view(np.uint16).reshape(3, I // 8, M, 8).transpose(0, 2, 1, 3).reshape(3, M, I)
+    got = (got.astype(np.uint32) << 16).view(np.float32).astype(np.float64).sum(0)
+    assert np.abs(got - want.cpu().numpy().astype(np.float64)).max() < 2e-6       # erff vs torch.erf, 1-2 ulp
+    # without planes output the fused activation is refused
+    assert lib.ac_linear_bf16x3(nv.ptr(Ad), K, nv.ptr(Ap), nv.ptr(Wd), K, nv.ptr(Wp), nv.ptr(bd), None, 0,
+                                nv.ptr(U), N, None, M, N, K, 3, st) != 0
