@@ -40,6 +40,11 @@ class ac_bert_config(ctypes.Structure):
                 ("vocab", c_int), ("max_pos", c_int), ("type_vocab", c_int), ("ln_eps", c_float)]
 
 
+class ac_prune_job(ctypes.Structure):
+    _fields_ = [("rows", c_void_p), ("ld", c_int64), ("n_old", c_int), ("n_new", c_int), ("cap", c_int),
+                ("reserved", c_int), ("sum", c_void_p), ("alive", c_void_p), ("dist", c_void_p), ("dropped", c_void_p)]
+
+
 class ac_modernbert_config(ctypes.Structure):
     _fields_ = [("hidden", c_int), ("layers", c_int), ("heads", c_int), ("intermediate", c_int), ("vocab", c_int),
                 ("max_pos", c_int), ("global_every", c_int), ("local_window", c_int), ("norm_eps", c_float)]
@@ -112,6 +117,7 @@ _SIGNATURES = {
     "ac_ewc_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                   c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p,
                                   c_void_p, c_void_p]),
+    "ac_memory_add_prune": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ac_blend_topk": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "ac_modernbert_workspace": (c_int, [ctypes.POINTER(ac_modernbert_config), c_int, c_int, ctypes.POINTER(c_size_t)]),

@@ -130,8 +130,9 @@ class AdaptiveClassifier:
                 self.label_to_id[label] = idx
                 self.id_to_label[idx] = label
         is_adding_new_classes = len(_new_classes) > 0
-        for text, embedding, label in zip(texts, embeddings, labels):
-            self.memory.add_example(Example(text, label, embedding), label)
+        # memory update for the whole call: sequential add_example semantics, the per-class prune loop on the device
+        self.memory.add_examples_batch([Example(t, l, e) for t, e, l in zip(texts, embeddings, labels)], list(labels))
+        for label in labels:
             self.training_history[label] = self.training_history.get(label, 0) + 1
         if is_adding_new_classes and _has_existing:
             old_head = copy.deepcopy(self.adaptive_head) if self.adaptive_head is not None else None

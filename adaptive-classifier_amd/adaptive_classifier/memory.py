@@ -17,6 +17,7 @@ Deliberate differences from the reference (DESIGN.md "quirks"):
 Beyond the reference: `load_rows()` puts an arbitrary [N, D] device matrix with an
 int32 row->class map behind the same search API (N >> #classes, BASELINE configs 1-2, 4).
 """
+import ctypes
 import logging
 import threading
 from collections import defaultdict
@@ -107,6 +108,144 @@ class PrototypeMemory:
                 self.just_rebuilt = True
             else:
                 self.just_rebuilt = False
+
+    def add_examples_batch(self, examples: List[Example], labels: List[str]):
+        """`add_example` for every (example, label) in order, with the same final state, but with the
+        per-class add -> mean -> drop-farthest loop of memory.py:41-83 / :196-217 run ON THE DEVICE for all the
+        examples a class receives (`ac_memory_add_prune`, one launch per class that overflows its cap) and the
+        Python lists / class matrices / prototypes updated once per class instead of once per example.
+        Falls back to `add_example` per example when there is no GPU or the class is beyond the kernel's
+        on-chip working set."""
+        if len(examples) != len(labels):
+            raise ValueError("Mismatched example and label lists")
+        for ex in examples:                               # same validation, before anything is mutated
+            if ex.embedding is None:
+                raise ValueError("Example must have an embedding")
+            if ex.embedding.size(-1) != self.embedding_dim:
+                raise ValueError(f"Example embedding dimension {ex.embedding.size(-1)} "
+                                 f"does not match memory dimension {self.embedding_dim}")
+        with self._lock:
+            cap = int(self.config.max_examples_per_class)
+            D = self.embedding_dim
+            dev = self.index.device if hasattr(self.index, "device") else None
+            groups: Dict[str, List[Example]] = {}
+            jobs = []                                      # classes that overflow their cap in this call
+            for ex, label in zip(examples, labels):
+                if ex.embedding.is_cuda:
+                    ex.embedding = ex.embedding.detach().cpu()
+                groups.setdefault(label, []).append(ex)
+            for label, new in groups.items():
+                lst = self.examples[label]
+                n0, k = len(lst), len(new)
+                on_chip = n0 + k <= 8192 and D <= 4096 and (n0 + k) * 9 + D * 12 + 16 <= 150 * 1024
+                if n0 + k > cap and (dev is None or dev.type != "cuda" or n0 > cap or not on_chip):
+                    for ex in new:                        # per-example host logic (counters handled below)
+                        self._add_one_no_counters(ex, label)
+                    continue
+                fresh = torch.stack([e.embedding.detach().to(torch.float32) for e in new])
+                ent = self._mats.get(label)
+                if ent is None or ent[1] != n0:            # (re)build the mirror of the stored rows
+                    rows0 = max(n0 + k + 1, 64)
+                    mat = torch.empty((rows0, D), dtype=torch.float32)
+                    if n0:
+                        mat[:n0] = torch.stack([e.embedding for e in lst])
+                    ent = [mat, n0]
+                cached = self._sums.get(label)
+                total = cached[0] if cached is not None and cached[1] == n0 else ent[0][:n0].double().sum(0)
+                if n0 + k <= cap:
+                    # nothing to prune: O(k) appends (list, class matrix with geometric growth, fp64 sum)
+                    if ent[0].shape[0] < n0 + k:
+                        mat = torch.empty((max(n0 + k, 2 * ent[0].shape[0]), D), dtype=torch.float32)
+                        mat[:n0] = ent[0][:n0]
+                        ent = [mat, n0]
+                    ent[0][n0:n0 + k] = fresh
+                    ent[1] = n0 + k
+                    lst.extend(new)
+                    self._mats[label] = ent
+                    self._sums[label] = (total + fresh.double().sum(0), n0 + k)
+                    self._update_prototype(label)
+                    continue
+                rows = torch.cat([ent[0][:n0], fresh])
+                jobs.append((label, lst, new, ent, rows, total, n0, k))
+            if jobs:
+                self._run_prune_jobs(jobs, cap, D, dev)
+            # the counter / lazy-rebuild state machine of memory.py:70-81, once per example
+            rebuild = False
+            for _ in examples:
+                if not getattr(self, "just_rebuilt", False):
+                    self.updates_since_rebuild += 1
+                if self.updates_since_rebuild >= self.config.prototype_update_frequency:
+                    self.updates_since_rebuild = 0
+                    rebuild = True
+                    self.just_rebuilt = True
+                else:
+                    self.just_rebuilt = False
+            if rebuild:
+                pending = self.updates_since_rebuild       # _rebuild_index zeroes the counter
+                self._rebuild_index()
+                self.updates_since_rebuild = pending
+
+    def _run_prune_jobs(self, jobs, cap, D, dev):
+        """One `ac_memory_add_prune` launch for all overflowing classes of a call, then the host-side update of
+        each class (list in ascending-distance order, class matrix, fp64 sum, prototype)."""
+        nj = len(jobs)
+        ntot = sum(j[6] + j[7] for j in jobs)
+        d_rows = torch.cat([j[4] for j in jobs]).to(dev)                       # all classes' rows, one H2D
+        d_sum = torch.stack([j[5] for j in jobs]).to(dev).contiguous()         # [nj, D] fp64
+        d_alive = torch.empty(ntot, dtype=torch.uint8, device=dev)
+        d_dist = torch.empty(ntot, dtype=torch.float64, device=dev)
+        d_drop = torch.empty(sum(j[7] for j in jobs), dtype=torch.int32, device=dev)
+        arr = (nv.ac_prune_job * nj)()
+        off = doff = 0
+        for i, (_, _, _, _, rows, _, n0, k) in enumerate(jobs):
+            arr[i].rows = d_rows.data_ptr() + off * d_rows.stride(0) * 4
+            arr[i].ld = d_rows.stride(0)
+            arr[i].n_old, arr[i].n_new, arr[i].cap, arr[i].reserved = n0, k, cap, 0
+            arr[i].sum = d_sum.data_ptr() + i * D * 8
+            arr[i].alive = d_alive.data_ptr() + off
+            arr[i].dist = d_dist.data_ptr() + off * 8
+            arr[i].dropped = d_drop.data_ptr() + doff * 4
+            off += n0 + k
+            doff += k
+        raw = bytes(arr)
+        d_jobs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        with torch.cuda.device(dev):
+            nv.check(nv.lib().ac_memory_add_prune(ctypes.cast(arr, ctypes.c_void_p), nv.ptr(d_jobs), nj, D,
+                                                  nv.stream_ptr(dev)), "ac_memory_add_prune")
+        alive_all = d_alive.cpu().numpy().astype(bool)
+        dist_all = d_dist.cpu().numpy()
+        sums = d_sum.cpu()
+        off = 0
+        for i, (label, lst, new, ent, rows, _, n0, k) in enumerate(jobs):
+            alive, dist = alive_all[off: off + n0 + k], dist_all[off: off + n0 + k]
+            off += n0 + k
+            kept = np.nonzero(alive)[0]
+            # the last prune leaves the list in ascending distance to the then-current mean (:212-214)
+            order = kept[np.argsort(dist[kept], kind="stable")]
+            everything = lst + new
+            self.examples[label] = [everything[i_] for i_ in order.tolist()]
+            n = len(order)
+            if ent[0].shape[0] < n + 1:
+                ent = [torch.empty((max(n + 1, 64), D), dtype=torch.float32), 0]
+            ent[0][:n] = rows[torch.from_numpy(np.ascontiguousarray(order))]
+            ent[1] = n
+            self._mats[label] = ent
+            self._sums[label] = (sums[i].clone(), n)
+            self._update_prototype(label)
+
+    def _add_one_no_counters(self, example: Example, label: str):
+        """add_example minus the rebuild counters (used by add_examples_batch's host fallback)."""
+        self.examples[label].append(example)
+        n = len(self.examples[label])
+        ent = self._class_matrix(label, n)
+        ent[0][n - 1] = example.embedding
+        ent[1] = n
+        cached = self._sums.get(label)
+        s = ent[0][: n - 1].double().sum(0) if cached is None or cached[1] != n - 1 else cached[0]
+        self._sums[label] = (s + example.embedding.detach().double(), n)
+        if n > self.config.max_examples_per_class:
+            self._prune_examples(label)
+        self._update_prototype(label)
 
     def _update_prototype(self, label: str):
         examples = self.examples[label]

@@ -358,6 +358,28 @@ typedef struct {
 } ac_bert_weights;
 
 /*
+ * memory.py:41-83 + :196-217 for ALL the examples one add_examples() call adds, one workgroup per class job,
+ * ONE launch.  Per job: rows [n_old + n_new, ld] = the class's stored embeddings in list order followed by the
+ * new ones in arrival order.  For t = 0 .. n_new-1: row n_old+t joins; if the class then holds more than `cap`
+ * rows, the row farthest (L2) from the class mean (fp64 running sum, mean rounded to fp32, fp32 differences,
+ * fp64 accumulation) is dropped -- exactly the sequential loop of the reference, whose cost there is O(n D)
+ * host work per example.  sum [D] fp64: in = sum of the n_old rows, out = sum of the survivors.
+ * alive [n_old + n_new]: 1 = kept.  dist [n_old + n_new] fp64: survivors' distance to the mean at the last
+ * prune (the reference leaves the list sorted ascending by it).  dropped [n_new]: row dropped at step t or -1.
+ * All job pointers are device pointers; the job array itself is passed twice: h_jobs (host copy, validated)
+ * and d_jobs (the same bytes in device memory, read by the kernel).  n_old + n_new <= 8192, D <= 4096
+ * (AC_EUNSUPPORTED beyond: callers fall back to per-example host logic).
+ */
+typedef struct {
+    const float* rows; int64_t ld;
+    int n_old, n_new, cap, reserved;
+    double* sum; uint8_t* alive; double* dist; int32_t* dropped;
+} ac_prune_job;
+
+int ac_memory_add_prune(const ac_prune_job* h_jobs, const ac_prune_job* d_jobs, int njobs, int D,
+                        ac_stream_t stream);
+
+/*
  * classifier.py:447-480 (predict) and :1359-1384 (predict_batch): blend prototype scores with head
  * probabilities, normalise, stable-sort, keep the top k -- on the device, in fp64 like the reference's
  * Python floats.  d_scores / d_hit_class [b, kp]: ac_proto_scores output and the class id of every hit

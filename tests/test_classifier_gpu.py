@@ -323,3 +323,43 @@ def test_device_blend_equals_numpy_formula(C, kp, k, regular, cuda_dev):
         for q, (g, w) in enumerate(zip(got, want)):
             assert [l for l, _ in g] == [l for l, _ in w], (q, use_s, use_p, g, w)
             assert np.allclose([s for _, s in g], [s for _, s in w], rtol=0, atol=1e-12), (q, g, w)
+
+
+@pytest.mark.parametrize("cap,D,stream", [(50, 128, 400), (10, 64, 90), (1000, 768, 1200)])
+def test_batched_device_prune_equals_per_example_host_logic(cap, D, stream, cuda_dev):
+    """PrototypeMemory.add_examples_batch (ac_memory_add_prune: the add -> mean -> drop-farthest loop per class on
+    the device) leaves exactly the state the per-example add_example loop (the statement of memory.py:41-83 /
+    :196-217 checked step by step against the reference algorithm in test_host_logic) leaves: same examples in
+    the same order per class, same prototypes, same counters."""
+    from adaptive_classifier.memory import PrototypeMemory
+    from adaptive_classifier.models import Example, ModelConfig
+    cfg = ModelConfig({"max_examples_per_class": cap, "prototype_update_frequency": 37})
+    a = PrototypeMemory(D, cfg, device=cuda_dev)
+    b = PrototypeMemory(D, cfg, device=cuda_dev)
+    g = torch.Generator().manual_seed(cap + D)
+    labels = ["x", "y", "z"]
+    cents = torch.randn(3, D, generator=g)
+    i = 0
+    for chunk in (7, 32, 32, 1, 64, 32, 200, 32):              # ragged call sizes, crossing the cap mid-call
+        if i >= stream:
+            break
+        exs, labs = [], []
+        for _ in range(chunk):
+            c = int(torch.randint(0, 3, (1,), generator=g))
+            v = torch.nn.functional.normalize(cents[c] + 0.5 * torch.randn(D, generator=g), dim=0)
+            exs.append(v); labs.append(labels[c]); i += 1
+        for v, l in zip(exs, labs):
+            a.add_example(Example(f"t{id(v)}", l, v.clone()), l)
+        b.add_examples_batch([Example(f"t{id(v)}", l, v.clone()) for v, l in zip(exs, labs)], labs)
+        for l in labels:
+            assert [e.text for e in a.examples[l]] == [e.text for e in b.examples[l]], (l, i)
+            if l in a.prototypes:
+                assert torch.allclose(a.prototypes[l], b.prototypes[l], atol=1e-6, rtol=0)
+        assert a.updates_since_rebuild == b.updates_since_rebuild
+        assert a.label_to_index == b.label_to_index
+    assert max(len(b.examples[l]) for l in labels) <= cap
+    # and the searchable state agrees
+    q = torch.nn.functional.normalize(torch.randn(D, generator=g), dim=0)
+    a._rebuild_index(); b._rebuild_index()
+    ra, rb = a.get_nearest_prototypes(q, 3), b.get_nearest_prototypes(q, 3)
+    assert [l for l, _ in ra] == [l for l, _ in rb] and np.allclose([s for _, s in ra], [s for _, s in rb], atol=1e-6)

@@ -20,11 +20,17 @@ def emb(i, c):
     v = cent[c] + 0.5 * noise[i]; return torch.from_numpy((v / np.linalg.norm(v)).astype(np.float32))
 E = [emb(i, i % C) for i in range(n)]
 t0 = time.perf_counter(); steps = 0; tmem = 0.0
+_orig = clf.memory.add_examples_batch
+def _timed(*a, **k):
+    global tmem
+    t = time.perf_counter(); r = _orig(*a, **k); torch.cuda.synchronize(); tmem += time.perf_counter() - t; return r
+clf.memory.add_examples_batch = _timed
 for s in range(0, n, 32):
     idx = range(s, min(n, s + 32))
     clf.add_embeddings([f"t{i}" for i in idx], [E[i] for i in idx], [f"c{i % C}" for i in idx])
     steps += clf.last_train_info["steps"]
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"memory bookkeeping: {tmem:.3f} s = {tmem/n*1e3:.3f} ms per example")
 print(f"{n} examples in chunks of 32: {dt:.2f} s = {n/dt:.0f} examples/s; {steps} training steps = {steps/dt:.0f} steps/s overall; "
       f"stored {clf.get_memory_stats()['total_examples']}")
 np.random.seed(0)

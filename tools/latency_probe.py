@@ -22,8 +22,8 @@ for S in (16, 64):
     ids_d = ids.to(dev)
     def one():
         emb = clf.model.encode_cls(ids_d)
-        S_, I_, P_ = clf._device_scores(emb, 4)
-        return clf._blend(S_, I_, P_, 3, True)
+        S_, I_, P_ = clf._device_stage(emb, 4)
+        return clf._finish(S_, I_, P_, 3, True, b=1)
     for _ in range(5): one()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 50
