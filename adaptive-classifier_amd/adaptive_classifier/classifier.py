@@ -156,10 +156,28 @@ class AdaptiveClassifier:
     @staticmethod
     def _index_loader(n, batch_size):
         """Batches of example indices in exactly the order the reference's
-        DataLoader(shuffle=True, generator=torch.Generator().manual_seed(42)) yields (classifier.py:1454-1459)."""
+        DataLoader(shuffle=True, generator=torch.Generator().manual_seed(42)) yields (classifier.py:1454-1459).
+        Kept as the executable definition of that order (tests compare `_EpochOrder` against it)."""
         ds = torch.utils.data.TensorDataset(torch.arange(n))
         return torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True,
                                            generator=torch.Generator().manual_seed(42))
+
+    class _EpochOrder:
+        """The index order of successive epochs of that DataLoader without iterating one (which costs ~150 us of
+        host time per 32-example batch -- more than the training step itself).  It consumes the generator exactly
+        as torch does per epoch: `_BaseDataLoaderIter.__init__` draws the base seed, `RandomSampler.__iter__`
+        draws `randperm(n)` for the epoch and, when the iterator is exhausted, one more `randperm(n)` for the
+        empty `num_samples % n` tail.  tests/test_host_logic.py pins this against a real DataLoader."""
+
+        def __init__(self, n, seed=42):
+            self.n = n
+            self.g = torch.Generator().manual_seed(seed)
+
+        def next_epoch(self):
+            torch.empty((), dtype=torch.int64).random_(generator=self.g)
+            order = torch.randperm(self.n, generator=self.g)
+            torch.randperm(self.n, generator=self.g)
+            return order
 
     LOSS_KIND = 0            # AC_LOSS_CE; the multi-label subclass trains new classes with CE on sigmoid outputs
 
@@ -173,7 +191,9 @@ class AdaptiveClassifier:
         if use_scheduler:        # ReduceLROnPlateau(mode=min, factor .5, patience 2) on a stand-in optimizer
             dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=trainer.lr)
             sched = torch.optim.lr_scheduler.ReduceLROnPlateau(dummy, mode="min", factor=0.5, patience=2)
-        loader = self._index_loader(X.shape[0], batch_size)
+        n_rows = X.shape[0]
+        epoch_order = self._EpochOrder(n_rows)
+        steps_per_epoch = (n_rows + batch_size - 1) // batch_size          # len(loader), drop_last=False
         best_loss, patience, patience_counter = float("inf"), 3, 0
         steps = 0
         X = X.contiguous()
@@ -184,20 +204,17 @@ class AdaptiveClassifier:
         base_seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self.train_steps * 1000003) & 0x7FFFFFFFFFFFFFFF
         for epoch in range(epochs):
             trainer.loss_accum.zero_()
-            # one H2D of the epoch's batch order (same order as the reference's seeded DataLoader)
-            batches = [idx for (idx,) in loader]
-            order = torch.cat(batches).to(X.device)
-            # every batch but the last has batch_size rows (DataLoader, drop_last=False): one native call
-            # runs the whole epoch (ac_head_train_epoch) -- no per-step Python / ctypes work
-            nb0 = batches[0].numel()
-            assert all(b.numel() == nb0 for b in batches[:-1]) and batches[-1].numel() <= nb0
+            # one H2D of the epoch's batch order (same order as the reference's seeded DataLoader); every batch
+            # but the last has batch_size rows (drop_last=False): one native call runs the whole epoch
+            order = epoch_order.next_epoch().to(X.device)
+            nb0 = min(batch_size, n_rows)
             steps += trainer.fused_epoch(X, y, order, nb0, AdaptiveHead.DROPOUT_P, base_seed + steps,
                                          fisher=None if ewc is None else ewc.fisher_flat,
                                          old_params=None if ewc is None else ewc.old_flat,
                                          lambda_B=0.0 if ewc is None else lambda_B, loss_kind=loss_kind,
                                          targets_all=targets)
             total = trainer.loss_accum
-            avg_loss = float(total.item()) / len(loader)         # the only host sync of the epoch
+            avg_loss = float(total.item()) / steps_per_epoch    # the only host sync of the epoch
             if sched is not None:
                 sched.step(avg_loss)
                 trainer.lr = dummy.param_groups[0]["lr"]
@@ -215,12 +232,20 @@ class AdaptiveClassifier:
         """classifier.py:1428-1522: retrain on everything stored, sorted by (label, text)."""
         if not self.memory.examples:
             return
-        embs, labs = [], []
+        blocks, labs = [], []
         for label in sorted(self.memory.examples.keys()):
-            for example in sorted(self.memory.examples[label], key=lambda x: x.text):
-                embs.append(example.embedding)
-                labs.append(self.label_to_id[example.label])
-        X = l2_normalize_rows(torch.stack(embs).to(self.device))               # :1450
+            exs = self.memory.examples[label]
+            if not exs:
+                continue
+            order = sorted(range(len(exs)), key=lambda i: exs[i].text)           # stable, like sorted(examples, key=text)
+            ent = self.memory._mats.get(label)
+            if ent is not None and ent[1] == len(exs):
+                # the memory's class matrix mirrors the list: one gather instead of stacking n small tensors
+                blocks.append(ent[0][:len(exs)][torch.tensor(order, dtype=torch.long)])
+            else:
+                blocks.append(torch.stack([exs[i].embedding for i in order]).to(torch.float32))
+            labs.extend([self.label_to_id[label]] * len(exs))
+        X = l2_normalize_rows(torch.cat(blocks).to(self.device))                # :1450
         y = torch.tensor(labs, dtype=torch.long, device=self.device)
         self._run_epochs(X, y, batch_size=min(32, X.shape[0]), epochs=epochs, use_scheduler=True)
 

@@ -135,9 +135,119 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, const f
     else if (t < H1 + H2) { src = d2; dst = gb2; n = H2; c = t - H1; }
     else if (t < H1 + H2 + C) { src = dz; dst = gb3; n = C; c = t - H1 - H2; }
     else return;
+    if (!dst) return;                            // already produced by head_top_kernel
     float s = 0.f;
     for (int b = 0; b < B; ++b) s += src[(size_t)b * n + c];
     dst[c] = s;
+}
+
+// The top of the network in ONE launch when there are few classes (C <= kTopMaxC): logits z = a2 W3^T + b3,
+// the loss and dz (same formulas as loss_fwd_bwd_kernel), gW3 = dz^T a2, gb3, d2 = (dz W3) gated by layer 2's
+// relu/dropout, gb2 -- everything above the second hidden layer is O(B * H2 * C) work, i.e. five launches'
+// worth of latency for a few microseconds of arithmetic.  One workgroup; thread k owns column k of a2 / W3.
+constexpr int kTopMaxC = 16;
+constexpr int kTopMaxB = 256;
+
+__global__ __launch_bounds__(512) void head_top_kernel(const float* __restrict__ a2, int H2, const float* __restrict__ W3,
+                                                       const float* __restrict__ b3, const int64_t* __restrict__ y,
+                                                       const float* __restrict__ T, int64_t ldt, int B, int C, int kind,
+                                                       float gate_scale, float* __restrict__ d2, float* __restrict__ gW3,
+                                                       float* __restrict__ gb3, float* __restrict__ gb2,
+                                                       float* __restrict__ loss) {
+    __shared__ float zs[kTopMaxB][kTopMaxC];
+    __shared__ float dzs[kTopMaxB][kTopMaxC];
+    __shared__ float rl[kTopMaxB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 1. logits: four threads per (row, class) pair, each a strided quarter of the dot product, so the usual
+    //    B * C = 128 pairs finish in one pass of the 512 threads with every load independent
+    for (int p0 = 0; p0 < B * C; p0 += 128) {
+        const int p = p0 + (tid >> 2), q = tid & 3;
+        float acc = 0.f;
+        if (p < B * C) {
+            const int b = p / C, c = p - b * C;
+            const float* ar = a2 + (size_t)b * H2;
+            const float* wr = W3 + (size_t)c * H2;
+#pragma unroll 8
+            for (int k = q; k < H2; k += 4) acc = fmaf(ar[k], wr[k], acc);
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (p < B * C && q == 0) { const int b = p / C, c = p - b * C; zs[b][c] = acc + b3[c]; }
+    }
+    __syncthreads();
+    // 2. loss and dz, one thread per row
+    if (tid < B) {
+        const int b = tid;
+        if (kind == AC_LOSS_BCE_SIGMOID) {
+            const float inv = 1.f / ((float)B * (float)C);
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float p = 1.f / (1.f + expf(-zs[b][c]));
+                const float t = T[(size_t)b * ldt + c];
+                s -= t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(logf(1.f - p), -100.f);
+                const float pq = p * (1.f - p);
+                dzs[b][c] = (p - t) / fmaxf(pq, 1e-12f) * inv * pq;
+            }
+            rl[b] = s / (float)C;
+        } else {
+            const bool sig = kind == AC_LOSS_CE_SIGMOID;
+            float v[kTopMaxC];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < kTopMaxC; ++c)
+                if (c < C) { v[c] = sig ? 1.f / (1.f + expf(-zs[b][c])) : zs[b][c]; mx = fmaxf(mx, v[c]); }
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < kTopMaxC; ++c) if (c < C) sum += expf(v[c] - mx);
+            const int yb = (int)y[b];
+            const float invB = 1.f / (float)B;
+            float vy = 0.f;
+#pragma unroll
+            for (int c = 0; c < kTopMaxC; ++c)
+                if (c < C) {
+                    float g = (expf(v[c] - mx) / sum - (c == yb ? 1.f : 0.f)) * invB;
+                    if (sig) g *= v[c] * (1.f - v[c]);
+                    dzs[b][c] = g;
+                    if (c == yb) vy = v[c];
+                }
+            rl[b] = (mx + logf(sum)) - vy;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float s = 0.f;
+        for (int b = lane; b < B; b += 64) s += rl[b];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+        if (lane == 0) *loss = s / (float)B;
+    }
+    if (tid >= 64 && tid < 64 + C) {                       // gb3 = column sums of dz, rows in order
+        const int c = tid - 64;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dzs[b][c];
+        gb3[c] = s;
+    }
+    // 3. thread k: column k of a2 / W3 -> gW3[:, k], d2[:, k], gb2[k]
+    for (int k = tid; k < H2; k += 512) {
+        float w3[kTopMaxC], dw[kTopMaxC];
+#pragma unroll
+        for (int c = 0; c < kTopMaxC; ++c) { w3[c] = c < C ? W3[(size_t)c * H2 + k] : 0.f; dw[c] = 0.f; }
+        float db = 0.f;
+#pragma unroll 8
+        for (int b = 0; b < B; ++b) {
+            const float a = a2[(size_t)b * H2 + k];
+            float t = 0.f;
+#pragma unroll
+            for (int c = 0; c < kTopMaxC; ++c)
+                if (c < C) { const float g = dzs[b][c]; t = fmaf(g, w3[c], t); dw[c] = fmaf(g, a, dw[c]); }
+            const float d = (a != 0.f) ? t * gate_scale : 0.f;
+            d2[(size_t)b * H2 + k] = d;
+            db += d;
+        }
+#pragma unroll
+        for (int c = 0; c < kTopMaxC; ++c) if (c < C) gW3[(size_t)c * H2 + k] = dw[c];
+        gb2[k] = db;
+    }
 }
 
 __global__ __launch_bounds__(256) void fisher_acc_kernel(const float* g, float inv, float* F, int64_t n) {
@@ -347,17 +457,25 @@ int head_fwd_bwd(const ac_head_dims& d, const float* P, const float* X, int64_t 
     rc = ac::linear_f32(a1, d.H1, P + o.w2, d.H1, P + o.b2, nullptr, 0, a2, d.H2, B, d.H2, d.H1, 1, mask2, s2, stream, p2,
                         seed ^ 0xA5A5A5A5A5A5A5A5ull);
     if (rc) return rc;
-    rc = ac::linear_f32(a2, d.H2, P + o.w3, d.H2, P + o.b3, nullptr, 0, z, d.C, B, d.C, d.H2, 0, nullptr, 1.f, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(1), dim3(256), 0, stream, z, y, targets, ldt, B, d.C, loss_kind, dz,
-                       rowloss, d_loss);
-    AC_LAUNCH_CHECK();
-    // backward.  dW = dY^T A  (transA=1: dY stored [B,out] is the [K,M] layout), dA = dY W gated
-    // by relu'/dropout (a != 0 ? scale : 0).
-    rc = ac::gemm_f32(1, 0, d.C, d.H2, B, 1.f, dz, d.C, a2, d.H2, 0.f, G + o.w3, d.H2, nullptr, 0, 1.f, stream);
-    if (rc) return rc;
-    rc = ac::gemm_f32(0, 0, B, d.H2, d.C, 1.f, dz, d.C, P + o.w3, d.H2, 0.f, d2, d.H2, a2, d.H2, s2, stream);
-    if (rc) return rc;
+    const bool top = d.C <= kTopMaxC && B <= kTopMaxB;
+    if (top) {
+        // logits + loss + dz + gW3 + gb3 + d2 + gb2 in one launch (see head_top_kernel)
+        hipLaunchKernelGGL(head_top_kernel, dim3(1), dim3(512), 0, stream, a2, d.H2, P + o.w3, P + o.b3, y, targets, ldt,
+                           B, d.C, loss_kind, s2, d2, G + o.w3, G + o.b3, G + o.b2, d_loss);
+        AC_LAUNCH_CHECK();
+    } else {
+        rc = ac::linear_f32(a2, d.H2, P + o.w3, d.H2, P + o.b3, nullptr, 0, z, d.C, B, d.C, d.H2, 0, nullptr, 1.f, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(1), dim3(256), 0, stream, z, y, targets, ldt, B, d.C, loss_kind, dz,
+                           rowloss, d_loss);
+        AC_LAUNCH_CHECK();
+        // backward.  dW = dY^T A  (transA=1: dY stored [B,out] is the [K,M] layout), dA = dY W gated
+        // by relu'/dropout (a != 0 ? scale : 0).
+        rc = ac::gemm_f32(1, 0, d.C, d.H2, B, 1.f, dz, d.C, a2, d.H2, 0.f, G + o.w3, d.H2, nullptr, 0, 1.f, stream);
+        if (rc) return rc;
+        rc = ac::gemm_f32(0, 0, B, d.H2, d.C, 1.f, dz, d.C, P + o.w3, d.H2, 0.f, d2, d.H2, a2, d.H2, s2, stream);
+        if (rc) return rc;
+    }
     rc = ac::gemm_f32(1, 0, d.H2, d.H1, B, 1.f, d2, d.H2, a1, d.H1, 0.f, G + o.w2, d.H1, nullptr, 0, 1.f, stream);
     if (rc) return rc;
     rc = ac::gemm_f32(0, 0, B, d.H1, d.H2, 1.f, d2, d.H2, P + o.w2, d.H1, 0.f, d1, d.H1, a1, d.H1, s1, stream);
@@ -366,7 +484,7 @@ int head_fwd_bwd(const ac_head_dims& d, const float* P, const float* X, int64_t 
     if (rc) return rc;
     const int nb = d.H1 + d.H2 + d.C;
     hipLaunchKernelGGL(bias_grad_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, dz, d2, d1, B, d.C, d.H2,
-                       d.H1, G + o.b3, G + o.b2, G + o.b1);
+                       d.H1, top ? nullptr : G + o.b3, top ? nullptr : G + o.b2, G + o.b1);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

@@ -278,3 +278,17 @@ def test_prune_matches_reference_algorithm_step_by_step():
         assert len(m.examples["x"]) == len(ref)
         assert all(torch.equal(a.embedding, b) for a, b in zip(m.examples["x"], ref)), i
         assert torch.allclose(m.prototypes["x"], torch.stack(ref).mean(0), atol=1e-6)
+
+
+def test_epoch_order_equals_the_seeded_dataloader():
+    """AdaptiveClassifier._EpochOrder reproduces, epoch after epoch, the index order of the reference's
+    DataLoader(shuffle=True, generator=Generator().manual_seed(42)) (classifier.py:1454-1459) without iterating a
+    DataLoader -- it depends on how many numbers torch's loader / sampler draw per epoch, so it is pinned here."""
+    import torch
+    from adaptive_classifier import AdaptiveClassifier
+    for n, bs in ((1, 1), (5, 32), (33, 32), (64, 32), (100, 32), (777, 32)):
+        loader = AdaptiveClassifier._index_loader(n, min(bs, n))
+        fast = AdaptiveClassifier._EpochOrder(n)
+        for epoch in range(5):
+            want = torch.cat([idx for (idx,) in loader])
+            assert torch.equal(fast.next_epoch(), want), (n, epoch)

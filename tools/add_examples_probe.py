@@ -25,12 +25,23 @@ def _timed(*a, **k):
     global tmem
     t = time.perf_counter(); r = _orig(*a, **k); torch.cuda.synchronize(); tmem += time.perf_counter() - t; return r
 clf.memory.add_examples_batch = _timed
+_T = {}
+def _wrap(obj, name):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        t = time.perf_counter(); r = f(*a, **k); torch.cuda.synchronize(); _T[name] = _T.get(name, 0.0) + time.perf_counter() - t; return r
+    setattr(obj, name, g)
+for nm in ("_run_epochs", "_train_adaptive_head"): _wrap(clf, nm)
+_wrap(clf.memory, "_rebuild_index")
+from adaptive_classifier import training as _tr
+_wrap(_tr.HeadTrainer, "fused_epoch")
 for s in range(0, n, 32):
     idx = range(s, min(n, s + 32))
     clf.add_embeddings([f"t{i}" for i in idx], [E[i] for i in idx], [f"c{i % C}" for i in idx])
     steps += clf.last_train_info["steps"]
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"memory bookkeeping: {tmem:.3f} s = {tmem/n*1e3:.3f} ms per example")
+print("phase seconds (synchronised):", {k: round(v, 3) for k, v in _T.items()})
 print(f"{n} examples in chunks of 32: {dt:.2f} s = {n/dt:.0f} examples/s; {steps} training steps = {steps/dt:.0f} steps/s overall; "
       f"stored {clf.get_memory_stats()['total_examples']}")
 np.random.seed(0)
