@@ -82,10 +82,9 @@ __device__ __forceinline__ float fast_epilogue(float acc, float bias, float res)
 __device__ __forceinline__ int acc_row32(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // shared epilogue of the LDS-tiled kernels: the 32x32 C/D layout (lane owns column lane & 31, 16 rows)
-template <int EPI, int TM>
+template <int EPI, int TM, int BM = 64 * TM>
 __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][2], float* __restrict__ C, int64_t ldc, int M, int N,
                                            int m0, int n0, int wm, int wn, int lane, const Epilogue& epi) {
-    constexpr int BM = 64 * TM;
     // epilogue: lane owns column (lane & 31) of each 32x32 tile, 16 rows
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
@@ -473,12 +472,14 @@ constexpr int SBK = 16;   // k per stage = one bf16 MFMA chunk
 //   (A three-buffer ring with loads spanning the barrier -- raw s_barrier + counted vmcnt -- measured 12 %
 //   SLOWER at 8192^3: 72 KB of LDS leaves 2 blocks per CU instead of 3, and occupancy is what hides the
 //   fragment-read latency here.)
-template <int EPI, int TM, bool A_PLANES, bool C_PLANES>
-__global__ __launch_bounds__(kTileThreads, 3) void gemm_planes_nt(
+//   WMW = wave rows of the block: 2 -> 4 waves, (64*TM) x 128 tile, 3 blocks/CU;  4 -> 8 waves, (128*TM) x 128
+//   tile (25 % fewer staged bytes per MFMA), 2 blocks/CU -- used when the problem has >= 1.5 rounds of such tiles.
+template <int EPI, int TM, bool A_PLANES, bool C_PLANES, int WMW = 2>
+__global__ __launch_bounds__(128 * WMW, (WMW == 2 ? 3 : 4)) void gemm_planes_nt(
     const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Ap, int64_t a_rows,
     const uint16_t* __restrict__ Wp, int64_t w_rows, float* __restrict__ C, int64_t ldc, int M, int N, int K,
     Epilogue epi) {
-    constexpr int BM = 64 * TM;
+    constexpr int BM = 32 * TM * WMW;
     constexpr int RA = BM / 32, RW = BN / 32;                       // 32-row groups per operand
     __shared__ uint4 lds[2][3][(RA + RW) * 64];                     // [buffer][plane][A groups | W groups][lane]
 
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(kTileThreads, 3) void gemm_planes_nt(
     const int m0 = bm * BM, n0 = bn * BN;
     const int i = lane & 31, kg = lane >> 5;
 
-    // W: wave w stages row group w.  Source of (plane p, stage kt): wsrc + p * w_plane + kt * w_step
-    int wrow = n0 + 32 * wave + i; if (wrow > N - 1) wrow = N - 1;
+    // W: wave w < 4 stages row group w.  Source of (plane p, stage kt): wsrc + p * w_plane + kt * w_step
+    int wrow = n0 + 32 * (wave & 3) + i; if (wrow > N - 1) wrow = N - 1;
     const uint16_t* wsrc = Wp + ((int64_t)kg * w_rows + wrow) * 8;
     const int64_t w_plane = w_rows * (int64_t)K, w_step = 2 * w_rows * 8;
     // A as planes: waves < RA stage row group `wave`
@@ -500,6 +501,7 @@ __global__ __launch_bounds__(kTileThreads, 3) void gemm_planes_nt(
     const uint16_t* asrc = A_PLANES ? Ap + ((int64_t)kg * a_rows + arow) * 8 : nullptr;
     const int64_t a_plane = a_rows * (int64_t)K, a_step = 2 * a_rows * 8;
     // A as fp32: thread -> (row = tid / 2, k-slot = tid % 2), 32 B of a row per thread
+    static_assert(!(WMW == 4 && !A_PLANES), "the 8-wave tile is built for pre-split A only");
     const int frow = tid >> 1, fkg = tid & 1;
     int farow = m0 + frow; if (farow > M - 1) farow = M - 1;
     const float* fsrc = A_PLANES ? nullptr : A + (int64_t)farow * lda + 8 * fkg;
@@ -507,10 +509,12 @@ __global__ __launch_bounds__(kTileThreads, 3) void gemm_planes_nt(
     const bool fact = frow < BM;                                    // TM = 1: half the threads stage A
 
     auto stage_glds = [&](int kt, int buf) {
+        if (WMW == 2 || wave < RW) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc + p * w_plane + kt * w_step),
-                                             (lds_void_t*)&lds[buf][p][(RA + wave) * 64], 16, 0, 0);
+            for (int p = 0; p < 3; ++p)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc + p * w_plane + kt * w_step),
+                                                 (lds_void_t*)&lds[buf][p][(RA + wave) * 64], 16, 0, 0);
+        }
         if (A_PLANES && wave < RA) {
 #pragma unroll
             for (int p = 0; p < 3; ++p)
@@ -568,10 +572,10 @@ __global__ __launch_bounds__(kTileThreads, 3) void gemm_planes_nt(
         __syncthreads();      // drains the global_load_lds queue (vmcnt(0)) and ends every read of `cur`
     }
     if (C_PLANES) {
-        static_assert(sizeof(lds) >= 4 * kTrFloats * sizeof(float), "transpose scratch must fit the staging buffers");
+        static_assert(sizeof(lds) >= 2 * WMW * kTrFloats * sizeof(float), "transpose scratch must fit the staging buffers");
         store_tile_planes<EPI, TM>(acc, reinterpret_cast<uint16_t*>(C), M, N, m0, n0, wm, wn, lane, epi,
                                    reinterpret_cast<float*>(&lds[0][0][0]) + wave * kTrFloats);
-    } else store_tile<EPI, TM>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, epi);
+    } else store_tile<EPI, TM, BM>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -780,6 +784,26 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         else if (tm == 2) hipLaunchKernelGGL((gemm_tile_nt<E, 2>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);     \
         else hipLaunchKernelGGL((gemm_tile_nt<E, 1>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);                  \
     } while (0)
+        // 8-wave 256 x 128 tile when both operands are pre-split and the grid has >= 1.5 rounds of such tiles
+        const int64_t b256 = (int64_t)((M + 255) / 256) * ntn;
+        static const int tile256_env = getenv("AC_GEMM_TILE256") ? atoi(getenv("AC_GEMM_TILE256")) : -1;
+        const bool big = planes && Ap && (tile256_env >= 0 ? tile256_env != 0 : b256 >= 3 * (int64_t)cus) &&
+                         (cls == EPI_BIAS || cls == EPI_BIAS_GELU || cls == EPI_BIAS_RES || cls == EPI_GEGLU32) &&
+                         !(cls == EPI_GEGLU32 && !Cp) && !(cls == EPI_BIAS_RES && Cp);
+        if (big) {
+            const dim3 grid8((unsigned)b256), block8(512);
+            float* Cq = Cp ? reinterpret_cast<float*>(Cp) : C;
+#define AC_L8(E, CP) hipLaunchKernelGGL((gemm_planes_nt<E, 2, true, CP, 4>), grid8, block8, 0, stream, A, lda, Ap, a_rows, Bp, b_rows, Cq, ldc, M, N, K, epi)
+            if (Cp) {
+                AC_REQUIRE((N % 8) == 0, AC_EUNSUPPORTED, "gemm: planes output needs N %% 8 == 0");
+                if (cls == EPI_GEGLU32) AC_L8(EPI_GEGLU32, true);
+                else if (cls == EPI_BIAS_GELU) AC_L8(EPI_BIAS_GELU, true);
+                else AC_L8(EPI_BIAS, true);
+            } else if (cls == EPI_BIAS) AC_L8(EPI_BIAS, false);
+            else if (cls == EPI_BIAS_GELU) AC_L8(EPI_BIAS_GELU, false);
+            else AC_L8(EPI_BIAS_RES, false);
+#undef AC_L8
+        } else
         if (Cp) {
             // result emitted as planes for the next GEMM: both operands pre-split, bias (+GELU) epilogues only
             AC_REQUIRE(planes && Ap && (cls == EPI_BIAS || cls == EPI_BIAS_GELU || cls == EPI_GEGLU32) && (N % 8) == 0, AC_EUNSUPPORTED,
