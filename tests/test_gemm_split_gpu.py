@@ -65,6 +65,8 @@ def _ref(A, W, b, R, act):
     (1024, 768, 3072, 0, True),     # FFN down + residual
     (200, 130, 96, 1, False),       # ragged edges: M, N not tile multiples, 64-row tile
     (333, 257, 32, 0, True),        # single k-tile
+    (8192, 3072, 128, 2, False),    # >= 1.5 rounds of 256 x 128 tiles: the 8-wave tile is auto-selected ("aw" mode)
+    (8200, 3072, 64, 0, True),      # ... with a ragged last row tile and a residual
 ])
 def test_split_gemm_is_fp32_grade(M, N, K, act, res, cuda_dev, arith):
     from adaptive_classifier import _native as nv
