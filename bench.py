@@ -13,6 +13,8 @@ N GPUs   one process per GPU: every rank encodes its own 256-text batch (data pa
 roofline the kNN distance sweep in its HBM-bound regime (the north star's roofline target): knn_sweep
          over 10M x 768 fp32 rows (30.7 GB) with 16 resident queries, timed with HIP events recorded
          around that kernel on its own stream (ac_knn_set_profile_events).  algorithmic bytes = N*D*4.
+         At N > 1 the 10M rows are sharded over the ranks (BASELINE configs[2]): every rank sweeps its shard,
+         achieved = total bytes / slowest rank's kernel time, peak = N x 8 TB/s.
          The encoder GEMM chain and the batched kNN of the timed step are MFMA-bound; their achieved
          TFLOP/s are reported next to it.  The encoder's large GEMMs default to the bf16x3 split arithmetic
          (every fp32 operand = h + m + l exactly, six bf16 MFMA products, fp32 accumulate: fp32-grade, see
@@ -106,9 +108,10 @@ def time_stages(clf, ids, types, mask, reps=5):
     return out
 
 
-def sweep_roofline(dev, n_rows):
+def sweep_roofline(dev, n_rows, full=True):
     """knn_sweep alone over n_rows x 768: algorithmic bytes / kernel time (HIP events around the kernel).
-    The headline entry uses 16 resident queries; `by_resident_queries` lists 1 / 8 / 16 / 32."""
+    The headline entry uses 16 resident queries; `by_resident_queries` lists 1 / 8 / 16 / 32.
+    full=False (the per-rank shard sweep at N > 1): only the 16-query measurement."""
     from adaptive_classifier import _native as nv
     from adaptive_classifier import index as ix
     k = 32
@@ -142,7 +145,7 @@ def sweep_roofline(dev, n_rows):
 
     ms, ms_min, call_ms, nfb = measure(16, 8)
     table = {}
-    for nq in (1, 8, 16, 32):
+    for nq in ((1, 8, 16, 32) if full else (16,)):
         t, _, c, _ = (ms, ms_min, call_ms, nfb) if nq == 16 else measure(nq, 4)
         table[str(nq)] = {"kernel_ms": t, "GBps": bytes_alg / t / 1e6, "frac": bytes_alg / t / 1e6 / HBM_PEAK_GBS,
                           "whole_call_ms": c}
@@ -264,6 +267,22 @@ def main():
         t = torch.tensor([dt32], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt32 = float(t.item())
+    # N > 1: the 10M x 768 store of BASELINE configs[2] row-sharded over the ranks; every rank sweeps its own shard
+    # (no collective in the sweep), the job's rate is total bytes / slowest rank's kernel time
+    shard_roof = None
+    if world > 1 and not args.no_sweep:
+        rows_rank = args.sweep_rows // world
+        r = sweep_roofline(dev, rows_rank, full=False)
+        tms = torch.tensor([r["avg_kernel_ms"]], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+        slow = float(tms.item())
+        total_bytes = rows_rank * world * DIM * 4
+        shard_roof = {"bound": "hbm", "achieved": total_bytes / slow / 1e6, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                      "frac": total_bytes / slow / 1e6 / (HBM_PEAK_GBS * world), "traffic": None,
+                      "kernel": "knn_sweep<1> (16-query tile), one shard per GPU", "rows": rows_rank * world,
+                      "rows_per_gpu": rows_rank, "dim": DIM, "resident_queries": 16,
+                      "algorithmic_bytes_per_launch": rows_rank * DIM * 4, "avg_kernel_ms": slow,
+                      "rank0_avg_kernel_ms": r["avg_kernel_ms"], "aggregation": "sum of shard bytes / max over ranks of the kernel time"}
     enc_peak = BF16_MFMA_PEAK_TF / 6.0 if arith == 1 else F32_MFMA_PEAK_TF
     if rank == 0:
         enc_flops = clf.model.flops(BATCH, SEQ)
@@ -304,6 +323,8 @@ def main():
             while n_rows * DIM * 4 > 0.8 * free and n_rows > 100_000:
                 n_rows //= 2
             line["roofline"] = sweep_roofline(dev, n_rows)
+        elif world > 1 and shard_roof is not None:
+            line["roofline"] = shard_roof
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hf, clf, clf.memory.index._store[:NPROTO])
         print(json.dumps(line), flush=True)
