@@ -294,8 +294,12 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
 // Last layer: only the CLS query of every sequence feeds the output (classifier.py:1272), so its
 // attention is a single-query problem.  One wave per (sequence, head): lane = key for the scores,
 // lane = output dim for the P.V reduction; K tile rows padded to 65 floats (conflict-free column reads).
+// ROPE (ModernBERT): the CLS query is at position 0, whose rotation is the identity, so only the keys rotate;
+// window >= 0: only keys at positions <= window are visible to it.
+template <bool ROPE>
 __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, const int64_t* mask, int S, int H,
-                                                           float scale, float* ctx_cls) {
+                                                           float scale, float* ctx_cls, const float* rope_cos,
+                                                           const float* rope_sin, int window) {
     __shared__ float Ks[KT][DH + 1];
     __shared__ __attribute__((aligned(16))) float Vs[KT][DH];
     __shared__ float qs[DH];
@@ -306,8 +310,9 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
     const float* base = qkv + (int64_t)bi * S * ld + head * DH;
     qs[lane] = base[lane] * scale;              // CLS token = row 0 of the sequence
     float m = -INFINITY, l = 0.f, o = 0.f;      // o: output dim `lane`
-    for (int k0 = 0; k0 < S; k0 += KT) {
-        const int nk = (S - k0) < KT ? (S - k0) : KT;
+    const int Svis = (window >= 0 && window + 1 < S) ? window + 1 : S;     // keys the CLS query can see
+    for (int k0 = 0; k0 < Svis; k0 += KT) {
+        const int nk = (Svis - k0) < KT ? (Svis - k0) : KT;
         __syncthreads();
         for (int r = lane >> 4; r < KT; r += 4) {
             const int c = (lane & 15) * 4;
@@ -323,8 +328,20 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
         __syncthreads();
         const bool valid = lane < nk && (!mask || mask[(int64_t)bi * S + k0 + lane] != 0);
         float sc = 0.f;
+        if (ROPE) {
+            const int pos = (k0 + lane < S) ? k0 + lane : S - 1;
+            const float* cs = rope_cos + (int64_t)pos * 32;
+            const float* sn = rope_sin + (int64_t)pos * 32;
+#pragma unroll 8
+            for (int d = 0; d < 32; ++d) {
+                const float lo = Ks[lane][d], hi = Ks[lane][d + 32], c = cs[d], sv = sn[d];
+                sc = fmaf(qs[d], lo * c + (-hi) * sv, sc);
+                sc = fmaf(qs[d + 32], hi * c + lo * sv, sc);
+            }
+        } else {
 #pragma unroll 16
-        for (int d = 0; d < DH; ++d) sc = fmaf(qs[d], Ks[lane][d], sc);
+            for (int d = 0; d < DH; ++d) sc = fmaf(qs[d], Ks[lane][d], sc);
+        }
         sc = valid ? sc : -INFINITY;
         float cmax = sc;
 #pragma unroll
@@ -474,7 +491,8 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
         const float* resid = x;                        // residual = layer input
         const int64_t ldres = last ? (int64_t)S * H : H;   // CLS rows of x are S*H apart
         if (last) {
-            hipLaunchKernelGGL(attention_cls_kernel, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale, ctx);
+            hipLaunchKernelGGL(attention_cls_kernel<false>, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale,
+                               ctx, nullptr, nullptr, -1);
         } else {
             hipLaunchKernelGGL(attention_mfma_kernel<false>, dim3((S + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv,
                                d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1);
@@ -603,39 +621,51 @@ extern "C" int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const a
                             1.f, stream, 0.f, 0, wplanes ? w->wqkv3[l] : nullptr, pl ? xnp : nullptr);
         if (rc) return rc;
         const bool global = (l % c.global_every) == 0;
-        hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((S + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv, d_mask,
-                           S, H, scale, ctx, pl ? ctxp : nullptr, global ? w->rope_cos_global : w->rope_cos_local,
-                           global ? w->rope_sin_global : w->rope_sin_local, global ? -1 : c.local_window);
+        const float* rc_ = global ? w->rope_cos_global : w->rope_cos_local;
+        const float* rs_ = global ? w->rope_sin_global : w->rope_sin_local;
+        const int win = global ? -1 : c.local_window;
+        const bool last = (l == c.layers - 1);
+        // After the last layer's attention only the CLS row of each sequence is consumed (classifier.py:1272):
+        // the CLS-query attention, the output projection, the MLP and the final norm run on b rows, not b*S.
+        const int Ml = last ? b : T;
+        const bool lp = last ? (wplanes && ac::linear_takes_planes(b, H, H) && ac::linear_takes_planes(b, H, I) && (H % 8) == 0) : pl;
+        if (last) {
+            hipLaunchKernelGGL(attention_cls_kernel<true>, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale, ctx,
+                               rc_, rs_, win);
+        } else {
+            hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((S + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv, d_mask,
+                               S, H, scale, ctx, pl ? ctxp : nullptr, rc_, rs_, win);
+        }
         AC_LAUNCH_CHECK();
-        // y = x + ctx Wo^T
-        rc = ac::linear_f32(ctx, H, w->wo[l], H, opt(w->wo_b, l), x, H, y, H, T, H, H, 0, nullptr, 1.f, stream, 0.f, 0,
-                            wplanes ? w->wo3[l] : nullptr, pl ? ctxp : nullptr);
+        // y = x + ctx Wo^T   (last layer: ctx is b compact rows, the residual rows of x are S*H apart)
+        rc = ac::linear_f32(ctx, H, w->wo[l], H, opt(w->wo_b, l), x, last ? (int64_t)S * H : H, y, H, Ml, H, H, 0, nullptr, 1.f,
+                            stream, 0.f, 0, wplanes ? w->wo3[l] : nullptr, (pl && !last) ? ctxp : nullptr);
         if (rc) return rc;
-        hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, y, T, H, w->mlp_norm_g[l],
-                           opt(w->mlp_norm_b, l), c.norm_eps, xn, pl ? xnp : nullptr, (int64_t)H);
+        hipLaunchKernelGGL(ln_kernel, dim3((Ml + 3) / 4), dim3(256), 0, stream, y, Ml, H, w->mlp_norm_g[l],
+                           opt(w->mlp_norm_b, l), c.norm_eps, xn, lp ? xnp : nullptr, (int64_t)H);
         AC_LAUNCH_CHECK();
-        if (pl && w->wi_interleaved32) {
+        if (lp && w->wi_interleaved32) {
             // GeGLU fused into the Wi GEMM's epilogue, result straight into the operand planes of the Wo2 GEMM
-            rc = ac::linear_f32(xn, H, w->wi[l], H, opt(w->wi_b, l), nullptr, 0, nullptr, I, T, 2 * I, H, 3, nullptr, 1.f,
+            rc = ac::linear_f32(xn, H, w->wi[l], H, opt(w->wi_b, l), nullptr, 0, nullptr, I, Ml, 2 * I, H, 3, nullptr, 1.f,
                                 stream, 0.f, 0, w->wi3[l], xnp, gp);
             if (rc) return rc;
         } else {
-            rc = ac::linear_f32(xn, H, w->wi[l], H, opt(w->wi_b, l), nullptr, 0, u, 2 * I, T, 2 * I, H, 0, nullptr, 1.f,
-                                stream, 0.f, 0, wplanes ? w->wi3[l] : nullptr, pl ? xnp : nullptr);
+            rc = ac::linear_f32(xn, H, w->wi[l], H, opt(w->wi_b, l), nullptr, 0, u, 2 * I, Ml, 2 * I, H, 0, nullptr, 1.f,
+                                stream, 0.f, 0, wplanes ? w->wi3[l] : nullptr, lp ? xnp : nullptr);
             if (rc) return rc;
-            const int64_t units = (int64_t)T * (I / 8);
-            hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, u, (int64_t)T, I, g,
-                               pl ? gp : nullptr, w->wi_interleaved32);
+            const int64_t units = (int64_t)Ml * (I / 8);
+            hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, u, (int64_t)Ml, I, g,
+                               lp ? gp : nullptr, w->wi_interleaved32);
             AC_LAUNCH_CHECK();
         }
-        // x = y + g Wo2^T
-        rc = ac::linear_f32(g, I, w->wo2[l], I, opt(w->wo2_b, l), y, H, x, H, T, H, I, 0, nullptr, 1.f, stream, 0.f, 0,
-                            wplanes ? w->wo23[l] : nullptr, pl ? gp : nullptr);
+        // x = y + g Wo2^T   (last layer: b compact rows)
+        rc = ac::linear_f32(g, I, w->wo2[l], I, opt(w->wo2_b, l), y, H, x, H, Ml, H, I, 0, nullptr, 1.f, stream, 0.f, 0,
+                            wplanes ? w->wo23[l] : nullptr, lp ? gp : nullptr);
         if (rc) return rc;
     }
-    // final LayerNorm on the CLS rows only (stride S*H), compact into xn, then L2-normalise
+    // after the CLS-only last layer x holds b compact rows: final LayerNorm, then L2-normalise
     hipLaunchKernelGGL(ln_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, b, H, w->final_norm_g,
-                       w->final_norm_b ? w->final_norm_b : zb, c.norm_eps, xn, (uint16_t*)nullptr, (int64_t)S * H);
+                       w->final_norm_b ? w->final_norm_b : zb, c.norm_eps, xn, (uint16_t*)nullptr, (int64_t)H);
     AC_LAUNCH_CHECK();
     hipLaunchKernelGGL(cls_normalize_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, xn, b, 1, H, d_out, ldo);
     AC_LAUNCH_CHECK();

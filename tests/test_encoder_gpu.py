@@ -69,6 +69,7 @@ def test_distilbert_encoder_matches_transformers(cuda_dev):
     (768, 5, 12, 1152, 128, 2, 200),      # ModernBERT-base width; +-64 windows cut inside S = 200; 7 key tiles
     (768, 2, 12, 1152, 128, 3, 33),       # one key past a tile boundary
     (128, 4, 2, 192, 128, 1, 1024),       # long sequence: 32 key tiles, +-64 windows skip most of them in local layers
+    (128, 3, 2, 192, 8, 200, 12),         # b >= 192: the CLS-only last layer (a local one here) runs on planes too
 ])
 def test_modernbert_encoder_matches_transformers(hidden, layers, heads, inter, local, b, S, cuda_dev):
     """N4: ModernBERT (RoPE, alternating global / sliding-window attention, pre-norm, GeGLU, bias-free) against
