@@ -19,6 +19,9 @@ import torch
 from . import _native as nv
 
 
+MAX_TOKENS = 1 << 17          # tokens per native encoder call (~8 GB of activations + planes for bert-base)
+
+
 class _Cfg:
     """The slice of a HF config the classifier reads (classifier.py:88,549)."""
 
@@ -146,14 +149,19 @@ class HipBertEncoder:
         H = self.ccfg.hidden
         if out is None:
             out = torch.empty((b, H), dtype=torch.float32, device=self.device)
-        need = self.workspace_bytes(b, S)
+        # activations cost ~64 KB per token; very large batches go through in row chunks of <= MAX_TOKENS tokens
+        cb = b if b * S <= MAX_TOKENS else max(1, MAX_TOKENS // S)
+        need = self.workspace_bytes(min(b, cb), S)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            nv.check(nv.lib().ac_bert_encode_cls(
-                ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids), nv.ptr(tt), nv.ptr(mk), b, S,
-                nv.ptr(out), out.stride(0), nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
-                "ac_bert_encode_cls")
+            for r0 in range(0, b, cb):
+                r1 = min(b, r0 + cb)
+                nv.check(nv.lib().ac_bert_encode_cls(
+                    ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
+                    nv.ptr(None if tt is None else tt[r0:r1]), nv.ptr(None if mk is None else mk[r0:r1]), r1 - r0, S,
+                    nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
+                    "ac_bert_encode_cls")
         return out
 
     def flops(self, b, S, executed=True):
@@ -298,14 +306,17 @@ class HipModernBertEncoder:
         H = self.ccfg.hidden
         if out is None:
             out = torch.empty((b, H), dtype=torch.float32, device=self.device)
-        need = self.workspace_bytes(b, S)
+        cb = b if b * S <= MAX_TOKENS else max(1, MAX_TOKENS // S)
+        need = self.workspace_bytes(min(b, cb), S)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            nv.check(nv.lib().ac_modernbert_encode_cls(
-                ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids), nv.ptr(mk), b, S, nv.ptr(out),
-                out.stride(0), nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
-                "ac_modernbert_encode_cls")
+            for r0 in range(0, b, cb):
+                r1 = min(b, r0 + cb)
+                nv.check(nv.lib().ac_modernbert_encode_cls(
+                    ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
+                    nv.ptr(None if mk is None else mk[r0:r1]), r1 - r0, S, nv.ptr(out[r0:r1]), out.stride(0),
+                    nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)), "ac_modernbert_encode_cls")
         return out
 
     def flops(self, b, S, executed=True):

@@ -91,3 +91,23 @@ def test_modernbert_encoder_matches_transformers(hidden, layers, heads, inter, l
     if S > 2 * (local // 2) + 1:
         model.config.sliding_window = 10 ** 6
         assert (bert_oracle.encode_cls_modernbert(model, ids, mask) - want).abs().max().item() > 1e-3
+
+
+def test_large_batches_are_encoded_in_row_chunks(cuda_dev, monkeypatch):
+    """encode_cls splits batches beyond MAX_TOKENS tokens into row chunks; the result does not depend on it beyond
+    fp32 rounding (different row counts take different GEMM kernels)."""
+    from adaptive_classifier import encoder as enc_mod
+    from oracle import bert_oracle
+    model = bert_oracle.make_bert(128, 2, 2, 512, vocab=2000, seed=0)
+    ids, types, mask = bert_oracle.synthetic_batch(23, 16, vocab=2000, seed=5, ragged=True)
+    enc = enc_mod.HipBertEncoder(model, device=cuda_dev)
+    whole = enc.encode_cls(ids, types, mask).cpu()
+    monkeypatch.setattr(enc_mod, "MAX_TOKENS", 5 * 16)          # 5 rows per native call, ragged last chunk
+    parts = enc.encode_cls(ids, types, mask).cpu()
+    assert (whole - parts).abs().max().item() < 2e-6
+    mb = bert_oracle.make_modernbert(128, 2, 2, 192, vocab=2000, max_pos=64, local_attention=8, seed=1)
+    enc2 = enc_mod.make_encoder(mb, device=cuda_dev)
+    monkeypatch.setattr(enc_mod, "MAX_TOKENS", 1 << 17)
+    whole = enc2.encode_cls(ids, None, mask).cpu()
+    monkeypatch.setattr(enc_mod, "MAX_TOKENS", 7 * 16)
+    assert (whole - enc2.encode_cls(ids, None, mask).cpu()).abs().max().item() < 2e-6
