@@ -127,7 +127,10 @@ class PrototypeMemory:
         with self._lock:
             cap = int(self.config.max_examples_per_class)
             D = self.embedding_dim
-            dev = self.index.device if hasattr(self.index, "device") else None
+            try:
+                dev = self.index.device
+            except (nv.NativeError, AttributeError):       # no GPU (CPU-side tests): per-example host logic below
+                dev = None
             groups: Dict[str, List[Example]] = {}
             jobs = []                                      # classes that overflow their cap in this call
             for ex, label in zip(examples, labels):

@@ -292,3 +292,31 @@ def test_epoch_order_equals_the_seeded_dataloader():
         for epoch in range(5):
             want = torch.cat([idx for (idx,) in loader])
             assert torch.equal(fast.next_epoch(), want), (n, epoch)
+
+
+def test_add_examples_batch_host_fallback_equals_add_example():
+    """Without a GPU `add_examples_batch` runs the per-example host logic for overflowing classes and the O(k)
+    append path otherwise; either way the state equals a loop of `add_example` (order, prototypes, counters)."""
+    import torch
+    from adaptive_classifier.memory import PrototypeMemory
+    from adaptive_classifier.models import Example, ModelConfig
+    cfg = ModelConfig({"max_examples_per_class": 9, "prototype_update_frequency": 5})
+    a, b = PrototypeMemory(16, cfg), PrototypeMemory(16, cfg)
+    g = torch.Generator().manual_seed(4)
+    n = 0
+    for chunk in (3, 8, 1, 20, 6):
+        vs = [torch.nn.functional.normalize(torch.randn(16, generator=g), dim=0) for _ in range(chunk)]
+        ls = ["p" if (n + i) % 3 else "q" for i in range(chunk)]
+        n += chunk
+        try:
+            for v, l in zip(vs, ls):
+                a.add_example(Example(f"t{id(v)}", l, v.clone()), l)
+            b.add_examples_batch([Example(f"t{id(v)}", l, v.clone()) for v, l in zip(vs, ls)], ls)
+        except Exception as e:                       # index rebuild needs a GPU: state up to that point still comparable
+            if "GPU" not in str(e) and "gpu" not in str(e):
+                raise
+            return
+        for l in ("p", "q"):
+            assert [e.text for e in a.examples[l]] == [e.text for e in b.examples[l]]
+            assert torch.allclose(a.prototypes[l], b.prototypes[l], atol=1e-6)
+        assert a.updates_since_rebuild == b.updates_since_rebuild
