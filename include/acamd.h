@@ -94,6 +94,7 @@ int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D,
 int ac_knn_set_profile_events(void* start_event, void* stop_event);
 
 /*
+ * (No reference counterpart: the reference searches one CPU index, memory.py:114.)
  * Merge per-shard results: in [shards, nq, k] ascending
  * lists -> global ascending top-k by (distance, id).  Entries with id < 0 are
  * padding.  Pure selection: no arithmetic on the distances.
@@ -130,17 +131,19 @@ int ac_synth_unit_rows(float* d_out, int64_t n, int64_t ld, int D,
  *  H: AdaptiveHead  (models.py:30-98) + EWC (ewc.py) + AdamW
  * ------------------------------------------------------------------------- */
 
-/* Dense fp32 GEMM with fused epilogue on the fp32 MFMA pipe:
+/* nn.Linear (models.py:49-69 in the head; the transformers Linear layers behind classifier.py:1271 in the
+ * encoder) with a fused epilogue:
  *   C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]) (+ residual[M,N])
- * W is the torch nn.Linear layout.  act: 0 none, 1 ReLU, 2 GELU(erf).
- * Exact fp32 fma chains (no reduced precision).  lda/ldw/ldc in elements. */
+ * W is the torch nn.Linear layout.  act: 0 none, 1 ReLU, 2 GELU(erf).  fp32 in, fp32 out; products on the
+ * fp32-input MFMA (exact fma chains) or, for M >= 192 under AC_GEMM_BF16X3 (the default, see
+ * ac_gemm_set_arith), as the exact three-term bf16 split -- fp32-grade either way.  lda/ldw/ldc in elements. */
 int ac_linear_f32(const float* d_A, int64_t lda, const float* d_W, int64_t ldw,
                   const float* d_bias, const float* d_residual, int64_t ldr,
                   float* d_C, int64_t ldc, int M, int N, int K, int act,
                   ac_stream_t stream);
 
-/* General fp32 GEMM C = alpha * op(A) @ op(B) + beta * C used by the head
- * backward (dW = dY^T X, dX = dY W).  transA/transB: 0 = as stored, 1 = T. */
+/* General fp32 GEMM C = alpha * op(A) @ op(B) + beta * C: what autograd runs for the head's Linear layers in
+ * loss.backward() (classifier.py:1499, :345): dW = dY^T X, dX = dY W.  transA/transB: 0 = as stored, 1 = T. */
 int ac_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                 const float* d_A, int64_t lda, const float* d_B, int64_t ldb,
                 float beta, float* d_C, int64_t ldc, ac_stream_t stream);
