@@ -70,13 +70,14 @@ def test_distilbert_encoder_matches_transformers(cuda_dev):
     (768, 2, 12, 1152, 128, 3, 33),       # one key past a tile boundary
     (128, 4, 2, 192, 128, 1, 1024),       # long sequence: 32 key tiles, +-64 windows skip most of them in local layers
     (128, 3, 2, 192, 8, 200, 12),         # b >= 192: the CLS-only last layer (a local one here) runs on planes too
+    (128, 3, 2, 192, 128, 1, 8192),       # ModernBERT's full context: 256 key tiles in the global layer
 ])
 def test_modernbert_encoder_matches_transformers(hidden, layers, heads, inter, local, b, S, cuda_dev):
     """N4: ModernBERT (RoPE, alternating global / sliding-window attention, pre-norm, GeGLU, bias-free) against
     transformers ModernBertModel fp32 eager on CPU; SURVEY 8c bar: 1e-4 max-abs on the unit-norm CLS vector."""
     from adaptive_classifier.encoder import make_encoder, HipModernBertEncoder
     from oracle import bert_oracle
-    model = bert_oracle.make_modernbert(hidden, layers, heads, inter, vocab=2000, max_pos=1024, local_attention=local,
+    model = bert_oracle.make_modernbert(hidden, layers, heads, inter, vocab=2000, max_pos=max(1024, S), local_attention=local,
                                         seed=3, init_scale=4.0)
     ids, _, mask = bert_oracle.synthetic_batch(b, S, vocab=2000, seed=77, ragged=True)
     ids[:, 0] = 1
