@@ -46,6 +46,7 @@ class AdaptiveClassifier:
                  seed: int = 42, use_onnx: Optional[Union[bool, str]] = "auto", trust_remote_code: bool = False,
                  *, encoder=None, tokenizer=None):
         torch.manual_seed(seed)
+        self._seed = int(seed)
         self.config = ModelConfig(config)
         self.device = device or ("cuda" if torch.cuda.is_available() else "cpu")
         if not str(self.device).startswith("cuda"):
@@ -196,12 +197,15 @@ class AdaptiveClassifier:
         steps_per_epoch = (n_rows + batch_size - 1) // batch_size          # len(loader), drop_last=False
         best_loss, patience, patience_counter = float("inf"), 3, 0
         steps = 0
-        X = X.contiguous()
-        y = None if y is None else y.contiguous()
+        X = X.to(device=self.device, dtype=torch.float32).contiguous()     # the kernels read fp32 rows
+        y = None if y is None else y.to(device=self.device, dtype=torch.int64).contiguous()
+        if targets is not None:
+            targets = targets.to(device=self.device, dtype=torch.float32).contiguous()
         loss_kind = self.LOSS_KIND if loss_kind is None else loss_kind
-        # dropout masks are generated in-kernel from (seed, step): counter-based, reproducible per
-        # classifier seed; the reference draws them from torch's global generator (not replayable)
-        base_seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self.train_steps * 1000003) & 0x7FFFFFFFFFFFFFFF
+        # dropout masks are generated in-kernel from (classifier seed, add_examples call, step): counter-based and
+        # reproducible per classifier seed, independent of later torch.manual_seed calls (AdaptiveHead.__init__ itself
+        # reseeds torch's global generator to 42); the reference draws them from that global generator (not replayable)
+        base_seed = (self._seed * 0x9E3779B97F4A7C15 + self.train_steps * 1000003) & 0x7FFFFFFFFFFFFFFF
         for epoch in range(epochs):
             trainer.loss_accum.zero_()
             # one H2D of the epoch's batch order (same order as the reference's seeded DataLoader); every batch
@@ -239,7 +243,7 @@ class AdaptiveClassifier:
                 continue
             order = sorted(range(len(exs)), key=lambda i: exs[i].text)           # stable, like sorted(examples, key=text)
             ent = self.memory._mats.get(label)
-            if ent is not None and ent[1] == len(exs):
+            if ent is not None and ent[1] == len(exs) and self.memory._mirror_valid(label, len(exs)):
                 # the memory's class matrix mirrors the list: one gather instead of stacking n small tensors
                 blocks.append(ent[0][:len(exs)][torch.tensor(order, dtype=torch.long)])
             else:
@@ -274,7 +278,7 @@ class AdaptiveClassifier:
                 for i in indices:
                     all_embeddings.append(examples[i].embedding)
                     all_labels.append(self.label_to_id[label])
-        X = torch.stack(all_embeddings).to(self.device)
+        X = torch.stack([e.to(torch.float32) for e in all_embeddings]).to(self.device)
         y = torch.tensor(all_labels, dtype=torch.long, device=self.device)
 
         ewc = None
@@ -288,7 +292,8 @@ class AdaptiveClassifier:
                         old_X.append(example.embedding)
                         old_y.append(old_label_to_id[label])
             if old_X:
-                ds = torch.utils.data.TensorDataset(torch.stack(old_X), torch.tensor(old_y, dtype=torch.long))
+                ds = torch.utils.data.TensorDataset(torch.stack([e.to(torch.float32) for e in old_X]),
+                                                    torch.tensor(old_y, dtype=torch.long))
                 ewc = self._expand_ewc(EWC(old_head, ds, device=self.device, ewc_lambda=5.0))
         # "as_wired": the reference's penalty is built on a frozen copy and is exactly 0 with no
         # gradient into the trained head, i.e. plain CE + AdamW -- which is what runs.
@@ -324,8 +329,13 @@ class AdaptiveClassifier:
                 Cid = self.memory.hit_class_ids(I, self.label_to_id)
             if self.adaptive_head is not None:
                 self.adaptive_head.eval()
-                probs = softmax_rows(self.adaptive_head.forward_native(emb))
+                probs = softmax_rows(self._head_outputs(emb))
         return S, Cid, probs
+
+    def _head_outputs(self, emb: torch.Tensor) -> torch.Tensor:
+        """What `self.adaptive_head(x)` returns in the reference before its F.softmax (classifier.py:432-435,
+        :1342-1345): the logits for AdaptiveHead.  The multi-label subclass overrides this (sigmoid outputs)."""
+        return self.adaptive_head.forward_native(emb)
 
     def _device_scores(self, emb: torch.Tensor, k_proto: int):
         """_device_stage copied to the host as numpy (the inputs of the numpy formula `_blend`)."""

@@ -103,14 +103,8 @@ class HipBertEncoder:
         # bf16x3 operand planes of the four weight matrices per layer (ac_split_bf16x3, once): with them the
         # token-row GEMMs stage pre-split operands instead of splitting inside every tile (AC_GEMM_BF16X3)
         self._planes = []
-        stream = nv.stream_ptr(self.device)
         for k in ("qkv_w", "ao_w", "ff1_w", "ff2_w"):
-            planes = []
-            for t in per[k]:
-                rows, K = t.shape
-                pl = torch.empty(3 * rows * K, dtype=torch.int16, device=self.device)
-                nv.check(nv.lib().ac_split_bf16x3(t.data_ptr(), K, rows, K, pl.data_ptr(), stream), "ac_split_bf16x3")
-                planes.append(pl)
+            planes = [_split_planes(t, self.device) for t in per[k]]
             self._planes.extend(planes)
             arr = (ctypes.c_void_p * L)(*[t.data_ptr() for t in planes])
             self._arrays[k + "3"] = arr
@@ -183,7 +177,8 @@ def _split_planes(t, device):
     """ac_split_bf16x3 of one [rows, K] fp32 weight (operand planes for AC_GEMM_BF16X3)."""
     rows, K = t.shape
     pl = torch.empty(3 * rows * K, dtype=torch.int16, device=device)
-    nv.check(nv.lib().ac_split_bf16x3(t.data_ptr(), K, rows, K, pl.data_ptr(), nv.stream_ptr(device)), "ac_split_bf16x3")
+    with torch.cuda.device(device):           # the launch must target the weights' GPU, not the process's current one
+        nv.check(nv.lib().ac_split_bf16x3(t.data_ptr(), K, rows, K, pl.data_ptr(), nv.stream_ptr(device)), "ac_split_bf16x3")
     return pl
 
 

@@ -49,6 +49,7 @@ class PrototypeMemory:
         self.updates_since_rebuild = 0
         self._sums = {}                      # label -> (fp64 running sum of the stored embeddings, count)
         self._mats = {}                      # label -> [host matrix of the stored embeddings, count]
+        self._fps = {}                       # label -> (count, identity fingerprint) the two caches above describe
         self._dirty = set()                  # labels whose index row is out of date
         self._lock = threading.RLock()       # add_example is called from threads (test_memory.py:226-256)
         self._row_labels = None              # int32 device tensor when load_rows() is in use
@@ -57,6 +58,24 @@ class PrototypeMemory:
     def _new_index(self):
         return HipFlatL2Index(self.embedding_dim, device=self._device)
 
+    # ------------------------------------------------------------------ mirror validity
+    # `examples` is a public attribute that callers (the classifier, the reference's tests) edit directly:
+    # lists are assigned, entries replaced, embeddings swapped.  The fp64 class sums (`_sums`) and host class
+    # matrices (`_mats`) are caches of those lists; they are trusted only while the list still holds the very same
+    # embedding tensors in the same order (identity fingerprint), not merely the same NUMBER of entries.
+    @staticmethod
+    def _fingerprint(exs, n):
+        return hash(tuple(id(e.embedding) for e in exs[:n]))
+
+    def _stamp(self, label):
+        exs = self.examples[label]
+        self._fps[label] = (len(exs), self._fingerprint(exs, len(exs)))
+
+    def _mirror_valid(self, label, n):
+        """True iff the caches of `label` describe exactly examples[label][:n]."""
+        fp = self._fps.get(label)
+        return fp is not None and fp[0] == n and fp[1] == self._fingerprint(self.examples[label], n)
+
     # ------------------------------------------------------------------ add / prune / prototype
     def _class_matrix(self, label, n_needed):
         """[rows >= n_needed, D] host matrix mirroring self.examples[label][:count]; rebuilt when the
@@ -64,11 +83,12 @@ class PrototypeMemory:
         ent = self._mats.get(label)
         exs = self.examples[label]
         count = len(exs) - 1                       # rows that must already be mirrored (all but the new one)
-        if ent is None or ent[1] != count or ent[0].shape[0] < n_needed:
+        valid = ent is not None and ent[1] == count and self._mirror_valid(label, count)
+        if not valid or ent[0].shape[0] < n_needed:
             rows = max(n_needed, 2 * (ent[0].shape[0] if ent is not None else 0), 64)
             mat = torch.empty((rows, self.embedding_dim), dtype=torch.float32)
             if count:
-                if ent is not None and ent[1] == count:
+                if valid:
                     mat[:count] = ent[0][:count]
                 else:
                     mat[:count] = torch.stack([ex.embedding for ex in exs[:count]])
@@ -88,15 +108,17 @@ class PrototypeMemory:
                 example.embedding = example.embedding.detach().cpu()   # prototypes stay on the host
             self.examples[label].append(example)
             n = len(self.examples[label])
+            trusted = self._mirror_valid(label, n - 1)
             ent = self._class_matrix(label, n)
             ent[0][n - 1] = example.embedding
             ent[1] = n
             cached = self._sums.get(label)
-            if cached is None or cached[1] != n - 1:        # first add, or the list was edited behind us
+            if cached is None or cached[1] != n - 1 or not trusted:   # first add, or the list was edited behind us
                 s = ent[0][: n - 1].double().sum(0)
             else:
                 s = cached[0]
             self._sums[label] = (s + example.embedding.detach().double(), n)
+            self._stamp(label)
             if n > self.config.max_examples_per_class:
                 self._prune_examples(label)
             self._update_prototype(label)
@@ -147,14 +169,16 @@ class PrototypeMemory:
                     continue
                 fresh = torch.stack([e.embedding.detach().to(torch.float32) for e in new])
                 ent = self._mats.get(label)
-                if ent is None or ent[1] != n0:            # (re)build the mirror of the stored rows
+                trusted = self._mirror_valid(label, n0)
+                if ent is None or ent[1] != n0 or not trusted:   # (re)build the mirror of the stored rows
                     rows0 = max(n0 + k + 1, 64)
                     mat = torch.empty((rows0, D), dtype=torch.float32)
                     if n0:
                         mat[:n0] = torch.stack([e.embedding for e in lst])
                     ent = [mat, n0]
                 cached = self._sums.get(label)
-                total = cached[0] if cached is not None and cached[1] == n0 else ent[0][:n0].double().sum(0)
+                total = (cached[0] if cached is not None and cached[1] == n0 and trusted
+                         else ent[0][:n0].double().sum(0))
                 if n0 + k <= cap:
                     # nothing to prune: O(k) appends (list, class matrix with geometric growth, fp64 sum)
                     if ent[0].shape[0] < n0 + k:
@@ -166,6 +190,7 @@ class PrototypeMemory:
                     lst.extend(new)
                     self._mats[label] = ent
                     self._sums[label] = (total + fresh.double().sum(0), n0 + k)
+                    self._stamp(label)
                     self._update_prototype(label)
                     continue
                 rows = torch.cat([ent[0][:n0], fresh])
@@ -234,18 +259,21 @@ class PrototypeMemory:
             ent[1] = n
             self._mats[label] = ent
             self._sums[label] = (sums[i].clone(), n)
+            self._stamp(label)
             self._update_prototype(label)
 
     def _add_one_no_counters(self, example: Example, label: str):
         """add_example minus the rebuild counters (used by add_examples_batch's host fallback)."""
         self.examples[label].append(example)
         n = len(self.examples[label])
+        trusted = self._mirror_valid(label, n - 1)
         ent = self._class_matrix(label, n)
         ent[0][n - 1] = example.embedding
         ent[1] = n
         cached = self._sums.get(label)
-        s = ent[0][: n - 1].double().sum(0) if cached is None or cached[1] != n - 1 else cached[0]
+        s = ent[0][: n - 1].double().sum(0) if cached is None or cached[1] != n - 1 or not trusted else cached[0]
         self._sums[label] = (s + example.embedding.detach().double(), n)
+        self._stamp(label)
         if n > self.config.max_examples_per_class:
             self._prune_examples(label)
         self._update_prototype(label)
@@ -255,9 +283,13 @@ class PrototypeMemory:
         if not examples:
             return
         cached = self._sums.get(label)
-        if cached is None or cached[1] != len(examples):
-            cached = (torch.stack([ex.embedding for ex in examples]).double().sum(0), len(examples))
+        if cached is None or cached[1] != len(examples) or not self._mirror_valid(label, len(examples)):
+            # the list was assigned / edited by the caller: recompute from the list, as the reference always does
+            mat = torch.stack([ex.embedding.detach().to(torch.float32) for ex in examples])
+            cached = (mat.double().sum(0), len(examples))
             self._sums[label] = cached
+            self._mats[label] = [mat, len(examples)]
+            self._stamp(label)
         self.prototypes[label] = (cached[0] / len(examples)).to(torch.float32)
         if label in self.label_to_index:
             self._dirty.add(label)           # row refreshed in place at the next search
@@ -271,12 +303,13 @@ class PrototypeMemory:
             return
         n = len(examples)
         ent = self._mats.get(label)
-        if ent is not None and ent[1] == n:
+        trusted = self._mirror_valid(label, n)
+        if ent is not None and ent[1] == n and trusted:
             emb = ent[0][:n]
         else:
             emb = torch.stack([ex.embedding for ex in examples])
         cached = self._sums.get(label)
-        total = cached[0] if cached is not None and cached[1] == n else emb.double().sum(0)
+        total = cached[0] if cached is not None and cached[1] == n and trusted else emb.double().sum(0)
         mean = (total / n).to(torch.float32)
         dist = torch.linalg.vector_norm(emb - mean, dim=1).numpy()
         order = np.argsort(dist)
@@ -292,8 +325,10 @@ class PrototypeMemory:
         if ent is not None and ent[0].shape[0] >= len(keep):
             ent[0][: len(keep)] = kept
             ent[1] = len(keep)
+            self._mats[label] = ent
         else:
             self._mats.pop(label, None)
+        self._stamp(label)
         assert len(self.examples[label]) <= self.config.max_examples_per_class
 
     # ------------------------------------------------------------------ index maintenance
@@ -426,6 +461,7 @@ class PrototypeMemory:
             self.prototypes.clear()
             self._sums.clear()
             self._mats.clear()
+            self._fps.clear()
             self._dirty.clear()
             self.index = self._new_index()
             self.label_to_index.clear()
@@ -438,4 +474,5 @@ class PrototypeMemory:
         """Forget cached sums when the classifier deletes a label's examples (classifier.py:1396-1399)."""
         self._sums.pop(label, None)
         self._mats.pop(label, None)
+        self._fps.pop(label, None)
         self._dirty.discard(label)

@@ -91,6 +91,12 @@ class MultiLabelAdaptiveClassifier(AdaptiveClassifier):
         return self.default_threshold * 0.2
 
     # ------------------------------------------------------------------------------ prediction
+    def _head_outputs(self, emb: torch.Tensor) -> torch.Tensor:
+        """The reference's inherited predict_batch / _predict_regular call `self.adaptive_head(x)` -- for this head
+        the SIGMOID outputs (multilabel.py:43) -- and then apply F.softmax to them (classifier.py:1342-1345, :432-435):
+        the blend sees softmax(sigmoid(z)), not softmax(z)."""
+        return sigmoid(self.adaptive_head.forward_native(emb))
+
     def _head_probabilities(self, emb: torch.Tensor):
         """sigmoid(head(emb)) for a device batch -> numpy [b, C] (one D2H)."""
         self.adaptive_head.eval()

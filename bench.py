@@ -108,7 +108,48 @@ def time_stages(clf, ids, types, mask, reps=5):
     return out
 
 
-def sweep_roofline(dev, n_rows, full=True):
+def step_parity(clf, hf, ids, types, mask, n_check=64, n_enc=8):
+    """Correctness evidence carried by the bench line itself: the timed step's kNN ids for `n_check` of its queries vs
+    the exact oracle on the same store (bit-exact bar), its encoder output vs transformers fp32 on CPU for `n_enc`
+    sequences and its head logits vs torch CPU (1e-4 bar).  The oracle is the CHECKER here, never the thing timed."""
+    from oracle import c_oracle
+    with torch.no_grad():
+        emb = clf.model.encode_cls(ids, types, mask)
+        S, I, D = clf.memory.search_batch(emb, KNN_K)
+        logits = clf.adaptive_head.forward_native(emb)
+        torch.cuda.synchronize()
+        n = clf.memory.index.ntotal
+        P = clf.memory.index._store[:n, :DIM].cpu().numpy()
+        Q = emb[:n_check].cpu().numpy()
+        oD, oI = c_oracle.knn_l2_topk_batch(P, Q, KNN_K)
+        got = I[:n_check].cpu().numpy()
+        want_emb = torch.nn.functional.normalize(
+            hf(input_ids=ids[:n_enc].cpu(), token_type_ids=types[:n_enc].cpu(), attention_mask=mask[:n_enc].cpu())
+            .last_hidden_state[:, 0, :], dim=1)
+        sd = {k: v.detach().cpu() for k, v in clf.adaptive_head.state_dict().items()}
+        x = emb[:n_check].cpu()
+        h = torch.relu(x @ sd["model.0.weight"].T + sd["model.0.bias"])
+        h = torch.relu(h @ sd["model.3.weight"].T + sd["model.3.bias"])
+        want_logits = h @ sd["model.6.weight"].T + sd["model.6.bias"]
+    return {"checked_queries": int(n_check), "id_mismatches": int((got != oI).sum()),
+            "dist_max_ulp": float(np.max(np.abs(D[:n_check].cpu().numpy() - oD) / np.spacing(np.maximum(oD, np.float32(1e-30))))),
+            "oracle": "oracle/knn_faiss_forms.c exact fp64 (p-q)^2, ties to the lower id, over the full 100k-row store",
+            "encoder_checked_sequences": int(n_enc),
+            "encoder_max_abs_diff_vs_transformers_fp32": float((emb[:n_enc].cpu() - want_emb).abs().max()),
+            "head_max_abs_diff_vs_torch_fp32": float((logits[:n_check].cpu() - want_logits).abs().max())}
+
+
+def sweep_parity(P, n_rows, Q, out_ids, k):
+    """ids of the roofline launch's resident queries vs the chunked exact oracle over the whole store
+    (device -> host in 1M-row chunks, per-chunk batched oracle + merge)."""
+    from oracle import c_oracle
+    Qh = Q[:, :DIM].cpu().numpy()
+    chunks = ((s, P[s:min(n_rows, s + 1_000_000), :DIM].cpu().numpy()) for s in range(0, n_rows, 1_000_000))
+    oD, oI = c_oracle.knn_l2_topk_chunked(chunks, Qh, k)
+    return {"checked_queries": int(Qh.shape[0]), "id_mismatches": int((out_ids.cpu().numpy() != oI).sum()), "rows": int(n_rows), "k": int(k)}
+
+
+def sweep_roofline(dev, n_rows, full=True, parity=False):
     """knn_sweep alone over n_rows x 768: algorithmic bytes / kernel time (HIP events around the kernel).
     The headline entry uses 16 resident queries; `by_resident_queries` lists 1 / 8 / 16 / 32.
     full=False (the per-rank shard sweep at N > 1): only the 16-query measurement."""
@@ -141,8 +182,11 @@ def sweep_roofline(dev, n_rows, full=True):
                 calls.append(c0.elapsed_time(c1))
         finally:
             nv.lib().ac_knn_set_profile_events(None, None)
+        if nq == 16 and parity:
+            par["v"] = sweep_parity(P, n_rows, Q, out[1], k)
         return float(np.mean(times)), float(np.min(times)), float(np.mean(calls)), int(stats[0].item())
 
+    par = {"v": None}
     ms, ms_min, call_ms, nfb = measure(16, 8)
     table = {}
     for nq in ((1, 8, 16, 32) if full else (16,)):
@@ -164,7 +208,7 @@ def sweep_roofline(dev, n_rows, full=True):
             "frac": bytes_alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "knn_sweep<1> (16-query tile)", "rows": n_rows, "dim": DIM, "resident_queries": 16,
             "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": ms, "min_kernel_ms": ms_min,
-            "whole_call_ms": call_ms, "exact_fallback_queries": nfb, "by_resident_queries": table}
+            "whole_call_ms": call_ms, "exact_fallback_queries": nfb, "parity": par["v"], "by_resident_queries": table}
 
 
 def cpu_baseline(hf, clf, rows_dev, sample=2048, chunk=64):
@@ -204,6 +248,7 @@ def main():
     ap.add_argument("--sweep-rows", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the on-box oracle checks (parity fields become null)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -322,9 +367,11 @@ def main():
             n_rows = args.sweep_rows
             while n_rows * DIM * 4 > 0.8 * free and n_rows > 100_000:
                 n_rows //= 2
-            line["roofline"] = sweep_roofline(dev, n_rows)
+            line["roofline"] = sweep_roofline(dev, n_rows, parity=not args.no_parity)
         elif world > 1 and shard_roof is not None:
             line["roofline"] = shard_roof
+        if world == 1 and not args.no_parity:
+            line["parity"] = step_parity(clf, hf, ids, types, mask)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hf, clf, clf.memory.index._store[:NPROTO])
         print(json.dumps(line), flush=True)

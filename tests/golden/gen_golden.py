@@ -259,9 +259,135 @@ def gen_multilabel():
               open(os.path.join(HERE, "multilabel.json"), "w"))
 
 
+def _ref_classifier(cls, mem, labels, head, history, name="stub-encoder"):
+    """A reference classifier object without the HF download: everything the predict / save paths touch."""
+    clf = cls.__new__(cls)
+    clf.config = ref.ModelConfig(); clf.device = "cpu"; clf.memory = mem; clf.embedding_dim = mem.embedding_dim
+    clf.label_to_id = {l: i for i, l in enumerate(labels)}; clf.id_to_label = {i: l for i, l in enumerate(labels)}
+    clf.training_history = dict(history); clf.train_steps = 3
+    clf.strategic_cost_function = None                     # strategic_mode (a property of config + this) -> False
+    clf.adaptive_head = head
+
+    class _Cfg:
+        _name_or_path = name
+        hidden_size = mem.embedding_dim
+
+    class _Model:
+        config = _Cfg()
+    clf.model = _Model()
+    return clf
+
+
+def _queries(n, D, seed, cent_seed, C):
+    Q = synth.synth_unit_rows(n, D, seed)
+    cent = synth.synth_unit_rows(C, D, cent_seed)
+    return np.stack([(q * 0.5 + cent[i % C]) / np.linalg.norm(q * 0.5 + cent[i % C]) for i, q in enumerate(Q)]).astype(np.float32)
+
+
+def gen_multilabel_predict():
+    """The reference's INHERITED predict_batch / _predict_regular on a multi-label classifier: they call
+    self.adaptive_head(x) -- sigmoid outputs for MultiLabelAdaptiveHead -- and softmax THOSE (classifier.py:1342-1345,
+    :432-435), i.e. the blend sees softmax(sigmoid(z)).  Also `predict()` falling through to super().predict
+    (multilabel.py:228-240) when nothing passes the threshold and min_predictions = 0."""
+    from adaptive_classifier.multilabel import MultiLabelAdaptiveClassifier, MultiLabelAdaptiveHead
+    mem, labels = build_memory()
+    torch.manual_seed(7)
+    head = MultiLabelAdaptiveHead(768, 4, [768, 384]).eval()
+    clf = _ref_classifier(MultiLabelAdaptiveClassifier, mem, labels, head, {"c0": 25, "c1": 5, "c2": 25, "c3": 9})
+    clf.default_threshold = 0.5; clf.min_predictions = 1; clf.max_predictions = None; clf.label_thresholds = {}
+    Q = _queries(8, 768, 78, 11, 4)
+    texts = [f"q{i}" for i in range(8)]
+    table = {t: torch.from_numpy(q) for t, q in zip(texts, Q)}
+    clf._get_embeddings = lambda ts: [table[t] for t in ts]
+    out = {"q_seed": 78, "head_seed": 7, "head_init": {k: summarize(v) for k, v in head.state_dict().items()}}
+    out["predict_batch"] = {f"k{k}": clf.predict_batch(texts, k=k) for k in (1, 2, 5)}
+    out["predict_regular"] = {f"k{k}": [ref.AdaptiveClassifier._predict_regular(clf, t, k) for t in texts] for k in (1, 3, 5)}
+    clf.min_predictions = 0; clf.default_threshold = 5.0           # nothing can pass -> predict() uses super().predict
+    out["predict_fallthrough_k3"] = [clf.predict(t, k=3) for t in texts]
+    json.dump(out, open(os.path.join(HERE, "multilabel_predict.json"), "w"))
+
+
+def gen_saved_dirs():
+    """N1: directories in the reference's on-disk formats, WRITTEN BY THE REFERENCE, plus what the reference predicts
+    from the restored state.
+      ref_saved_d64/         written by the reference's own _save_pretrained (config.json, examples.json with the
+                             k-means representatives, model.safetensors; classifier.py:524-628) from a 4-class D=64
+                             classifier whose head went through the reference's _train_adaptive_head
+      adaptive_router_legacy/  the reference's shipped scripts/adaptive_router fixture (older layout: examples inline
+                             in config.json + tensors.safetensors), byte-for-byte
+    expected.json in each: predict_batch / _predict_regular outputs of reference objects restored the way
+    _from_pretrained restores them (classifier.py:864-913)."""
+    import shutil
+    from safetensors.torch import load_file
+    # ---- (a) reference-written directory, D = 64 (small files)
+    D = 64
+    np.random.seed(0)                                    # k-means inside select_representative_examples
+    torch.manual_seed(11)
+    mem, labels = build_memory(C=4, per_class=12, D=D, seed=50)
+    head = ref.AdaptiveHead(D, 4, [D, D // 2])
+    clf = _ref_classifier(ref.AdaptiveClassifier, mem, labels, head, {"c0": 12, "c1": 12, "c2": 4, "c3": 12}, name="stub-encoder-d64")
+    clf._train_adaptive_head(epochs=3)                   # the reference's own loop (classifier.py:1428-1522), torch CPU
+    clf.adaptive_head.eval()
+    out_dir = os.path.join(HERE, "ref_saved_d64")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    clf._save_pretrained(out_dir, include_onnx=False)
+    os.remove(os.path.join(out_dir, "README.md"))        # model card: not part of the format under test
+    Q = _queries(8, D, 79, 51, 4)
+    texts = [f"q{i}" for i in range(8)]
+
+    def restored(save_dir, tensors_name, examples, D_, head_dims):
+        """What _from_pretrained does after constructing the classifier (classifier.py:864-913)."""
+        cfg = json.load(open(os.path.join(save_dir, "config.json")))
+        tensors = load_file(os.path.join(save_dir, tensors_name))
+        m = ref.PrototypeMemory(D_, config=ref.ModelConfig(cfg.get("config")))
+        for label, exs in examples.items():
+            m.examples[label] = [ref.Example.from_dict(e) for e in exs]
+        for label in cfg["label_to_id"]:
+            if f"prototype_{label}" in tensors:
+                m.prototypes[label] = tensors[f"prototype_{label}"]
+        m._restore_from_save()
+        h = ref.AdaptiveHead(D_, len(cfg["label_to_id"]), head_dims)
+        h.load_state_dict({k.replace("adaptive_head_", ""): v for k, v in tensors.items() if k.startswith("adaptive_head_")})
+        hist = cfg.get("training_history") or {l: len(e) * 20 for l, e in examples.items()}
+        c = _ref_classifier(ref.AdaptiveClassifier, m, [cfg["id_to_label"][str(i)] for i in range(len(cfg["id_to_label"]))],
+                            h.eval(), hist, name=cfg["model_name"])
+        c.label_to_id = cfg["label_to_id"]
+        return c
+
+    r = restored(out_dir, "model.safetensors", json.load(open(os.path.join(out_dir, "examples.json"))), D, [D, D // 2])
+    table = {t: torch.from_numpy(q) for t, q in zip(texts, Q)}
+    r._get_embeddings = lambda ts: [table[t] for t in ts]
+    exp = {"q_seed": 79, "cent_seed": 51, "D": D,
+           "predict_batch": {f"k{k}": r.predict_batch(texts, k=k) for k in (1, 2, 4)},
+           "predict": {f"k{k}": [r._predict_regular(t, k) for t in texts] for k in (1, 3)},
+           "training_history": r.training_history,
+           "stats": {"examples_per_class": {l: len(e) for l, e in r.memory.examples.items()}}}
+    json.dump(exp, open(os.path.join(out_dir, "expected.json"), "w"))
+    # ---- (b) the shipped legacy-layout fixture
+    src = "/root/reference/scripts/adaptive_router"
+    dst = os.path.join(HERE, "adaptive_router_legacy")
+    shutil.rmtree(dst, ignore_errors=True)
+    os.makedirs(dst)
+    for f in ("config.json", "tensors.safetensors"):
+        shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+        os.chmod(os.path.join(dst, f), 0o644)
+    cfg = json.load(open(os.path.join(dst, "config.json")))
+    r = restored(dst, "tensors.safetensors", cfg["examples"], 768, [768, 384])
+    emb = [np.asarray(e["embedding"], np.float32) for l in ("HIGH", "LOW") for e in cfg["examples"][l]]
+    texts = [f"r{i}" for i in range(len(emb))]
+    table = {t: torch.from_numpy(q) for t, q in zip(texts, emb)}
+    r._get_embeddings = lambda ts: [table[t] for t in ts]
+    exp = {"predict_batch": {f"k{k}": r.predict_batch(texts, k=k) for k in (1, 2)},
+           "predict": {f"k{k}": [r._predict_regular(t, k) for t in texts] for k in (1, 2)},
+           "training_history": r.training_history}
+    json.dump(exp, open(os.path.join(dst, "expected.json"), "w"))
+
+
 if __name__ == "__main__":
     gen_router(); gen_knn(); gen_memory_and_blend(); gen_head_step(); gen_ewc(); gen_multilabel()
+    gen_multilabel_predict(); gen_saved_dirs()
     print("golden fixtures written to", HERE)
-    for f in sorted(os.listdir(HERE)):
-        print(f"  {f:28s} {os.path.getsize(os.path.join(HERE, f)):8d} B")
+    for dp, _, files in sorted(os.walk(HERE)):
+        for f in sorted(files):
+            print(f"  {os.path.relpath(os.path.join(dp, f), HERE):44s} {os.path.getsize(os.path.join(dp, f)):8d} B")
 

@@ -1,6 +1,7 @@
 """Shared test helpers: an offline tokenizer stub and a small random BERT."""
 import zlib
 
+import numpy as np
 import torch
 
 
@@ -28,3 +29,21 @@ class HashTokenizer:
 def small_bert(hidden=128, layers=2, heads=2, inter=512, vocab=2000, seed=0):
     from oracle import bert_oracle
     return bert_oracle.make_bert(hidden, layers, heads, inter, vocab=vocab, seed=seed)
+
+
+def near_tie_store(n, D, seed, clusters=50, noise=2e-4):
+    """Rows that cluster tightly around `clusters` unit centres (thousands of near-equal distances per query: the
+    norm/dot fp32 forms reorder them), a third of them copies of other rows with three coordinates moved by one ulp
+    (pairs whose exact distances differ by ~1e-9 relative: below what ANY fp32 summation resolves).  Returns (P, centres)."""
+    from oracle import synth
+    centres = synth.synth_unit_rows(clusters, D, seed)
+    rng = np.random.default_rng(seed)
+    P = centres[rng.integers(0, clusters, n)] + (rng.standard_normal((n, D)) * noise).astype(np.float32)
+    P = np.ascontiguousarray(P, dtype=np.float32)
+    src = rng.integers(0, n, n // 3)
+    dst = rng.permutation(n)[: n // 3]
+    P[dst] = P[src]
+    for t in range(3):
+        c = rng.integers(0, D, n // 3)
+        P[dst, c] = np.nextafter(P[dst, c], np.float32(np.inf if t % 2 else -np.inf))
+    return P, centres

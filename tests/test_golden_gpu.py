@@ -151,3 +151,98 @@ def test_memory_and_both_blend_formulas(cuda_dev):
         k = int(key[1:])
         for got, w in zip(clf.predict_batch(texts, k=k), want):
             _same_preds(got, w)
+
+
+def test_multilabel_inherited_predict_paths_blend_softmax_of_sigmoid(cuda_dev):
+    """The reference's inherited predict_batch / _predict_regular on a multi-label classifier softmax the head's
+    SIGMOID outputs (classifier.py:1342-1345, :432-435; multilabel.py:43).  Fixture: reference outputs
+    (tests/golden/multilabel_predict.json), incl. predict() falling through to super().predict."""
+    from adaptive_classifier import MultiLabelAdaptiveClassifier, MultiLabelAdaptiveHead
+    g = json.load(open(os.path.join(G, "multilabel_predict.json")))
+    base, mem, texts, _ = _golden_classifier(cuda_dev)
+    cent = synth.synth_unit_rows(4, 768, 11)
+    Q = synth.synth_unit_rows(8, 768, g["q_seed"])
+    Q = np.stack([(q * 0.5 + cent[i % 4]) / np.linalg.norm(q * 0.5 + cent[i % 4]) for i, q in enumerate(Q)]).astype(np.float32)
+    clf = MultiLabelAdaptiveClassifier.__new__(MultiLabelAdaptiveClassifier)
+    clf.__dict__.update(base.__dict__)
+    torch.manual_seed(g["head_seed"])
+    head = MultiLabelAdaptiveHead(768, 4, [768, 384])
+    for k, v in head.state_dict().items():                              # same init as the reference's head
+        flat = v.detach().reshape(-1).double().numpy()
+        s = g["head_init"][k]
+        assert np.abs(flat[np.asarray(s["idx"]) % flat.size] - np.asarray(s["vals"])).max() < 1e-9
+    clf.adaptive_head = head.to(cuda_dev).eval()
+    clf.default_threshold, clf.min_predictions, clf.max_predictions, clf.label_thresholds = 0.5, 1, None, {}
+    table = {t: torch.from_numpy(q) for t, q in zip(texts, Q)}
+    clf._embed_device = lambda ts: torch.stack([table[t] for t in ts]).to(cuda_dev)
+    for key, want in g["predict_batch"].items():
+        for got, w in zip(clf.predict_batch(texts, k=int(key[1:])), want):
+            _same_preds(got, w)
+    for key, want in g["predict_regular"].items():
+        for t, w in zip(texts, want):
+            _same_preds(clf._predict_regular(t, int(key[1:])), w)
+    clf.min_predictions, clf.default_threshold = 0, 5.0                 # nothing passes -> super().predict
+    for t, w in zip(texts, g["predict_fallthrough_k3"]):
+        _same_preds(clf.predict(t, k=3), w)
+
+
+class _StubEncoder:
+    """Stands in for the HF encoder when a saved classifier is loaded offline (no weights to download)."""
+
+    def __init__(self, hidden, name):
+        from adaptive_classifier.encoder import _Cfg
+        self.config = _Cfg(hidden, name)
+
+
+def _queries(n, D, seed, cent_seed, C):
+    Q = synth.synth_unit_rows(n, D, seed)
+    cent = synth.synth_unit_rows(C, D, cent_seed)
+    return np.stack([(q * 0.5 + cent[i % C]) / np.linalg.norm(q * 0.5 + cent[i % C]) for i, q in enumerate(Q)]).astype(np.float32)
+
+
+def test_load_directory_written_by_the_reference(cuda_dev):
+    """N1: tests/golden/ref_saved_d64 was written by the REFERENCE's _save_pretrained (classifier.py:524-628:
+    config.json sorted keys, examples.json with the k-means representatives, model.safetensors).  AdaptiveClassifier.load
+    restores it and predicts what the reference predicts from the same restored state (expected.json)."""
+    from adaptive_classifier import AdaptiveClassifier
+    d = os.path.join(G, "ref_saved_d64")
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    D = exp["D"]
+    clf = AdaptiveClassifier.load(d, device="cuda:0", encoder=_StubEncoder(D, "stub-encoder-d64"), tokenizer=None)
+    assert clf.embedding_dim == D and clf.label_to_id == {"c0": 0, "c1": 1, "c2": 2, "c3": 3}
+    assert clf.training_history == exp["training_history"] and clf.train_steps == 4    # 3 + the reference's training call
+    assert {l: len(e) for l, e in clf.memory.examples.items()} == exp["stats"]["examples_per_class"]
+    assert clf.memory.index.ntotal == 4 and clf.adaptive_head.model[-1].out_features == 4
+    Q = torch.from_numpy(_queries(8, D, exp["q_seed"], exp["cent_seed"], 4)).to(cuda_dev)
+    for key, want in exp["predict_batch"].items():
+        for got, w in zip(clf.predict_embeddings(Q, int(key[1:])), want):
+            _same_preds(got, w)
+    for key, want in exp["predict"].items():
+        for i, w in enumerate(want):
+            S, I, P = clf._device_stage(Q[i:i + 1], len(clf.id_to_label))
+            _same_preds(clf._finish(S, I, P, int(key[1:]), regular=True, b=1)[0], w)
+    # and a loaded classifier keeps learning: add_embeddings on top of the restored state
+    extra = _queries(6, D, 80, 51, 4)
+    clf.add_embeddings([f"n{i}" for i in range(6)], [torch.from_numpy(e) for e in extra], [f"c{i % 4}" for i in range(6)])
+    assert sum(len(e) for e in clf.memory.examples.values()) == sum(exp["stats"]["examples_per_class"].values()) + 6
+
+
+def test_load_reference_legacy_router_layout(cuda_dev):
+    """N1: the reference's shipped scripts/adaptive_router fixture (older layout: examples inline in config.json +
+    tensors.safetensors; 768-d, trained head), byte-for-byte under tests/golden/adaptive_router_legacy."""
+    from adaptive_classifier import AdaptiveClassifier
+    d = os.path.join(G, "adaptive_router_legacy")
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    cfg = json.load(open(os.path.join(d, "config.json")))
+    clf = AdaptiveClassifier.load(d, device="cuda:0", encoder=_StubEncoder(768, cfg["model_name"]), tokenizer=None)
+    assert clf.label_to_id == {"HIGH": 0, "LOW": 1} and clf.train_steps == 20
+    assert clf.training_history == exp["training_history"] == {"HIGH": 100, "LOW": 100}        # :909-913 estimate
+    emb = np.stack([np.asarray(e["embedding"], np.float32) for l in ("HIGH", "LOW") for e in cfg["examples"][l]])
+    Q = torch.from_numpy(emb).to(cuda_dev)
+    for key, want in exp["predict_batch"].items():
+        for got, w in zip(clf.predict_embeddings(Q, int(key[1:])), want):
+            _same_preds(got, w)
+    for key, want in exp["predict"].items():
+        for i, w in enumerate(want):
+            S, I, P = clf._device_stage(Q[i:i + 1], 2)
+            _same_preds(clf._finish(S, I, P, int(key[1:]), regular=True, b=1)[0], w)

@@ -179,11 +179,6 @@ def test_ewc_fisher_penalty_and_fused_step(cuda_dev):
         assert (tr.flat.cpu() - head_oracle.flat(ref)).abs().max().item() < 5e-5
 
 
-def test_ewc_generic_module_contract():
-    """The EWC class on an arbitrary nn.Module (tests/test_ewc.py fixtures) -- runs on CPU."""
-    pass
-
-
 def _dropout_keep_np(seed, n_rows, n_cols, p):
     """numpy port of ac::dropout_keep (csrc/common.h): keep iff u(seed, row*N+col) >= p."""
     M = np.uint64(0xFFFFFFFFFFFFFFFF)

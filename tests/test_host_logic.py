@@ -320,3 +320,94 @@ def test_add_examples_batch_host_fallback_equals_add_example():
             assert [e.text for e in a.examples[l]] == [e.text for e in b.examples[l]]
             assert torch.allclose(a.prototypes[l], b.prototypes[l], atol=1e-6)
         assert a.updates_since_rebuild == b.updates_since_rebuild
+
+
+def test_ewc_generic_module_contract():
+    """The EWC class on an arbitrary nn.Module (the reference's tests/test_ewc.py:34-84,128-153 scenarios: nn.Linear
+    model, dataset sizes that leave a 1-sample last batch, penalty after p += 0.1 with and without batch_size), on CPU
+    through the generic autograd route -- and equal to the reference's formula evaluated by hand with the same RNG."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from adaptive_classifier.ewc import EWC
+
+    class SimpleModel(nn.Module):
+        def __init__(self, input_dim=10, num_classes=3):
+            super().__init__()
+            self.fc = nn.Linear(input_dim, num_classes)
+
+        def forward(self, x):
+            return self.fc(x)
+
+    for size in (1, 31, 32, 33, 64, 65, 100):                       # test_ewc.py:56-84
+        torch.manual_seed(size)
+        model = SimpleModel()
+        ds = torch.utils.data.TensorDataset(torch.randn(size, 10), torch.randint(0, 3, (size,)))
+        # the reference algorithm by hand (ewc.py:51-94), consuming the global RNG the same way
+        state = torch.get_rng_state()
+        loader = torch.utils.data.DataLoader(ds, batch_size=32, shuffle=True)
+        want = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+        for xb, _ in loader:
+            model.zero_grad()
+            out = model(xb)
+            y = torch.multinomial(F.softmax(out, dim=1), 1).squeeze(-1)
+            F.nll_loss(F.log_softmax(out, dim=1), y).backward()
+            for n, p in model.named_parameters():
+                want[n] += p.grad.data ** 2 / len(loader)
+        model.zero_grad()
+        torch.set_rng_state(state)
+        ewc = EWC(model, ds, device="cpu", ewc_lambda=100.0)
+        assert set(ewc.fisher_info) == set(ewc.old_params) == {"fc.weight", "fc.bias"}
+        for n in want:
+            assert torch.equal(ewc.fisher_info[n], want[n])
+            assert torch.equal(ewc.old_params[n], dict(model.named_parameters())[n].data)
+        assert ewc.ewc_loss(batch_size=32).item() == 0.0            # unchanged parameters: penalty exactly 0
+        for p_ in model.parameters():                               # test_ewc.py:140-153
+            p_.data += 0.1
+        loss = ewc.ewc_loss()
+        loss_n = ewc.ewc_loss(batch_size=32)
+        ref = 100.0 * sum((want[n] * (p_ - ewc.old_params[n]) ** 2).sum() for n, p_ in model.named_parameters())
+        assert loss.item() > 0 and abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
+        assert abs(loss_n.item() - loss.item() / 32) <= 1e-6 * abs(loss.item())
+        loss.backward()                                             # autograd reaches the live parameters
+        assert all(p_.grad is not None and p_.grad.abs().sum() > 0 for p_ in model.parameters())
+
+
+def test_mirrors_follow_direct_edits_of_examples_with_unchanged_length():
+    """`memory.examples` is public and the reference's callers edit it directly.  Replacing entries while keeping
+    the list LENGTH must not leave the cached fp64 sums / class matrices stale: the next prototype update and prune
+    use the edited list, exactly like the reference, which always recomputes from the list (memory.py:138-159)."""
+    from adaptive_classifier import Example, ModelConfig, PrototypeMemory
+    from oracle import synth
+    D = 32
+    X = torch.from_numpy(synth.synth_unit_rows(40, D, 5))
+    mem = PrototypeMemory(D, ModelConfig({"max_examples_per_class": 12}))
+    for i in range(10):
+        mem.add_example(Example(f"t{i}", "a", X[i].clone()), "a")
+    assert torch.allclose(mem.prototypes["a"], X[:10].mean(0), atol=1e-6)
+    # caller swaps two stored examples for new ones: same length, different content
+    mem.examples["a"][3] = Example("new3", "a", X[20].clone())
+    mem.examples["a"][7].embedding = X[21].clone()
+    want_rows = [X[i] for i in range(10)]
+    want_rows[3], want_rows[7] = X[20], X[21]
+    mem._update_prototype("a")
+    assert torch.allclose(mem.prototypes["a"], torch.stack(want_rows).mean(0), atol=1e-6)
+    # the next add (per-example and batched paths) builds on the edited list, not on the stale mirror
+    mem.add_example(Example("t10", "a", X[10].clone()), "a")
+    want_rows.append(X[10])
+    assert torch.allclose(mem.prototypes["a"], torch.stack(want_rows).mean(0), atol=1e-6)
+    mem.examples["a"][0] = Example("new0", "a", X[22].clone())
+    want_rows[0] = X[22]
+    mem.add_examples_batch([Example("t11", "a", X[11].clone())], ["a"])
+    want_rows.append(X[11])
+    assert torch.allclose(mem.prototypes["a"], torch.stack(want_rows).mean(0), atol=1e-6)
+    # ... and a prune after an edit keeps the 12 closest to the mean of the EDITED list
+    mem.examples["a"][1] = Example("far", "a", (-X[1]).clone())
+    want_rows[1] = -X[1]
+    mem.add_example(Example("t12", "a", X[12].clone()), "a")
+    want_rows.append(X[12])
+    allr = torch.stack(want_rows)
+    dist = (allr - allr.mean(0)).norm(dim=1)
+    keep = torch.argsort(dist)[:12]
+    assert sorted(e.text for e in mem.examples["a"]) == sorted(["new0", "far", "t2", "new3", "t4", "t5", "t6", "t7", "t8",
+                                                                 "t9", "t10", "t11", "t12"][i] for i in keep.tolist())
+    assert torch.allclose(mem.prototypes["a"], allr[keep].mean(0), atol=1e-6)

@@ -1,0 +1,143 @@
+"""Parity of the HIP kNN path AT THE BASELINE.json SHAPES, through the C ABI:
+
+  configs[1]  100k x 768, k = 16, nq = 256            every query vs the exact oracle
+  configs[2]  10M x 768, k = 32, nq = 4096 (one GPU)  64-query subset vs the chunked exact oracle (device -> host in
+                                                      1M-row chunks, per-chunk batched oracle + topk_merge) and the
+                                                      size-independent properties of the full 4096-query call
+  configs[4]  2M x 1024, k = 32, nq = 1024            64-query subset vs the exact oracle
+
+plus the second oracles: every id disagreement between the HIP result (= exact-definition ids) and each fp32
+faiss-form restatement (oracle/knn_faiss_forms.c) is a provable fp32 near-tie.
+
+Bar: ids bit-exact vs the exact oracle; distances = the exact squared distance rounded to fp32 (1 ulp: the fp64
+summation order differs between device and host).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import near_tie_store
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_close(a, b):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    return np.all(np.abs(a - b) <= np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)))
+
+
+def _device_chunks(P, N, D, rows=1_000_000):
+    """Yield (row_offset, float32 [n, D] host block) over a device store (chunked D2H)."""
+    for s in range(0, N, rows):
+        e = min(N, s + rows)
+        yield s, P[s:e, :D].cpu().numpy()
+
+
+def _properties(Dd, Id, k):
+    d = Dd.cpu().numpy()
+    i = Id.cpu().numpy()
+    assert np.all(np.diff(d, axis=1) >= 0), "distances not ascending"
+    srt = np.sort(i, axis=1)
+    assert np.all(srt[:, 1:] != srt[:, :-1]) and np.all(i >= 0), "duplicate or padded ids"
+    return d, i
+
+
+def test_cfg1_100k_k16_nq256_all_queries(cuda_dev):
+    from adaptive_classifier import index as ix
+    from oracle import c_oracle
+    N, D, nq, k = 100_000, 768, 256, 16
+    P = ix.synth_unit_rows(N, D, 1, device=cuda_dev)
+    Q = ix.synth_unit_rows(nq, D, 2, device=cuda_dev)
+    stats = torch.zeros(4, dtype=torch.int32, device=cuda_dev)
+    Dd, Id = ix.knn_l2_topk(P, N, D, Q, k, stats=stats)
+    d, i = _properties(Dd, Id, k)
+    Ph, Qh = P[:, :D].cpu().numpy(), Q[:, :D].cpu().numpy()
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, k)
+    assert np.array_equal(i, oI), f"{(i != oI).sum()} id mismatches of {i.size}"
+    assert _ulp_close(d, oD)
+    assert int(stats[0].item()) == 0                                 # no exact-fallback query on the benchmark data
+    # second oracles on a 32-query subset: HIP ids vs every fp32 faiss form -- disagreements only inside near-ties
+    sub = slice(0, 32)
+    report = {}
+    for name in c_oracle.FORMS:
+        _, If = c_oracle.knn_form_topk(Ph, Qh[sub], k, name)
+        n_mis, n_unexplained = c_oracle.classify_disagreements(Ph, Qh[sub], i[sub], If, c_oracle.form_error_bound(Ph, Qh[sub], name))
+        report[name] = n_mis
+        assert n_unexplained == 0, (name, n_mis, n_unexplained)
+    print("cfg1 id disagreements HIP vs fp32 faiss forms (all provable near-ties):", report)
+
+
+def test_near_tie_store_hip_equals_exact_and_forms_differ_only_in_near_ties(cuda_dev):
+    """A store built to be full of fp32-unresolvable near-ties: the HIP path still returns the exact-definition ids
+    (certificate + fp64 re-rank / fallback), and each fp32 form's disagreements with it are all provable near-ties."""
+    from adaptive_classifier import index as ix
+    from oracle import c_oracle, synth
+    D, k = 768, 16
+    Ph, centres = near_tie_store(60_000, D, 7)
+    Qh = (centres[:40] + synth.synth_unit_rows(40, D, 8) * 1e-3).astype(np.float32)
+    P = torch.from_numpy(Ph).to(cuda_dev)
+    Q = torch.from_numpy(Qh).to(cuda_dev)
+    stats = torch.zeros(4, dtype=torch.int32, device=cuda_dev)
+    Dd, Id = ix.knn_l2_topk(P, Ph.shape[0], D, Q, k, stats=stats)
+    i = Id.cpu().numpy()
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, k)
+    assert np.array_equal(i, oI)
+    assert _ulp_close(Dd.cpu().numpy(), oD)
+    total = 0
+    for name in ("seq_scalar", "seq_avx2_fma", "seq_avx512_fma", "blas_scalar", "blas_avx2_fma", "blas_avx512_fma"):
+        _, If = c_oracle.knn_form_topk(Ph, Qh, k, name)
+        n_mis, n_unexplained = c_oracle.classify_disagreements(Ph, Qh, i, If, c_oracle.form_error_bound(Ph, Qh, name))
+        assert n_unexplained == 0, (name, n_mis, n_unexplained)
+        total += n_mis
+    assert total > 0                                                 # the criterion was exercised
+    print("near-tie store: exact-fallback queries =", int(stats[0].item()), " form disagreements =", total)
+
+
+def test_cfg2_10M_k32_nq4096_subset_and_properties(cuda_dev):
+    from adaptive_classifier import index as ix
+    from oracle import c_oracle
+    N, D, nq, k = 10_000_000, 768, 4096, 32
+    free, _ = torch.cuda.mem_get_info(cuda_dev)
+    if free < 40e9:
+        pytest.skip("needs 40 GB of free HBM")
+    P = ix.synth_unit_rows(N, D, 1, device=cuda_dev)
+    Q = ix.synth_unit_rows(nq, D, 2, device=cuda_dev)
+    stats = torch.zeros(4, dtype=torch.int32, device=cuda_dev)
+    Dd, Id = ix.knn_l2_topk(P, N, D, Q, k, stats=stats)
+    d, i = _properties(Dd, Id, k)
+    assert int(stats[0].item()) == 0
+    assert i.max() < N
+    # shard consistency: top-k of the whole store == merge of the halves' top-k (the N > 1 path, logically)
+    h = N // 2
+    D0, I0 = ix.knn_l2_topk(P[:h], h, D, Q, k)
+    D1, I1 = ix.knn_l2_topk(P[h:], N - h, D, Q, k, row_offset=h)
+    Dm, Im = ix.topk_merge(torch.stack([D0, D1]), torch.stack([I0, I1]))
+    assert torch.equal(Im, Id) and torch.equal(Dm, Dd)
+    del D0, I0, D1, I1, Dm, Im
+    # 64-query subset (every 64th query: one per pair of 32-query tiles) vs the chunked exact oracle
+    sel = np.arange(0, nq, 64)
+    Qh = Q[:, :D].cpu().numpy()[sel]
+    oD, oI = c_oracle.knn_l2_topk_chunked(_device_chunks(P, N, D), Qh, k)
+    assert np.array_equal(i[sel], oI), f"{(i[sel] != oI).sum()} id mismatches"
+    assert _ulp_close(d[sel], oD)
+    # the HBM-bound configuration the roofline is quoted on (16 resident queries, knn_sweep<1>) gives the same ids
+    D16, I16 = ix.knn_l2_topk(P, N, D, Q[:16], k)
+    assert torch.equal(I16, Id[:16]) and torch.equal(D16, Dd[:16])
+
+
+def test_cfg4_2M_x1024_k32_nq1024_subset(cuda_dev):
+    from adaptive_classifier import index as ix
+    from oracle import c_oracle
+    N, D, nq, k = 2_000_000, 1024, 1024, 32
+    P = ix.synth_unit_rows(N, D, 1, device=cuda_dev)
+    Q = ix.synth_unit_rows(nq, D, 2, device=cuda_dev)
+    stats = torch.zeros(4, dtype=torch.int32, device=cuda_dev)
+    Dd, Id = ix.knn_l2_topk(P, N, D, Q, k, stats=stats)
+    d, i = _properties(Dd, Id, k)
+    assert int(stats[0].item()) == 0
+    sel = np.arange(0, nq, 16)
+    Qh = Q[:, :D].cpu().numpy()[sel]
+    oD, oI = c_oracle.knn_l2_topk_chunked(_device_chunks(P, N, D, rows=500_000), Qh, k)
+    assert np.array_equal(i[sel], oI), f"{(i[sel] != oI).sum()} id mismatches"
+    assert _ulp_close(d[sel], oD)

@@ -186,3 +186,41 @@ def test_knn_randomised_shapes(cuda_dev):
         if rng.random() < 0.3:
             Q[0] = P[0]
         _check(P, Q, k, cuda_dev, row_offset=int(rng.choice([0, 7, 1 << 40])))
+
+
+def test_index_remove_ids_compacts_like_faiss(cuda_dev):
+    """HipFlatL2Index.remove_ids (the faiss protocol method memory.py:156-159 calls before re-adding a prototype):
+    rows compact (later rows shift down), ntotal / return value follow faiss, and searches after remove + add see
+    exactly the store the oracle shim holds after the same operations."""
+    from adaptive_classifier.index import HipFlatL2Index
+    from oracle import faiss_shim, synth
+    D = 96
+    X = synth.synth_unit_rows(300, D, 21)
+    Q = synth.synth_unit_rows(7, D, 22)
+    idx, ref = HipFlatL2Index(D, device=cuda_dev), faiss_shim.IndexFlatL2(D)
+    for blk in (X[:100], X[100:250]):
+        idx.add(blk)
+        ref.add(blk)
+    assert idx.remove_ids(torch.tensor([5])) == ref.remove_ids(np.array([5])) == 1        # the call shape memory.py:158 uses
+    assert idx.ntotal == ref.ntotal == 249
+    ids = np.array([0, 17, 17, 248, 400, -3, 100])                                         # duplicates / out of range ignored
+    assert idx.remove_ids(ids) == ref.remove_ids(ids) == 4
+    assert idx.ntotal == ref.ntotal == 245
+    idx.add(X[250:])                                                                       # re-add after compaction
+    ref.add(X[250:])
+    d, i = idx.search(Q, 12)
+    rd, ri = ref.search(Q, 12)
+    assert np.array_equal(i, ri) and _ulp_close(d, rd)
+    assert np.array_equal(idx._store[: idx.ntotal, :D].cpu().numpy(), ref._x)              # same rows, same order
+    # removing everything leaves an empty, still usable index
+    assert idx.remove_ids(np.arange(idx.ntotal)) == 295 and idx.ntotal == 0
+    idx.add(X[:3])
+    d, i = idx.search(Q[:1], 3)
+    assert sorted(i[0].tolist()) == [0, 1, 2]
+    # pending (not yet uploaded) rows are removable too
+    idx2 = HipFlatL2Index(D, device=cuda_dev)
+    idx2.add(X[:10])
+    assert idx2.remove_ids([2, 3]) == 2 and idx2.ntotal == 8
+    d2, i2 = idx2.search(Q, 4)
+    ref2 = faiss_shim.IndexFlatL2(D); ref2.add(X[:10]); ref2.remove_ids([2, 3])
+    assert np.array_equal(i2, ref2.search(Q, 4)[1])
