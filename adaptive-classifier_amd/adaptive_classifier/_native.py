@@ -74,8 +74,11 @@ _SIGNATURES = {
     "ac_knn_l2_topk_workspace": (c_int, [c_int64, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "ac_knn_l2_topk": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64,
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "ac_knn_l2_topk_x": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "ac_knn_set_profile_events": (c_int, [c_void_p, c_void_p]),
     "ac_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ac_topk_merge_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ac_rows_to_class": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "ac_proto_scores": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ac_synth_unit_rows": (c_int, [c_void_p, c_int64, c_int64, c_int, c_uint64, c_int64, c_void_p]),

@@ -23,10 +23,11 @@ def knn_workspace_bytes(N, D, nq, k):
     return b.value
 
 
-def knn_l2_topk(P, N, D, Q, k, row_offset=0, out=None, workspace=None, stats=None):
+def knn_l2_topk(P, N, D, Q, k, row_offset=0, out=None, workspace=None, stats=None, exact_out=None):
     """Low-level device call.  P: [>=N, ldP] fp32 cuda tensor, Q: [nq, >=D] fp32 cuda tensor.
 
     Returns (dist fp32 [nq,k], ids int64 [nq,k]) on the same device.  Asynchronous.
+    exact_out: optional float64 [nq,k] cuda tensor that receives the exact fp64 distances (shard merges).
     """
     nv.require_gpu()
     assert P.dtype == torch.float32 and Q.dtype == torch.float32 and P.is_cuda and Q.is_cuda
@@ -42,12 +43,19 @@ def knn_l2_topk(P, N, D, Q, k, row_offset=0, out=None, workspace=None, stats=Non
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = nv.lib().ac_knn_l2_topk(
+        rc = nv.lib().ac_knn_l2_topk_x(
             nv.ptr(P), N, P.stride(0), D, nv.ptr(Q), nq, Q.stride(0), k, row_offset,
-            nv.ptr(outD), nv.ptr(outI), nv.ptr(workspace), workspace.numel(),
+            nv.ptr(outD), nv.ptr(exact_out), nv.ptr(outI), nv.ptr(workspace), workspace.numel(),
             nv.ptr(stats), nv.stream_ptr(dev))
-    nv.check(rc, "ac_knn_l2_topk")
+    nv.check(rc, "ac_knn_l2_topk_x")
     return outD, outI
+
+
+def knn_l2_topk_exact(P, N, D, Q, k, row_offset=0, workspace=None, stats=None):
+    """(exact fp64 dist [nq,k], ids [nq,k]): what a row shard contributes to a sharded search."""
+    ex = torch.empty((Q.shape[0], k), dtype=torch.float64, device=Q.device)
+    _, I = knn_l2_topk(P, N, D, Q, k, row_offset=row_offset, workspace=workspace, stats=stats, exact_out=ex)
+    return ex, I
 
 
 class HipFlatL2Index:
@@ -192,16 +200,20 @@ class HipFlatL2Index:
 
 
 def topk_merge(D_in, I_in):
-    """[shards, nq, k] per-shard ascending lists -> global (dist, ids) [nq, k] (ac_topk_merge)."""
+    """[shards, nq, k] per-shard ascending lists -> global (dist fp32, ids) [nq, k].  float64 input (the shards' exact
+    distances, `knn_l2_topk_exact`) is merged by (exact distance, id) -- ac_topk_merge_f64, what a sharded search needs to
+    equal the unsharded one bit for bit; float32 input by (fp32 distance, id) -- ac_topk_merge."""
     nv.require_gpu()
     S, nq, k = D_in.shape
     D_in = D_in.contiguous()
     I_in = I_in.contiguous()
     outD = torch.empty((nq, k), dtype=torch.float32, device=D_in.device)
     outI = torch.empty((nq, k), dtype=torch.int64, device=D_in.device)
+    fn, name = ((nv.lib().ac_topk_merge_f64, "ac_topk_merge_f64") if D_in.dtype == torch.float64
+                else (nv.lib().ac_topk_merge, "ac_topk_merge"))
+    assert D_in.dtype in (torch.float32, torch.float64)
     with torch.cuda.device(D_in.device):
-        nv.check(nv.lib().ac_topk_merge(nv.ptr(D_in), nv.ptr(I_in), S, nq, k, nv.ptr(outD), nv.ptr(outI),
-                                        nv.stream_ptr(D_in.device)), "ac_topk_merge")
+        nv.check(fn(nv.ptr(D_in), nv.ptr(I_in), S, nq, k, nv.ptr(outD), nv.ptr(outI), nv.stream_ptr(D_in.device)), name)
     return outD, outI
 
 

@@ -3,10 +3,13 @@
   partition   prototype rows P[g*N/G : (g+1)*N/G] live on rank g (contiguous; global id = local id +
               row_offset); the head and encoder weights are replicated; query batches are data parallel.
   exchange    1. all_gather the ranks' query blocks  [b/G, D] -> [b, D]        (RCCL over xGMI)
-              2. local `ac_knn_l2_topk` of all b queries against the rank's shard
-              3. all_gather the per-shard (dist fp32, id int64) [b, k] lists
-              4. `ac_topk_merge` -> global top-k by (distance, id) on every rank
-The messages are tiny (cfg2: 1.6 MB per rank and step), i.e. latency bound; there is no other
+              2. local `ac_knn_l2_topk_x` of all b queries against the rank's shard
+              3. all_gather the per-shard (EXACT fp64 dist, id int64) [b, k] lists
+              4. `ac_topk_merge_f64` -> global top-k by (exact distance, id) on every rank, distances rounded to fp32
+              (fp64 on the wire: two candidates on different shards whose exact distances differ but round to the same
+              fp32 value must be ordered by distance, not by id, or the sharded result differs from the unsharded one --
+              measured: ~40 of 131k neighbour pairs at 10M x 768, 4096 queries)
+The messages are tiny (cfg2: 2.1 MB per rank and step), i.e. latency bound; there is no other
 collective on the data path.  One process per GPU, torch.distributed backend "nccl" (= RCCL).
 
 The local search and the merge are injected so that the orchestration (offsets, gather layout,
@@ -30,7 +33,7 @@ class ShardedSearch:
         self.group = group
         if local_search is None or merge is None:
             from . import index as ix
-            local_search = local_search or (lambda P, n, D, Q, k, off: ix.knn_l2_topk(P, n, D, Q, k, row_offset=off))
+            local_search = local_search or (lambda P, n, D, Q, k, off: ix.knn_l2_topk_exact(P, n, D, Q, k, row_offset=off))
             merge = merge or ix.topk_merge
         self._search, self._merge = local_search, merge
         self._ws = None
@@ -64,8 +67,9 @@ class ShardedSearch:
         return g.reshape(-1, q_local.shape[-1])
 
     def search(self, queries, k):
-        """queries [b, D] (identical on all ranks) -> global (dist [b,k], ids [b,k]) on every rank."""
+        """queries [b, D] (identical on all ranks) -> global (dist fp32 [b,k], ids [b,k]) on every rank.
+        The local search returns EXACT fp64 distances; they are what travels and what the merge orders by."""
         D_loc, I_loc = self._search(self.rows, self.n_local, self.dim, queries, k, self.row_offset)
         if self.world == 1:
-            return D_loc, I_loc
+            return D_loc.to(torch.float32), I_loc
         return self._merge(self._all_gather(D_loc), self._all_gather(I_loc))

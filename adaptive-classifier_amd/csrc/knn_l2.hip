@@ -392,6 +392,7 @@ struct MergeParams {
     const int32_t* part_i;
     const float* part_maxnorm;
     float* outD;
+    double* outD64;   // optional: the exact fp64 distances next to their fp32 roundings (shard merges order by these)
     int64_t* outI;
     int32_t* flags;   // [nq] 0 = certified; slot + 1 = exact fallback over fb_S row slabs; -1 = fallback, no slot
     int32_t* stats;   // optional
@@ -546,12 +547,14 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
         }
         if (rank < kout) {
             prm.outD[(size_t)q * kout + rank] = (float)dt;
+            if (prm.outD64) prm.outD64[(size_t)q * kout + rank] = dt;
             prm.outI[(size_t)q * kout + rank] = (int64_t)it + prm.row_offset;
         }
         if (rank == kout - 1) dmisc[1] = dt;
     }
     for (int t = ns + tid; t < kout; t += kMergeThreads) {   // k > N: faiss-style padding
         prm.outD[(size_t)q * kout + t] = FLT_MAX;
+        if (prm.outD64) prm.outD64[(size_t)q * kout + t] = INFINITY;
         prm.outI[(size_t)q * kout + t] = -1;
     }
     __syncthreads();
@@ -680,6 +683,7 @@ __global__ __launch_bounds__(kFbThreads) void knn_exact_fallback(MergeParams prm
     if (direct) {
         for (int t = tid; t < k; t += kFbThreads) {
             prm.outD[(size_t)q * k + t] = t < n ? (float)ld[t] : FLT_MAX;
+            if (prm.outD64) prm.outD64[(size_t)q * k + t] = t < n ? ld[t] : (double)INFINITY;
             prm.outI[(size_t)q * k + t] = t < n ? (int64_t)li[t] + prm.row_offset : -1;
         }
     } else {
@@ -722,6 +726,7 @@ __global__ __launch_bounds__(256) void knn_exact_fb_merge(MergeParams prm, int n
     for (int t = tid; t < prm.k; t += 256) {
         const bool real = is[t] != 0x7fffffff;
         prm.outD[(size_t)q * prm.k + t] = real ? (float)ds[t] : FLT_MAX;
+        if (prm.outD64) prm.outD64[(size_t)q * prm.k + t] = real ? ds[t] : (double)INFINITY;
         prm.outI[(size_t)q * prm.k + t] = real ? (int64_t)is[t] + prm.row_offset : -1;
     }
 }
@@ -729,14 +734,15 @@ __global__ __launch_bounds__(256) void knn_exact_fb_merge(MergeParams prm, int n
 // --------------------------------------------------------------------------------------
 // shard merge and prototype scores
 // --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void topk_merge_kernel(const float* Din, const int64_t* Iin,
+template <typename DT>
+__global__ __launch_bounds__(256) void topk_merge_kernel(const DT* Din, const int64_t* Iin,
                                                          int shards, int nq, int k, float* outD,
                                                          int64_t* outI) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int q = blockIdx.x, tid = threadIdx.x;
     const int n = shards * k;
     int64_t* ids = reinterpret_cast<int64_t*>(smem);
-    float* ds = reinterpret_cast<float*>(ids + n);
+    DT* ds = reinterpret_cast<DT*>(ids + n);
     for (int t = tid; t < n; t += 256) {
         const int s = t / k, e = t - s * k;
         ids[t] = Iin[((size_t)s * nq + q) * k + e];
@@ -747,15 +753,15 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* Din, const
     for (int t = tid; t < n; t += 256) {
         const int64_t it = ids[t];
         if (it < 0) continue;
-        const float dt = ds[t];
+        const DT dt = ds[t];
         int rank = 0;
         for (int s = 0; s < n; ++s) {
             const int64_t is = ids[s];
             if (is < 0) continue;
-            const float d = ds[s];
+            const DT d = ds[s];
             rank += (d < dt || (d == dt && (is < it || (is == it && s < t)))) ? 1 : 0;
         }
-        if (rank < k) { outD[(size_t)q * k + rank] = dt; outI[(size_t)q * k + rank] = it; }
+        if (rank < k) { outD[(size_t)q * k + rank] = (float)dt; outI[(size_t)q * k + rank] = it; }
     }
 }
 
@@ -844,6 +850,7 @@ __global__ __launch_bounds__(kSmallThreads) void knn_small_exact(MergeParams prm
     for (int t = tid; t < prm.k; t += kSmallThreads) {
         const bool real = t < prm.N;
         prm.outD[(size_t)q * prm.k + t] = real ? (float)ds[t] : FLT_MAX;
+        if (prm.outD64) prm.outD64[(size_t)q * prm.k + t] = real ? ds[t] : (double)INFINITY;
         prm.outI[(size_t)q * prm.k + t] = real ? (int64_t)is[t] + prm.row_offset : -1;
     }
 }
@@ -974,6 +981,14 @@ extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, c
                               int nq, int64_t ldQ, int k, int64_t row_offset, float* d_outD,
                               int64_t* d_outI, void* d_ws, size_t ws_bytes, int32_t* d_stats,
                               ac_stream_t stream_) {
+    return ac_knn_l2_topk_x(d_P, N, ldP, D, d_Q, nq, ldQ, k, row_offset, d_outD, nullptr, d_outI, d_ws, ws_bytes,
+                            d_stats, stream_);
+}
+
+extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D, const float* d_Q,
+                                int nq, int64_t ldQ, int k, int64_t row_offset, float* d_outD, double* d_outD64,
+                                int64_t* d_outI, void* d_ws, size_t ws_bytes, int32_t* d_stats,
+                                ac_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     Plan pl;
     int rc = make_plan(N, D, nq, k, &pl);
@@ -995,7 +1010,7 @@ extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, c
         MergeParams sp;
         memset(&sp, 0, sizeof(sp));
         sp.P = d_P; sp.N = N; sp.ldP = ldP; sp.Q = d_Q; sp.ldQ = ldQ; sp.D = D; sp.k = k; sp.row_offset = row_offset;
-        sp.outD = d_outD; sp.outI = d_outI;
+        sp.outD = d_outD; sp.outD64 = d_outD64; sp.outI = d_outI;
         const size_t lds = (size_t)pl.small_pow2 * 12;
         (void)hipFuncSetAttribute((const void*)knn_small_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(knn_small_exact, dim3(nq), dim3(kSmallThreads), lds, stream, sp, pl.small_pow2);
@@ -1011,7 +1026,7 @@ extern "C" int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D, c
     mp.part_d = (const float*)(ws + pl.off_part_d);
     mp.part_i = (const int32_t*)(ws + pl.off_part_i);
     mp.part_maxnorm = (const float*)(ws + pl.off_maxnorm);
-    mp.outD = d_outD; mp.outI = d_outI;
+    mp.outD = d_outD; mp.outD64 = d_outD64; mp.outI = d_outI;
     mp.flags = (int32_t*)(ws + pl.off_flags);
     mp.stats = d_stats;
     mp.fb_S = pl.fb_S; mp.fb_F = pl.fb_F;
@@ -1073,8 +1088,23 @@ extern "C" int ac_topk_merge(const float* d_D_in, const int64_t* d_I_in, int sha
     if (nq == 0) return AC_OK;
     const size_t lds = (size_t)shards * k * 12;
     AC_REQUIRE(lds <= 96 * 1024, AC_EUNSUPPORTED, "topk_merge: shards*k=%d too large", shards * k);
-    (void)hipFuncSetAttribute((const void*)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(256), lds, stream, d_D_in, d_I_in, shards, nq, k,
+    (void)hipFuncSetAttribute((const void*)topk_merge_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(topk_merge_kernel<float>, dim3(nq), dim3(256), lds, stream, d_D_in, d_I_in, shards, nq, k,
+                       d_outD, d_outI);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_topk_merge_f64(const double* d_D_in, const int64_t* d_I_in, int shards, int nq, int k,
+                                 float* d_outD, int64_t* d_outI, ac_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_REQUIRE(shards >= 1 && nq >= 0 && k >= 1, AC_EINVAL, "topk_merge_f64: bad shape");
+    AC_REQUIRE(d_D_in && d_I_in && d_outD && d_outI, AC_EINVAL, "topk_merge_f64: null pointer");
+    if (nq == 0) return AC_OK;
+    const size_t lds = (size_t)shards * k * 16;
+    AC_REQUIRE(lds <= 128 * 1024, AC_EUNSUPPORTED, "topk_merge_f64: shards*k=%d too large", shards * k);
+    (void)hipFuncSetAttribute((const void*)topk_merge_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(topk_merge_kernel<double>, dim3(nq), dim3(256), lds, stream, d_D_in, d_I_in, shards, nq, k,
                        d_outD, d_outI);
     AC_LAUNCH_CHECK();
     return AC_OK;

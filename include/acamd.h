@@ -85,6 +85,20 @@ int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D,
                    ac_stream_t stream);
 
 /*
+ * ac_knn_l2_topk with one more output: d_outD64 [nq, k] (may be NULL) receives the exact fp64 distances whose
+ * fp32 roundings go to d_outD (padding: +inf).  A row-sharded search must merge the shards' lists by
+ * THESE: two candidates whose exact distances differ but round to the same fp32 value would otherwise be ordered
+ * by id instead of by distance, and the sharded result could differ from the unsharded one (memory.py:114 has one
+ * index, so the reference never faces this).
+ */
+int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
+                     const float* d_Q, int nq, int64_t ldQ, int k,
+                     int64_t row_offset,
+                     float* d_outD, double* d_outD64, int64_t* d_outI,
+                     void* d_ws, size_t ws_bytes, int32_t* d_stats,
+                     ac_stream_t stream);
+
+/*
  * Optional profiling hook: when both events are non-NULL, every following
  * ac_knn_l2_topk call of THIS thread records `start` immediately before and
  * `stop` immediately after its sweep kernel (the HBM-bound kernel) on the
@@ -102,6 +116,11 @@ int ac_knn_set_profile_events(void* start_event, void* stop_event);
 int ac_topk_merge(const float* d_D_in, const int64_t* d_I_in, int shards,
                   int nq, int k, float* d_outD, int64_t* d_outI,
                   ac_stream_t stream);
+/* The same over exact fp64 per-shard distances (ac_knn_l2_topk_x's d_outD64): order by (exact distance, id),
+ * emit the fp32 rounding -- the merge a row-sharded search uses so that it equals the unsharded search bit for bit. */
+int ac_topk_merge_f64(const double* d_D_in, const int64_t* d_I_in, int shards,
+                      int nq, int k, float* d_outD, int64_t* d_outI,
+                      ac_stream_t stream);
 
 /*
  * memory.py:117,129-130: s = exp(-d) per hit, then softmax over the k hits of

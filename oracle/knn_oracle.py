@@ -42,18 +42,21 @@ def exact_sqdist(P, Q, chunk_rows=32768):
     return out
 
 
-def knn_l2_topk(P, Q, k, row_offset=0):
+def knn_l2_topk(P, Q, k, row_offset=0, return_exact=False):
     """(float32 [nq,k], int64 [nq,k]) -- the oracle for ac_knn_l2_topk.
 
     k > N pads with (FLT_MAX, -1), faiss's convention for an under-full heap.
+    return_exact=True: (float64 exact distances [nq,k] padded with +inf, ids) -- the oracle for ac_knn_l2_topk_x's
+    d_outD64, i.e. what one row shard contributes to a sharded search.
     """
     P = np.asarray(P, dtype=np.float32)
     Q = np.asarray(Q, dtype=np.float32)
     nq, N = Q.shape[0], P.shape[0]
     outD = np.full((nq, k), FLT_MAX, dtype=np.float32)
+    outE = np.full((nq, k), np.inf, dtype=np.float64)
     outI = np.full((nq, k), -1, dtype=np.int64)
     if N == 0 or nq == 0:
-        return outD, outI
+        return (outE, outI) if return_exact else (outD, outI)
     d = exact_sqdist(P, Q)
     kk = min(k, N)
     ids = np.arange(N, dtype=np.int64)
@@ -67,13 +70,16 @@ def knn_l2_topk(P, Q, k, row_offset=0):
         order = np.lexsort((cand, d[q][cand]))[:kk]
         sel = cand[order]
         outD[q, :kk] = d[q][sel].astype(np.float32)
+        outE[q, :kk] = d[q][sel]
         outI[q, :kk] = sel + row_offset
-    return outD, outI
+    return (outE, outI) if return_exact else (outD, outI)
 
 
 def topk_merge(D_in, I_in, k):
-    """Oracle for ac_topk_merge: [shards, nq, k] ascending lists -> global top-k by (d, id)."""
-    D_in = np.asarray(D_in, dtype=np.float32)
+    """Oracle for ac_topk_merge / ac_topk_merge_f64: [shards, nq, k] ascending lists -> global top-k by (d, id) in the
+    precision of D_in (float32, or the shards' exact float64 distances); the distances come out rounded to float32."""
+    D_in = np.asarray(D_in)
+    D_in = D_in.astype(np.float64 if D_in.dtype == np.float64 else np.float32)
     I_in = np.asarray(I_in, dtype=np.int64)
     S, nq, kk = D_in.shape
     outD = np.full((nq, k), FLT_MAX, dtype=np.float32)

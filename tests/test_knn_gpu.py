@@ -124,8 +124,8 @@ def test_large_sweep_properties(cuda_dev):
     Q = ix.synth_unit_rows(nq, D, 2, device=cuda_dev)
     Dd, Id = ix.knn_l2_topk(P, N, D, Q, k)
     h = N // 2
-    D0, I0 = ix.knn_l2_topk(P[:h], h, D, Q, k)
-    D1, I1 = ix.knn_l2_topk(P[h:], N - h, D, Q, k, row_offset=h)
+    D0, I0 = ix.knn_l2_topk_exact(P[:h], h, D, Q, k)                # shards contribute exact fp64 distances
+    D1, I1 = ix.knn_l2_topk_exact(P[h:], N - h, D, Q, k, row_offset=h)
     Dm, Im = ix.topk_merge(torch.stack([D0, D1]), torch.stack([I0, I1]))
     torch.cuda.synchronize()
     assert torch.equal(Im, Id) and torch.equal(Dm, Dd)

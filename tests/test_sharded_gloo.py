@@ -29,7 +29,7 @@ def _worker(rank, world, port, N, D, nq, k, ret):
     q_local = torch.from_numpy(synth.synth_unit_rows(nq // world, D, 2, row_offset=rank * (nq // world)))
 
     def local_search(P, n, Dd, Q, kk, off):
-        d, i = knn_oracle.knn_l2_topk(P.numpy()[:n], Q.numpy(), kk, row_offset=off)
+        d, i = knn_oracle.knn_l2_topk(P.numpy()[:n], Q.numpy(), kk, row_offset=off, return_exact=True)   # fp64 on the wire
         return torch.from_numpy(d), torch.from_numpy(i)
 
     def merge(Ds, Is):

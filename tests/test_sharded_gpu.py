@@ -84,6 +84,33 @@ def test_logical_shards_equal_unsharded_1M(G, cuda_dev):
     parts = []
     for g in range(G):
         lo, hi = shard_bounds(N, G, g)
-        parts.append(ix.knn_l2_topk(P[lo:hi], hi - lo, D, Q, k, row_offset=lo))
+        parts.append(ix.knn_l2_topk_exact(P[lo:hi], hi - lo, D, Q, k, row_offset=lo))
     mD, mI = ix.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert torch.equal(mI, uI) and torch.equal(mD, uD)
+
+
+@pytest.mark.parametrize("N", [64, 20_000])
+def test_shard_merge_orders_fp32_ties_by_exact_distance(N, cuda_dev):
+    """Two candidates on different shards whose exact distances differ but round to the same fp32 value: the sharded
+    search must order them like the unsharded one (by exact distance), which is why the shards exchange fp64."""
+    from adaptive_classifier import index as ix
+    from oracle import c_oracle
+    D, k = 8, 4
+    P = np.full((N, D), 3.0, np.float32)                   # filler rows far from the query
+    a, b = 5, N - 7                                        # a on shard 0 (low id), b on shard 1 (high id)
+    P[a] = 0; P[a, 0] = 1.0; P[a, 1] = 2.0 ** -13          # |p|^2 = 1 + 2^-26  -> fp32(1.0)
+    P[b] = 0; P[b, 0] = 1.0                                # |p|^2 = 1 exactly: the closer one, higher id
+    Q = np.zeros((1, D), np.float32)
+    Pd, Qd = torch.from_numpy(P).to(cuda_dev), torch.from_numpy(Q).to(cuda_dev)
+    uD, uI = ix.knn_l2_topk(Pd, N, D, Qd, k)
+    oD, oI = c_oracle.knn_l2_topk(P, Q, k)
+    assert uI[0, :2].tolist() == oI[0, :2].tolist() == [b, a] and uD[0, 0].item() == uD[0, 1].item() == 1.0
+    h = N // 2
+    E0, I0 = ix.knn_l2_topk_exact(Pd[:h], h, D, Qd, k)
+    E1, I1 = ix.knn_l2_topk_exact(Pd[h:], N - h, D, Qd, k, row_offset=h)
+    assert E0[0, 0].item() == 1.0 + 2.0 ** -26 and E1[0, 0].item() == 1.0
+    mD, mI = ix.topk_merge(torch.stack([E0, E1]), torch.stack([I0, I1]))
+    assert torch.equal(mI, uI) and torch.equal(mD, uD)
+    # the fp32 merge (ac_topk_merge) cannot see the difference and falls back to the id order
+    fD, fI = ix.topk_merge(torch.stack([E0, E1]).float(), torch.stack([I0, I1]))
+    assert fI[0, :2].tolist() == [a, b]
