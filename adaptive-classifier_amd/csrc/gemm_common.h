@@ -1,0 +1,192 @@
+// Shared pieces of the GEMM kernels (gemm.hip, gemm_ring.hip): the runtime epilogue description, the compile-time
+// epilogue classes and the C/D-layout tile stores (fp32 rows, or bf16x3 operand planes of the next GEMM).
+// Device code only; include inside an anonymous namespace user.
+#pragma once
+#include "common.h"
+
+#include <math.h>
+
+namespace acg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_GEGLU32 = 3 };
+
+struct Epilogue {
+    const float* bias;      // [N] or null
+    const float* residual;  // [M, ldr] or null  (added after the activation)
+    int64_t ldr;
+    int act;
+    float alpha;            // C = alpha * acc (+ beta * Cold) before bias/act
+    float beta;
+    // inverted-dropout mask applied after the activation (train-mode head): 1 = keep
+    const uint8_t* mask;    // [M, N] or null
+    float mask_scale;
+    // ... or generated in-kernel from a counter-based hash (no mask tensor, no torch RNG launch):
+    // keep element (row, col) iff u(drop_seed, row * N + col) >= drop_p
+    uint64_t drop_seed;
+    float drop_p;
+    // relu/dropout backward gate: out = gate[row,col] != 0 ? out * gate_scale : 0
+    const float* gate;      // [M, ldg] or null
+    int64_t ldg;
+    float gate_scale;
+};
+
+__device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, int64_t row, int col,
+                                                const float* C, int64_t ldc, int N) {
+    float v = e.alpha * acc;
+    if (e.beta != 0.f) v = fmaf(e.beta, C[row * ldc + col], v);
+    if (e.bias) v += e.bias[col];
+    if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (e.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (e.mask) v = e.mask[row * (int64_t)N + col] ? v * e.mask_scale : 0.f;
+    else if (e.drop_p > 0.f) v = ac::dropout_keep(e.drop_seed, (uint64_t)(row * (int64_t)N + col), e.drop_p) ? v * e.mask_scale : 0.f;
+    if (e.residual) v += e.residual[row * e.ldr + col];
+    if (e.gate) v = (e.gate[row * e.ldg + col] != 0.f) ? v * e.gate_scale : 0.f;
+    return v;
+}
+
+// compile-time epilogue classes for the hot encoder/head shapes; EPI_GENERIC keeps the runtime flags
+enum { EPI_GENERIC = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RES = 3, EPI_BIAS_RELU = 4,
+       // GeGLU over 32-column blocks: output columns [64t, 64t+32) are the inputs and [64t+32, 64t+64) the gates of
+       // result columns [32t, 32t+32) -- a wave's two 32x32 tiles hold input_j and gate_j in the same lane/register
+       EPI_GEGLU32 = 5 };
+
+template <int EPI>
+__device__ __forceinline__ float fast_epilogue(float acc, float bias, float res) {
+    float v = acc + bias;
+    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+    if (EPI == EPI_BIAS_RES) v += res;
+    return v;
+}
+
+__device__ __forceinline__ int acc_row32(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// shared epilogue of the LDS-tiled kernels: the 32x32 C/D layout (lane owns column lane & 31, 16 rows)
+template <int EPI, int TM, int BM = 64 * TM>
+__device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][2], float* __restrict__ C, int64_t ldc, int M, int N,
+                                           int m0, int n0, int wm, int wn, int lane, const Epilogue& epi) {
+    // epilogue: lane owns column (lane & 31) of each 32x32 tile, 16 rows
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+            if (col >= N) continue;
+            const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
+            if (EPI == EPI_GENERIC) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = rbase + acc_row32(r, lane);
+                    if (row < M) C[row * ldc + col] = apply_epilogue(epi, acc[mi][ni][r], row, col, C, ldc, N);
+                }
+            } else {
+                const float bias = epi.bias[col];
+                float res[16];
+                if (EPI == EPI_BIAS_RES) {   // issue all residual loads first, then compute + store
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int64_t row = rbase + acc_row32(r, lane);
+                        if (row > M - 1) row = M - 1;
+                        res[r] = epi.residual[row * epi.ldr + col];
+                    }
+                }
+                if (m0 + BM <= M) {          // block-uniform: interior tile, branch-free stores
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        C[(rbase + acc_row32(r, lane)) * ldc + col] =
+                            fast_epilogue<EPI>(acc[mi][ni][r], bias, EPI == EPI_BIAS_RES ? res[r] : 0.f);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = rbase + acc_row32(r, lane);
+                        const float v = fast_epilogue<EPI>(acc[mi][ni][r], bias, EPI == EPI_BIAS_RES ? res[r] : 0.f);
+                        if (row < M) C[row * ldc + col] = v;
+                    }
+                }
+            }
+        }
+}
+
+// epilogue that emits the result as operand planes of the NEXT GEMM (C[M,N] -> planes[p][n/8][row][n%8]).
+// In the C/D layout a lane owns one column, but a plane k-slot is 8 neighbouring columns of one row: each
+// wave transposes its 32x32 tiles through a private LDS scratch (the staging buffers are idle by now), so
+// every lane ends up with 8 consecutive columns of a row = one split8 and three 16-byte stores.
+constexpr int kTrLd = 36;                                  // padded row of the 32x32 transpose scratch (floats)
+constexpr int kTrFloats = 32 * kTrLd;                      // per wave
+
+template <int EPI, int TM>
+__device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][2], uint16_t* __restrict__ Cp, int M, int N,
+                                                  int m0, int n0, int wm, int wn, int lane, const Epilogue& epi,
+                                                  float* scratch /* this wave's kTrFloats floats of LDS */) {
+    constexpr bool GLU = EPI == EPI_GEGLU32;
+    const int NO = GLU ? N / 2 : N;                                  // result columns
+    const int64_t plane = (int64_t)M * NO;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < (GLU ? 1 : 2); ++ni) {
+            const int c0 = GLU ? n0 / 2 + wn * 32 : n0 + wn * 64 + ni * 32;      // first result column of the tile
+            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);                  // GEMM column of acc[mi][ni]
+            const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
+            const float bias = col < N ? epi.bias[col] : 0.f;
+            const float bias_g = (GLU && col + 32 < N) ? epi.bias[col + 32] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v;
+                if (GLU) {
+                    const float x = acc[mi][0][r] + bias;
+                    v = 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)) * (acc[mi][1][r] + bias_g);
+                } else {
+                    v = fast_epilogue<EPI>(acc[mi][ni][r], bias, 0.f);
+                }
+                scratch[acc_row32(r, lane) * kTrLd + (lane & 31)] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int rr = (lane >> 2) + 16 * u, q = lane & 3;       // row of the tile, k-slot of 8 columns
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(scratch + rr * kTrLd + 8 * q);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(scratch + rr * kTrLd + 8 * q + 4);
+                const int64_t row = rbase + rr;
+                const int cq = c0 + 8 * q;
+                if (row < M && cq < NO) {
+                    uint4 H, Mi, L;
+                    ac::split8(v0, v1, H, Mi, L);
+                    uint16_t* dst = Cp + ac::plane_off(M, row, cq);
+                    *reinterpret_cast<uint4*>(dst) = H;              // (N % 8 == 0: checked at launch)
+                    *reinterpret_cast<uint4*>(dst + plane) = Mi;
+                    *reinterpret_cast<uint4*>(dst + 2 * plane) = L;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// Workgroups are dealt round-robin to the 8 XCDs (workgroup id % 8), each with a private 4 MB L2.  Map the
+// hardware id to a logical tile id so that every XCD owns one CONTIGUOUS range of tiles (column tiles
+// fastest): its resident blocks then share A row-panels and sweep the W panels together, instead of every
+// XCD touching every A panel.  Bijective for any block count (the guide's q/r formula).
+__device__ __forceinline__ int xcd_tile_id(int wg, int nwg) {
+    const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+}
+
+}  // namespace acg
+
+namespace ac {
+// gemm_ring.hip: persistent stream-K ring kernel for large-M GEMMs with both operands pre-split
+bool ring_takes(int M, int N, int K, int cls, bool c_planes, bool allow_cuts);
+int launch_gemm_ring(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, float* C, int64_t ldc,
+                     uint16_t* Cp, int M, int N, int K, int cls, const acg::Epilogue& epi, hipStream_t stream);
+int gemm_variant();            // diagnostic switch (ac_gemm_set_variant): 0 = default dispatch, 2 = ring kernel where it applies
+}  // namespace ac

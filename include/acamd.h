@@ -180,6 +180,10 @@ int ac_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
 #define AC_GEMM_BF16X3 1
 int ac_gemm_set_arith(int mode);
 int ac_gemm_get_arith(void);
+/* Diagnostic / A-B switch for the large-M pre-split GEMM: 0 = default dispatch (the three-blocks-per-CU tile kernels),
+ * 2 = the experimental persistent stream-K ring kernel (gemm_ring.hip; measured and rejected as default)
+ * where it applies.  Env AC_GEMM_VARIANT sets the initial value. */
+int ac_gemm_set_variant(int variant);
 
 /* Diagnostic: resident workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor) of the LDS-tiled
  * GEMM kernels.  kernel: 0 = fp32-MFMA tile, 1 = bf16x3 split-in-kernel, 2 = bf16x3 planes; tm: 1 = 64-row,

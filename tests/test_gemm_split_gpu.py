@@ -207,3 +207,35 @@ def test_fused_geglu_epilogue(cuda_dev, arith):
     # without planes output the fused activation is refused
     assert lib.ac_linear_bf16x3(nv.ptr(Ad), K, nv.ptr(Ap), nv.ptr(Wd), K, nv.ptr(Wp), nv.ptr(bd), None, 0,
                                 nv.ptr(U), N, None, M, N, K, 3, st) != 0
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (8192, 768, 768, 0, True),      # 192 tiles of 256 x 128 on 256 CUs: every tile is cut between 2-3 workgroups
+    (8192, 2304, 768, 0, False),    # 2.25 tiles per workgroup
+    (8200, 3072, 64, 2, False),     # ragged last row tile, 4 k-stages per tile
+    (4096, 1024, 1024, 0, True),    # 0.5 tile per workgroup
+])
+def test_ring_kernel_with_stream_k_cuts_is_fp32_grade(M, N, K, act, res, cuda_dev, arith):
+    """gemm_ring.hip in its stream-K mode (opt-in, ac_gemm_set_variant(2)): tiles cut between workgroups, partial
+    accumulators handed over inside an XCD, owner adds them in a fixed order.  Same fp32-grade bounds as the tile
+    kernels, and deterministic (two runs bit-identical)."""
+    from adaptive_classifier import _native as nv
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    want = _ref(A, W, b, R, act)
+    arith(BF16X3)
+    tile = _linear(nv, cuda_dev, A, W, b, R, act, "aw")
+    bound = K * 2.0 ** -24 * (np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T) + 1e-6
+    nv.check(nv.lib().ac_gemm_set_variant(2), "ac_gemm_set_variant")
+    try:
+        got = _linear(nv, cuda_dev, A, W, b, R, act, "aw")
+        again = _linear(nv, cuda_dev, A, W, b, R, act, "aw")
+    finally:
+        nv.lib().ac_gemm_set_variant(0)
+    es = np.abs(got - want)
+    assert np.all(es <= bound), (es.max(), bound.min())
+    assert es.max() <= 1.5 * np.abs(tile - want).max() + 1e-7
+    assert np.array_equal(got, again)                       # fixed summation order: deterministic

@@ -1,0 +1,92 @@
+// Standalone A/B harness for the planes GEMM variants (no torch: runs in seconds on the GPU box).
+//   hipcc -O2 --offload-arch=gfx950 tools/gemm_bench.hip -o tools/ab/gemm_bench \
+//         -Ladaptive-classifier_amd/adaptive_classifier -lacamd -Wl,-rpath,/root/repo/adaptive-classifier_amd/adaptive_classifier
+//   tools/ab/gemm_bench [variants, e.g. 0,1] [reps] [M,N,K,act,res,cplanes ...]
+// For every shape: time each variant (ac_gemm_set_variant) of ac_linear_bf16x3 with pre-split operands, and compare
+// every variant's output with variant 0's (max |diff|, count of differing elements).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../include/acamd.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+#define AC(x) do { int r_ = (x); if (r_ != 0) { printf("acamd error %d: %s at line %d\n", r_, ac_last_error(), __LINE__); exit(1); } } while (0)
+
+__global__ void fill(float* x, size_t n, uint64_t seed, float scale) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = seed + i * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    x[i] = ((float)(z >> 40) * (1.0f / 16777216.0f) - 0.5f) * 2.f * scale;
+}
+
+struct Shape { int M, N, K, act, res, cplanes; };
+
+int main(int argc, char** argv) {
+    std::vector<int> variants = {0, 2};
+    int reps = 20;
+    std::vector<Shape> shapes = {{8192, 2304, 768, 0, 0, 0}, {8192, 768, 768, 0, 1, 0}, {8192, 3072, 768, 2, 0, 1},
+                                 {8192, 768, 3072, 0, 1, 0}, {8192, 8192, 8192, 0, 0, 0}};
+    if (argc > 1) { variants.clear(); char* s = strdup(argv[1]); for (char* t = strtok(s, ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t)); }
+    if (argc > 2) reps = atoi(argv[2]);
+    if (argc > 3) {
+        shapes.clear();
+        for (int i = 3; i < argc; ++i) { Shape s{0, 0, 0, 0, 0, 0}; sscanf(argv[i], "%d,%d,%d,%d,%d,%d", &s.M, &s.N, &s.K, &s.act, &s.res, &s.cplanes); shapes.push_back(s); }
+    }
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (const Shape& sh : shapes) {
+        const size_t MA = (size_t)sh.M * sh.K, MW = (size_t)sh.N * sh.K, MC = (size_t)sh.M * sh.N;
+        float *A, *W, *bias, *R, *C0, *C1; uint16_t *Ap, *Wp, *Cp0, *Cp1;
+        CK(hipMalloc(&A, MA * 4)); CK(hipMalloc(&W, MW * 4)); CK(hipMalloc(&bias, sh.N * 4)); CK(hipMalloc(&R, MC * 4));
+        CK(hipMalloc(&C0, MC * 4)); CK(hipMalloc(&C1, MC * 4));
+        CK(hipMalloc(&Ap, MA * 6)); CK(hipMalloc(&Wp, MW * 6)); CK(hipMalloc(&Cp0, MC * 6)); CK(hipMalloc(&Cp1, MC * 6));
+        hipLaunchKernelGGL(fill, dim3((MA + 255) / 256), dim3(256), 0, st, A, MA, 1, 1.0f);
+        hipLaunchKernelGGL(fill, dim3((MW + 255) / 256), dim3(256), 0, st, W, MW, 2, 0.05f);
+        hipLaunchKernelGGL(fill, dim3((sh.N + 255) / 256), dim3(256), 0, st, bias, (size_t)sh.N, 3, 0.1f);
+        hipLaunchKernelGGL(fill, dim3((MC + 255) / 256), dim3(256), 0, st, R, MC, 4, 1.0f);
+        AC(ac_split_bf16x3(A, sh.K, sh.M, sh.K, Ap, st));
+        AC(ac_split_bf16x3(W, sh.K, sh.N, sh.K, Wp, st));
+        CK(hipStreamSynchronize(st));
+        printf("M=%d N=%d K=%d act=%d res=%d cplanes=%d\n", sh.M, sh.N, sh.K, sh.act, sh.res, sh.cplanes);
+        const size_t cbytes = sh.cplanes ? MC * 6 : MC * 4;
+        std::vector<uint8_t> ref(cbytes), got(cbytes);
+        for (size_t vi = 0; vi < variants.size(); ++vi) {
+            const int v = variants[vi];
+            AC(ac_gemm_set_variant(v));
+            float* C = vi == 0 ? C0 : C1; uint16_t* Cp = vi == 0 ? Cp0 : Cp1;
+            CK(hipMemsetAsync(sh.cplanes ? (void*)Cp : (void*)C, 0xff, cbytes, st));
+            auto run = [&]() { AC(ac_linear_bf16x3(A, sh.K, Ap, W, sh.K, Wp, bias, sh.res ? R : nullptr, sh.N, sh.cplanes ? nullptr : C, sh.N,
+                                                   sh.cplanes ? Cp : nullptr, sh.M, sh.N, sh.K, sh.act, st)); };
+            for (int i = 0; i < 3; ++i) run();
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < reps; ++i) run();
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / reps, tf = 2.0 * sh.M * sh.N * (double)sh.K / (us * 1e-6) / 1e12;
+            CK(hipMemcpy((vi == 0 ? ref : got).data(), sh.cplanes ? (void*)Cp : (void*)C, cbytes, hipMemcpyDeviceToHost));
+            printf("  variant %d: %9.1f us  %7.1f TF fp32-equiv (%.3f of 416.7)", v, us, tf, tf / 416.7);
+            if (vi > 0) {
+                size_t ndiff = 0; double maxd = 0;
+                if (sh.cplanes) { for (size_t i = 0; i < cbytes; ++i) ndiff += ref[i] != got[i]; }
+                else {
+                    const float* a = (const float*)ref.data(); const float* b = (const float*)got.data();
+                    for (size_t i = 0; i < MC; ++i) { if (a[i] != b[i]) { ++ndiff; double d = fabs((double)a[i] - b[i]); if (!(d <= maxd)) maxd = d; } }
+                }
+                printf("   vs variant %d: %zu differing, max |diff| %.3g", variants[0], ndiff, maxd);
+            }
+            printf("\n");
+        }
+        hipFree(A); hipFree(W); hipFree(bias); hipFree(R); hipFree(C0); hipFree(C1); hipFree(Ap); hipFree(Wp); hipFree(Cp0); hipFree(Cp1);
+    }
+    AC(ac_gemm_set_variant(0));
+    return 0;
+}
