@@ -193,6 +193,26 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
         t, _, c, _ = (ms, ms_min, call_ms, nfb) if nq == 16 else measure(nq, 4)
         table[str(nq)] = {"kernel_ms": t, "GBps": bytes_alg / t / 1e6, "frac": bytes_alg / t / 1e6 / HBM_PEAK_GBS,
                           "whole_call_ms": c}
+    # BASELINE configs[2] on this one GPU: 4096 queries x the whole store, k = 32 (compute-bound regime, whole call)
+    batch = None
+    if full:
+        nqb = 4096
+        Qb = ix.synth_unit_rows(nqb, DIM, 2, device=dev)
+        wsb = torch.empty(ix.knn_workspace_bytes(n_rows, DIM, nqb, k), dtype=torch.uint8, device=dev)
+        stb = torch.zeros(4, dtype=torch.int32, device=dev)
+        outb = (torch.empty((nqb, k), dtype=torch.float32, device=dev), torch.empty((nqb, k), dtype=torch.int64, device=dev))
+        ix.knn_l2_topk(P, n_rows, DIM, Qb, k, out=outb, workspace=wsb, stats=stb)
+        torch.cuda.synchronize()
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b0.record()
+        for _ in range(2):
+            ix.knn_l2_topk(P, n_rows, DIM, Qb, k, out=outb, workspace=wsb, stats=stb)
+        b1.record(); torch.cuda.synchronize()
+        bms = b0.elapsed_time(b1) / 2
+        batch = {"workload": "BASELINE configs[2] on ONE GPU: %d x %d store, k=%d, batch %d" % (n_rows, DIM, k, nqb),
+                 "ms_per_batch": bms, "queries_per_s": nqb / bms * 1e3, "TFLOPs": 2.0 * nqb * n_rows * DIM / bms / 1e9,
+                 "exact_fallback_queries": int(stb[0].item())}
+        del Qb, wsb, outb
     # HBM traffic per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 gfx950 correction,
     # profiles/<round>/knn_sweep_pmc.json); null when no pass exists for this problem size.
     traffic, traffic_src = None, None
@@ -208,7 +228,8 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
             "frac": bytes_alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "knn_sweep<1> (16-query tile)", "rows": n_rows, "dim": DIM, "resident_queries": 16,
             "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": ms, "min_kernel_ms": ms_min,
-            "whole_call_ms": call_ms, "exact_fallback_queries": nfb, "parity": par["v"], "by_resident_queries": table}
+            "whole_call_ms": call_ms, "exact_fallback_queries": nfb, "parity": par["v"], "by_resident_queries": table,
+            "batch4096": batch}
 
 
 def cpu_baseline(hf, clf, rows_dev, sample=2048, chunk=64):
@@ -240,6 +261,158 @@ def cpu_baseline(hf, clf, rows_dev, sample=2048, chunk=64):
             "encode_s": t1 - t0, "knn_s": t2 - t1, "head_s": t3 - t2}
 
 
+def sharded_cfg2(dev, rank, world, total_rows, batch=4096, k=32, reps=3):
+    """BASELINE configs[2] on N GPUs through ShardedSearch (the production exchange): returns the rank-0 report."""
+    from adaptive_classifier import index as ix
+    from adaptive_classifier.sharded import ShardedSearch, shard_bounds
+    lo, hi = shard_bounds(total_rows, world, rank)
+    rows = ix.synth_unit_rows(hi - lo, DIM, 1, row_offset=lo, device=dev)
+    b = batch // world
+    q_local = ix.synth_unit_rows(b, DIM, 2, row_offset=rank * b, device=dev)
+    ss = ShardedSearch(rows, hi - lo, DIM, lo)
+    for _ in range(1):
+        ss.search(ss.gather_queries(q_local), k)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        Dg, Ig = ss.search(ss.gather_queries(q_local), k)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    del rows
+    torch.cuda.empty_cache()
+    return {"workload": "BASELINE configs[2]: %d x %d row-sharded over %d GPUs, k=%d, batch %d (all-gather queries, local "
+                        "sweep, all-gather exact fp64 dist + ids, merge)" % (total_rows, DIM, world, k, b * world),
+            "ms_per_batch": dt / reps * 1e3, "queries_per_s": b * world * reps / dt, "rows_per_gpu": hi - lo}
+
+
+def bench_cfg4(dev, args):
+    """BASELINE configs[4] end to end on ONE GPU: e5-large-v2 architecture (= BERT-large: 24 layers, 1024 hidden, 16 heads,
+    4096 intermediate; random init, no weights offline), 2M x 1024 prototype store, 64 classes (row % 64), batch 1024,
+    k = 32, S = 32.  Same step as the headline: encode -> kNN -> head -> blend -> Python result lists."""
+    from adaptive_classifier import AdaptiveClassifier, AdaptiveHead
+    from adaptive_classifier import index as ix
+    from adaptive_classifier.encoder import HipBertEncoder
+    from transformers import BertConfig, BertModel
+    D, NP_, C, B, K_, S = 1024, 2_000_000, 64, 1024, 32, 32
+    cfg = BertConfig(hidden_size=D, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    torch.manual_seed(0)
+    hf = BertModel(cfg, add_pooling_layer=False).eval()
+    enc = HipBertEncoder(hf, device=dev)
+    clf = AdaptiveClassifier("e5-large-v2(random-init)", device=str(dev), encoder=enc, tokenizer=None)
+    labels = [f"c{i}" for i in range(C)]
+    clf.label_to_id = {l: i for i, l in enumerate(labels)}
+    clf.id_to_label = {i: l for i, l in enumerate(labels)}
+    clf.training_history = {l: 25 for l in labels}
+    clf.adaptive_head = AdaptiveHead(D, C, [D, D // 2]).to(dev).eval()
+    rows = ix.synth_unit_rows(NP_, D, 1, device=dev)
+    clf.memory.load_rows(rows, torch.arange(NP_, dtype=torch.int32) % C, labels)
+    g = torch.Generator().manual_seed(1234)
+    ids = torch.randint(1000, VOCAB, (B, S), generator=g); ids[:, 0] = 101
+    lens = torch.randint(8, S + 1, (B,), generator=g); lens[0] = S
+    mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64)
+    ids = (ids * mask).to(dev); mask = mask.to(dev); types = torch.zeros_like(ids)
+    step = lambda: clf.predict_embeddings(clf.model.encode_cls(ids, types, mask), k=K_)
+    for _ in range(args.warmup):
+        preds = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        preds = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert len(preds) == B
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record(); emb = clf.model.encode_cls(ids, types, mask); ev[1].record()
+    S_, I_, D_ = clf.memory.search_batch(emb, K_); ev[2].record(); torch.cuda.synchronize()
+    parity = None
+    if not args.no_parity:
+        from oracle import c_oracle
+        sel = np.arange(0, B, 64)
+        chunks = ((s, rows[s:min(NP_, s + 500_000), :D].cpu().numpy()) for s in range(0, NP_, 500_000))
+        oD, oI = c_oracle.knn_l2_topk_chunked(chunks, emb[:, :D].cpu().numpy()[sel], K_)
+        want = torch.nn.functional.normalize(hf(input_ids=ids[:4].cpu(), token_type_ids=types[:4].cpu(),
+                                                attention_mask=mask[:4].cpu()).last_hidden_state[:, 0, :], dim=1)
+        parity = {"checked_queries": int(len(sel)), "id_mismatches": int((I_.cpu().numpy()[sel] != oI).sum()),
+                  "encoder_max_abs_diff_vs_transformers_fp32": float((emb[:4].cpu() - want.detach()).abs().max())}
+    print(json.dumps({
+        "metric": "predict() queries/sec + kNN GB/s vs HBM roofline, 768-d", "value": B * args.steps / dt, "unit": "queries/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4] on ONE GPU (the config names 4): e5-large-v2 architecture (BERT-large, random "
+                               "init), 1024-d, 2M prototypes, 64 classes, batch=1024, k=32, S=32, end-to-end predict()",
+                   "batch_per_gpu": B, "seq_len": S, "prototypes": NP_, "dim": D, "k": K_, "classes": C, "parallelism": "dp1"},
+        "stages_ms": {"encode_ms": ev[0].elapsed_time(ev[1]), "knn_ms": ev[1].elapsed_time(ev[2])},
+        "roofline_encoder": {"bound": "mfma", "achieved": enc.flops(B, S) / ev[0].elapsed_time(ev[1]) / 1e9,
+                             "peak": BF16_MFMA_PEAK_TF / 6.0, "unit": "TFLOP/s",
+                             "frac": enc.flops(B, S) / ev[0].elapsed_time(ev[1]) / 1e9 / (BF16_MFMA_PEAK_TF / 6.0)},
+        "parity": parity}), flush=True)
+
+
+def bench_add_examples(dev, args):
+    """BASELINE configs[3]: the add_examples() continuous-learning loop on one GPU.  50 000 pre-computed unit-norm 768-d
+    embeddings (class centroid + 0.5 noise, 4 classes) fed in chunks of 32 through add_embeddings (= add_examples after
+    the encoder call), max_examples_per_class = 1000; every call updates the memory (device prune), retrains the head on
+    everything stored (<= 10 epochs, early stopping) and rebuilds the index -- what the reference does per call.  Then a
+    5th class in both EWC modes.  `--examples N` shrinks the run."""
+    from adaptive_classifier import AdaptiveClassifier
+    from adaptive_classifier import index as ix
+    from adaptive_classifier.encoder import _Cfg
+
+    class _NoEncoder:                      # the loop is fed embeddings; the encoder is bypassed (SURVEY 8d cfg3)
+        config = _Cfg(DIM, "precomputed-embeddings")
+
+    n, C = args.examples, 4
+    cent = ix.synth_unit_rows(C + 1, DIM, 3, device=dev)[:, :DIM]
+    noise = ix.synth_unit_rows(n + 64, DIM, 4, device=dev)[:, :DIM]
+    cls = torch.arange(n + 64, device=dev) % C
+    cls[n:] = C
+    E = torch.nn.functional.normalize(cent[cls] + 0.5 * noise, dim=1).cpu()
+    out = {}
+    for mode in ("as_wired", "intended"):
+        clf = AdaptiveClassifier("precomputed", device=str(dev), config={"ewc_mode": mode}, encoder=_NoEncoder(), tokenizer=None)
+        T = {"memory": 0.0, "train": 0.0, "rebuild": 0.0}
+
+        def timed(obj, name, key):
+            f = getattr(obj, name)
+
+            def g(*a, **k):
+                t = time.perf_counter(); r = f(*a, **k); T[key] += time.perf_counter() - t; return r
+            setattr(obj, name, g)
+        timed(clf.memory, "add_examples_batch", "memory"); timed(clf, "_train_adaptive_head", "train")
+        timed(clf.memory, "_rebuild_index", "rebuild")
+        steps = 0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for s in range(0, n, 32):
+            e = min(n, s + 32)
+            clf.add_embeddings([f"t{i}" for i in range(s, e)], [E[i] for i in range(s, e)], [f"c{i % C}" for i in range(s, e)])
+            steps += clf.last_train_info["steps"]
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        np.random.seed(0)
+        t1 = time.perf_counter()
+        clf.add_embeddings([f"n{i}" for i in range(32)], [E[n + i] for i in range(32)], ["znew"] * 32)
+        torch.cuda.synchronize(); dt_new = time.perf_counter() - t1
+        test = torch.nn.functional.normalize(cent[torch.arange(200, device=dev) % (C + 1)] + 0.5 * ix.synth_unit_rows(200, DIM, 9, device=dev)[:, :DIM], dim=1)
+        preds = clf.predict_embeddings(test, k=1)
+        names = [f"c{i}" for i in range(C)] + ["znew"]
+        acc = float(np.mean([p[0][0] == names[i % (C + 1)] for i, p in enumerate(preds)]))
+        out[mode] = {"examples": n, "seconds": dt, "examples_per_s": n / dt, "train_steps": steps, "steps_per_s": steps / dt,
+                     "host_seconds_by_phase": T, "stored": clf.get_memory_stats()["total_examples"],
+                     "new_class_seconds": dt_new, "new_class_info": clf.last_train_info, "accuracy_5way": acc}
+        if mode == "as_wired":
+            headline = out[mode]
+    print(json.dumps({
+        "metric": "add_examples() examples/sec (continuous-learning loop)", "value": headline["examples_per_s"], "unit": "examples/s",
+        "n_gpus": 1, "steps": headline["train_steps"], "warmup": 0, "ms_per_step": headline["seconds"] / max(1, headline["train_steps"]) * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: add_examples() loop, %d pre-computed 768-d examples in chunks of 32, 4 classes, "
+                               "cap 1000/class, head retrained per call (<= 10 epochs), then a 5th class (EWC path)" % n,
+                   "dim": DIM, "chunk": 32, "max_examples_per_class": 1000},
+        "modes": out}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,6 +422,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the on-box oracle checks (parity fields become null)")
+    ap.add_argument("--config", default="predict", choices=["predict", "cfg4", "add_examples"],
+                    help="predict = BASELINE configs[1] (the headline, default); cfg4 = configs[4] end to end on one GPU; "
+                         "add_examples = configs[3] continuous-learning loop")
+    ap.add_argument("--examples", type=int, default=50_000, help="--config add_examples: number of examples fed")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -269,6 +446,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.config != "predict":
+        if world > 1:
+            raise SystemExit("--config %s is a single-GPU measurement" % args.config)
+        return bench_cfg4(dev, args) if args.config == "cfg4" else bench_add_examples(dev, args)
 
     clf, hf = make_classifier(dev, rank, world)
     ids, types, mask = synthetic_tokens(dev, rank)
@@ -328,6 +510,11 @@ def main():
                       "rows_per_gpu": rows_rank, "dim": DIM, "resident_queries": 16,
                       "algorithmic_bytes_per_launch": rows_rank * DIM * 4, "avg_kernel_ms": slow,
                       "rank0_avg_kernel_ms": r["avg_kernel_ms"], "aggregation": "sum of shard bytes / max over ranks of the kernel time"}
+    # N > 1: BASELINE configs[2] itself -- 10M x 768 row-sharded over the ranks, k = 32, 4096 queries per batch
+    # (4096 / N per rank, data parallel): all-gather(queries) -> local sweep -> all-gather(exact dist, ids) -> merge
+    cfg2 = None
+    if world > 1 and not args.no_sweep:
+        cfg2 = sharded_cfg2(dev, rank, world, args.sweep_rows)
     enc_peak = BF16_MFMA_PEAK_TF / 6.0 if arith == 1 else F32_MFMA_PEAK_TF
     if rank == 0:
         enc_flops = clf.model.flops(BATCH, SEQ)
@@ -370,6 +557,7 @@ def main():
             line["roofline"] = sweep_roofline(dev, n_rows, parity=not args.no_parity)
         elif world > 1 and shard_roof is not None:
             line["roofline"] = shard_roof
+            line["configs2_sharded"] = cfg2
         if world == 1 and not args.no_parity:
             line["parity"] = step_parity(clf, hf, ids, types, mask)
         if world == 1 and not args.no_cpu_baseline:

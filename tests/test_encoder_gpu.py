@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
     (768, 2, 12, 3072, 2, 512, True),     # the reference's max_length (classifier.py:1262), 16 key tiles
     (768, 1, 12, 3072, 3, 33, True),      # one key past a tile boundary
     (1024, 2, 16, 4096, 9, 30, True),     # bert-large width with T = 270 rows: pre-split operand planes, ragged tiles
+    (1024, 24, 16, 4096, 16, 32, True),   # FULL-DEPTH bert-large = e5-large-v2 architecture (BASELINE configs[4]): 24 layers
 ])
 def test_encoder_cls_matches_transformers(hidden, layers, heads, inter, b, S, ragged, cuda_dev):
     from adaptive_classifier.encoder import HipBertEncoder
