@@ -31,9 +31,19 @@ class ShardedSearch:
     def __init__(self, local_rows, n_local, dim, row_offset, group=None, local_search=None, merge=None):
         self.rows, self.n_local, self.dim, self.row_offset = local_rows, n_local, dim, row_offset
         self.group = group
+        self._prepared = None          # bf16 planes + norms of the local shard (batched searches), built on first use
         if local_search is None or merge is None:
             from . import index as ix
-            local_search = local_search or (lambda P, n, D, Q, k, off: ix.knn_l2_topk_exact(P, n, D, Q, k, row_offset=off))
+
+            def _hip_search(P, n, D, Q, k, off):
+                # many queries x a big shard: the prepared-store GEMM-form sweep (same exact result)
+                if ix.batch_applies(n, Q.shape[0], k, auto=True):
+                    if self._prepared is None:
+                        self._prepared = ix.prepare_store(P, n, D)
+                    return ix.knn_l2_topk_exact(P, n, D, Q, k, row_offset=off, prepared=self._prepared)
+                return ix.knn_l2_topk_exact(P, n, D, Q, k, row_offset=off)
+
+            local_search = local_search or _hip_search
             merge = merge or ix.topk_merge
         self._search, self._merge = local_search, merge
         self._ws = None

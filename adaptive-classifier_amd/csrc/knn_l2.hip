@@ -386,7 +386,12 @@ struct MergeParams {
     int kp;
     int G;
     int nblk;       // entries of part_maxnorm
-    int nterms;     // max roundings any term of the sweep's fp32 sum passes through
+    double gamma;   // |sweep value - exact| <= gamma (|p| + |q|)^2: n * 2^-24 for the fp32 fma chain (n roundings per term);
+                    // the bf16x2 GEMM-form sweep adds its split-truncation term (knn_batch.hip)
+    // candidate-buffer mode (knn_batch.hip): one list of up to cand_cap entries per query instead of G lists of kp;
+    // cand_cnt[q] = entries offered (may exceed cand_cap: overflow -> exact fallback)
+    const int32_t* cand_cnt;
+    int cand_cap;
     int64_t row_offset;
     const float* part_d;
     const int32_t* part_i;
@@ -443,8 +448,10 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int n = prm.G * prm.kp;
+    const int n = prm.cand_cnt ? prm.cand_cap : prm.G * prm.kp;
     const int kp = prm.kp;
+    const int nfill = prm.cand_cnt ? (prm.cand_cnt[q] < n ? prm.cand_cnt[q] : n) : n;    // entries actually written
+    const bool overflow = prm.cand_cnt && prm.cand_cnt[q] > n;
 
     // LDS: keys[n] u32 | qrow[Dp] f32 | sel[kp] u64 | exact[kp] f64 | hist[256] | misc
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
     const int32_t* pi = prm.part_i + (size_t)q * n;
     int nreal_local = 0;
     for (int t = tid; t < n; t += kMergeThreads) {
-        const bool real = pi[t] >= 0;
+        const bool real = t < nfill && pi[t] >= 0;
         keys[t] = real ? fkey(pd[t]) : 0xffffffffu;
         nreal_local += real ? 1 : 0;
     }
@@ -489,14 +496,15 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
             int r2 = 0, c2 = 0;
             tie_id_max = (int32_t)block_radix_select(
                 n, r, [&](int t) { return (uint32_t)pi[t]; },
-                [&](int t) { return pi[t] >= 0 && keys[t] == T; }, hist, misc, &r2, &c2);
+                [&](int t) { return keys[t] != 0xffffffffu && keys[t] == T; }, hist, misc, &r2, &c2);
         }
     }
     // ---- compact the selected candidates ----
     for (int t = tid; t < n; t += kMergeThreads) {
-        const int32_t id = pi[t];
+        const uint32_t key0 = keys[t];
+        const int32_t id = key0 != 0xffffffffu ? pi[t] : -1;
         if (nsel > 0 && id >= 0) {
-            const uint32_t key = keys[t];
+            const uint32_t key = key0;
             if (key < T || (key == T && id <= tie_id_max)) {
                 const int s = atomicAdd(&misc[4], 1);
                 if (s < kp) sel[s] = ((unsigned long long)key << 32) | (uint32_t)id;
@@ -569,13 +577,13 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
             const double pn = sqrt((double)mx * 1.001), qn = sqrt(qn2);
             // fp32 fma-chain roundoff of |p|^2 - 2 q.p: every term passes through at most
             // nterms roundings, so |err| <= gamma_n * (|p|^2 + 2 sum|q_i p_i|) <= gamma_n (|p|+|q|)^2
-            const double gamma = 1.01 * (double)prm.nterms * 5.9604644775390625e-08;  // n * 2^-24
-            const double E = gamma * (pn + qn) * (pn + qn) + 1e-30;
+            const double E = prm.gamma * (pn + qn) * (pn + qn) + 1e-30;
             const double a_last = (double)fkey_inv((uint32_t)(T64 >> 32));
             // every row that was NOT re-ranked has sweep value >= a_last, hence exact
             // distance >= a_last - E + |q|^2.  The k-th re-ranked must beat that strictly.
             const double kth = dmisc[1];
-            ok = (ns >= kout) && (kth < a_last - E + qn2);
+            ok = (ns >= kout) && (kth < a_last - E + qn2) && !overflow;
+            if (prm.cand_cnt && nreal < kp) ok = 0;      // fewer than k' candidates kept: the "unseen rows >= a_last" premise is gone
         }
         int flag = 0;
         if (!ok) {
@@ -1021,7 +1029,8 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
     MergeParams mp;
     mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = pl.Dp;
     mp.k = k; mp.kp = pl.kp; mp.G = pl.G; mp.nblk = pl.G * pl.nqt;
-    mp.nterms = pl.ng * kGroup * 16 + 16;
+    mp.gamma = 1.01 * (double)(pl.ng * kGroup * 16 + 16) * 5.9604644775390625e-08;    // n * 2^-24, n roundings per term
+    mp.cand_cnt = nullptr; mp.cand_cap = 0;
     mp.row_offset = row_offset;
     mp.part_d = (const float*)(ws + pl.off_part_d);
     mp.part_i = (const int32_t*)(ws + pl.off_part_i);
@@ -1077,6 +1086,166 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
         hipLaunchKernelGGL(knn_exact_fb_merge, dim3(nq), dim3(256), (size_t)np2 * 12, stream, mp, np2);
         AC_LAUNCH_CHECK();
     }
+    return AC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// batched search with a prepared store (bf16x2 planes + row norms): sample -> thresholds -> GEMM-form filter ->
+// the same merge / fp64 re-rank / certificate / exact fallback as above (knn_batch.hip explains the scheme)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kBatchPad = 24;            // k' = k + 24 candidates re-ranked per query (the certificate's slack)
+constexpr int kBatchMaxK = 100;
+constexpr int64_t kBatchMinRows = 65536;
+
+struct BatchPlan {
+    int kp, cap, Dp;
+    int64_t stride, S, q_rows;
+    size_t off_sD32, off_sD64, off_sI, off_thr, off_cnt, off_qp, off_cd, off_ci, off_flags, off_fb_d, off_fb_i, off_fb_ctr,
+        off_sub, sub_bytes, total;
+    int fb_S, fb_F;
+    size_t merge_lds, fb_lds;
+};
+
+int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
+    AC_REQUIRE(N >= kBatchMinRows && N < 2147483647LL, AC_EUNSUPPORTED, "knn batch: N=%lld outside [%lld, 2^31)", (long long)N,
+               (long long)kBatchMinRows);
+    AC_REQUIRE(D >= 1 && nq >= 1 && k >= 1 && k <= kBatchMaxK, AC_EUNSUPPORTED, "knn batch: D=%d nq=%d k=%d unsupported (k <= %d)",
+               D, nq, k, kBatchMaxK);
+    bp->kp = k + kBatchPad;
+    bp->Dp = (D + 3) / 4 * 4;
+    int64_t stride = N / 4096;
+    if (stride > 64) stride = 64;
+    if (stride < 1) stride = 1;
+    bp->stride = stride;
+    bp->S = (N + stride - 1) / stride;
+    const int64_t expect = (int64_t)bp->kp * stride;             // E[candidates per query] = N * k' / S
+    int cap = 1024;
+    while (cap < 2 * expect) cap <<= 1;
+    if (cap > 16384) cap = 16384;
+    bp->cap = cap;
+    bp->q_rows = ((int64_t)nq + 127) / 128 * 128;
+    size_t sub = 0;
+    int rc = ac_knn_l2_topk_workspace(bp->S, D, nq, bp->kp, &sub);
+    if (rc != AC_OK) return rc;
+    bp->sub_bytes = sub;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += ac::align_up(n, 256); return o; };
+    bp->off_sD32 = take((size_t)nq * bp->kp * 4);
+    bp->off_sD64 = take((size_t)nq * bp->kp * 8);
+    bp->off_sI = take((size_t)nq * bp->kp * 8);
+    bp->off_thr = take((size_t)bp->q_rows * 4);
+    bp->off_cnt = take((size_t)bp->q_rows * 4);
+    bp->off_qp = take(ac::knn_planes_bytes(nq, D));
+    bp->off_cd = take((size_t)bp->q_rows * cap * 4);
+    bp->off_ci = take((size_t)bp->q_rows * cap * 4);
+    bp->off_flags = take((size_t)nq * 4);
+    bp->fb_S = 4096 / next_pow2(k);
+    if (bp->fb_S > 64) bp->fb_S = 64;
+    if (bp->fb_S < 1) bp->fb_S = 1;
+    bp->fb_F = nq < 64 ? nq : 64;
+    bp->off_fb_d = take((size_t)bp->fb_F * bp->fb_S * k * 8);
+    bp->off_fb_i = take((size_t)bp->fb_F * bp->fb_S * k * 4);
+    bp->off_fb_ctr = take(256);
+    bp->off_sub = take(sub);
+    bp->total = off;
+    bp->merge_lds = ac::align_up((size_t)cap * 4, 16) + ac::align_up((size_t)bp->Dp * 4, 16) + (size_t)bp->kp * 16 + 256 * 4 + 64;
+    bp->fb_lds = (size_t)kFbCap * 12 + ac::align_up((size_t)bp->Dp, 4) * 4 + 64;
+    return AC_OK;
+}
+
+}  // namespace
+
+extern "C" int ac_knn_store_bytes(int64_t N, int D, size_t* planes_bytes, size_t* norms_bytes) {
+    AC_REQUIRE(planes_bytes && norms_bytes && N >= 0 && D >= 1, AC_EINVAL, "knn_store_bytes: bad arguments");
+    *planes_bytes = ac::knn_planes_bytes(N, D);
+    *norms_bytes = (size_t)((N + 127) / 128 * 128 + 64) * sizeof(float);
+    return AC_OK;
+}
+
+extern "C" int ac_knn_prepare_store(const float* d_P, int64_t N, int64_t ldP, int D, uint16_t* d_planes, float* d_norms,
+                                    ac_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_REQUIRE(d_P && d_planes && d_norms && N >= 1 && D >= 1 && ldP >= D, AC_EINVAL, "knn_prepare_store: bad arguments");
+    AC_REQUIRE((((uintptr_t)d_planes) & 15) == 0 && (((uintptr_t)d_norms) & 15) == 0, AC_EINVAL,
+               "knn_prepare_store: planes / norms must be 16-byte aligned");
+    const int64_t np = (N + 127) / 128 * 128;
+    AC_HIP_CHECK(hipMemsetAsync(d_norms + np, 0, 64 * sizeof(float), stream));          // [np] = max |p|^2 (float bits)
+    return ac::knn_split2(d_P, ldP, N, D, 1.0f, d_planes, d_norms, reinterpret_cast<uint32_t*>(d_norms + np), stream);
+}
+
+extern "C" int ac_knn_l2_topk_batch_workspace(int64_t N, int D, int nq, int k, size_t* bytes) {
+    AC_REQUIRE(bytes != nullptr, AC_EINVAL, "knn batch workspace: bytes is NULL");
+    BatchPlan bp;
+    int rc = make_batch_plan(N, D, nq, k, &bp);
+    if (rc != AC_OK) return rc;
+    *bytes = bp.total;
+    return AC_OK;
+}
+
+extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, int D, const uint16_t* d_planes,
+                                    const float* d_norms, const float* d_Q, int nq, int64_t ldQ, int k, int64_t row_offset,
+                                    float* d_outD, double* d_outD64, int64_t* d_outI, void* d_ws, size_t ws_bytes,
+                                    int32_t* d_stats, ac_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    BatchPlan bp;
+    int rc = make_batch_plan(N, D, nq, k, &bp);
+    if (rc != AC_OK) return rc;
+    AC_REQUIRE(d_P && d_planes && d_norms && d_Q && d_outD && d_outI, AC_EINVAL, "knn batch: null pointer");
+    AC_REQUIRE(ldQ >= D && ldP >= bp.Dp && (ldP % 4) == 0 && (((uintptr_t)d_P) & 15) == 0, AC_EINVAL, "knn batch: bad leading dimension / alignment");
+    AC_REQUIRE(d_ws && ws_bytes >= bp.total, AC_EWORKSPACE, "knn batch: workspace %zu < required %zu", ws_bytes, bp.total);
+    char* ws = (char*)d_ws;
+    const int64_t np = (N + 127) / 128 * 128;
+    const uint32_t* d_maxnorm = reinterpret_cast<const uint32_t*>(d_norms + np);
+    // |v - exact| <= gamma (|p| + |q|)^2: 3 Kp + 16 accumulated terms at 2 ulp each (the MFMA's internal summation is
+    // not documented: twice the round-to-nearest bound), the dropped m.m / residual products (3.02 * 2^-16 |p_i||2 q_i| per
+    // term, sum <= 2 |p||q| <= (|p|+|q|)^2 / 2), the rounding of |p|^2 to fp32
+    const int Kp = (D + 15) / 16 * 16;
+    const double gamma = 1.01 * (2.0 * (3.0 * Kp + 16.0) * 5.9604644775390625e-08 + 0.5 * 3.02 * 1.52587890625e-05 + 5.9604644775390625e-08);
+
+    // 1. exact top-k' over the strided sample (rows 0, stride, 2 stride, ...) through the ordinary path
+    rc = ac_knn_l2_topk_x(d_P, bp.S, ldP * bp.stride, D, d_Q, nq, ldQ, bp.kp, 0, (float*)(ws + bp.off_sD32),
+                          (double*)(ws + bp.off_sD64), (int64_t*)(ws + bp.off_sI), ws + bp.off_sub, bp.sub_bytes, nullptr, stream_);
+    if (rc != AC_OK) return rc;
+    // 2. per-query filter thresholds; query planes (-2 q)
+    rc = ac::knn_thresholds((const double*)(ws + bp.off_sD64), bp.kp, d_Q, ldQ, D, nq, (int)bp.q_rows, d_maxnorm, gamma,
+                            (float*)(ws + bp.off_thr), stream);
+    if (rc != AC_OK) return rc;
+    rc = ac::knn_split2(d_Q, ldQ, nq, D, -2.0f, (uint16_t*)(ws + bp.off_qp), nullptr, nullptr, stream);
+    if (rc != AC_OK) return rc;
+    AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4, stream));
+    // 3. the GEMM-form sweep: candidates (row, v) with v below the query's threshold
+    if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
+    rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
+                              (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, stream);
+    if (rc != AC_OK) return rc;
+    if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_stop, stream));
+    // 4. merge + exact re-rank + certificate, then the exact fallback for uncertified queries
+    if (d_stats) AC_HIP_CHECK(hipMemsetAsync(d_stats, 0, 4 * sizeof(int32_t), stream));
+    MergeParams mp;
+    mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = bp.Dp;
+    mp.k = k; mp.kp = bp.kp; mp.G = 1; mp.nblk = 1; mp.gamma = gamma;
+    mp.cand_cnt = (const int32_t*)(ws + bp.off_cnt); mp.cand_cap = bp.cap;
+    mp.row_offset = row_offset;
+    mp.part_d = (const float*)(ws + bp.off_cd); mp.part_i = (const int32_t*)(ws + bp.off_ci);
+    mp.part_maxnorm = reinterpret_cast<const float*>(d_maxnorm);
+    mp.outD = d_outD; mp.outD64 = d_outD64; mp.outI = d_outI;
+    mp.flags = (int32_t*)(ws + bp.off_flags);
+    mp.stats = d_stats;
+    mp.fb_S = bp.fb_S; mp.fb_F = bp.fb_F;
+    mp.fb_d = (double*)(ws + bp.off_fb_d); mp.fb_i = (int32_t*)(ws + bp.off_fb_i); mp.fb_slotctr = (int32_t*)(ws + bp.off_fb_ctr);
+    AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_fb_ctr, 0, 256, stream));
+    (void)hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.merge_lds);
+    hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), bp.merge_lds, stream, mp);
+    AC_LAUNCH_CHECK();
+    (void)hipFuncSetAttribute((const void*)knn_exact_fallback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.fb_lds);
+    hipLaunchKernelGGL(knn_exact_fallback, dim3(bp.fb_S, nq), dim3(kFbThreads), bp.fb_lds, stream, mp);
+    AC_LAUNCH_CHECK();
+    const int np2 = next_pow2(bp.fb_S * k > 2 ? bp.fb_S * k : 2);
+    (void)hipFuncSetAttribute((const void*)knn_exact_fb_merge, hipFuncAttributeMaxDynamicSharedMemorySize, np2 * 12);
+    hipLaunchKernelGGL(knn_exact_fb_merge, dim3(nq), dim3(256), (size_t)np2 * 12, stream, mp, np2);
+    AC_LAUNCH_CHECK();
     return AC_OK;
 }
 

@@ -182,11 +182,14 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
                 calls.append(c0.elapsed_time(c1))
         finally:
             nv.lib().ac_knn_set_profile_events(None, None)
+        if nq == 16:
+            keep["ids16"] = out[1].clone()
         if nq == 16 and parity:
             par["v"] = sweep_parity(P, n_rows, Q, out[1], k)
         return float(np.mean(times)), float(np.min(times)), float(np.mean(calls)), int(stats[0].item())
 
     par = {"v": None}
+    keep = {"ids16": None}
     ms, ms_min, call_ms, nfb = measure(16, 8)
     table = {}
     for nq in ((1, 8, 16, 32) if full else (16,)):
@@ -195,24 +198,28 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
                           "whole_call_ms": c}
     # BASELINE configs[2] on this one GPU: 4096 queries x the whole store, k = 32 (compute-bound regime, whole call)
     batch = None
+    out16_ids = keep["ids16"]           # ids of the 16 roofline queries (= the first 16 of the 4096-query batch, same seed)
     if full:
         nqb = 4096
         Qb = ix.synth_unit_rows(nqb, DIM, 2, device=dev)
-        wsb = torch.empty(ix.knn_workspace_bytes(n_rows, DIM, nqb, k), dtype=torch.uint8, device=dev)
+        prep = ix.prepare_store(P, n_rows, DIM)        # bf16 (h, m) planes + row norms, once per store
+        wsb = torch.empty(ix.knn_batch_workspace_bytes(n_rows, DIM, nqb, k), dtype=torch.uint8, device=dev)
         stb = torch.zeros(4, dtype=torch.int32, device=dev)
         outb = (torch.empty((nqb, k), dtype=torch.float32, device=dev), torch.empty((nqb, k), dtype=torch.int64, device=dev))
-        ix.knn_l2_topk(P, n_rows, DIM, Qb, k, out=outb, workspace=wsb, stats=stb)
+        ix.knn_l2_topk(P, n_rows, DIM, Qb, k, out=outb, workspace=wsb, stats=stb, prepared=prep)
         torch.cuda.synchronize()
         b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         b0.record()
         for _ in range(2):
-            ix.knn_l2_topk(P, n_rows, DIM, Qb, k, out=outb, workspace=wsb, stats=stb)
+            ix.knn_l2_topk(P, n_rows, DIM, Qb, k, out=outb, workspace=wsb, stats=stb, prepared=prep)
         b1.record(); torch.cuda.synchronize()
         bms = b0.elapsed_time(b1) / 2
         batch = {"workload": "BASELINE configs[2] on ONE GPU: %d x %d store, k=%d, batch %d" % (n_rows, DIM, k, nqb),
-                 "ms_per_batch": bms, "queries_per_s": nqb / bms * 1e3, "TFLOPs": 2.0 * nqb * n_rows * DIM / bms / 1e9,
-                 "exact_fallback_queries": int(stb[0].item())}
-        del Qb, wsb, outb
+                 "path": "prepared store: bf16x2 GEMM-form proposals (3 MFMA products) + fp64 re-rank / certificate (ac_knn_l2_topk_batch)",
+                 "ms_per_batch": bms, "queries_per_s": nqb / bms * 1e3, "TFLOPs_fp32_equiv": 2.0 * nqb * n_rows * DIM / bms / 1e9,
+                 "exact_fallback_queries": int(stb[0].item()),
+                 "ids_equal_fp32_sweep_subset": bool(torch.equal(outb[1][:16], out16_ids)) if out16_ids is not None else None}
+        del Qb, wsb, outb, prep
     # HBM traffic per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 gfx950 correction,
     # profiles/<round>/knn_sweep_pmc.json); null when no pass exists for this problem size.
     traffic, traffic_src = None, None

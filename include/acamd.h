@@ -99,6 +99,28 @@ int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
                      ac_stream_t stream);
 
 /*
+ * Batched search over a PREPARED store (many queries: predict_batch, BASELINE configs[2] / [4]).  Same result
+ * contract as ac_knn_l2_topk_x -- the ids are the exact top-k, bit for bit -- but the proposal sweep runs as a
+ * GEMM on the bf16 matrix pipe (three split products, 3/16 of the fp32-input MFMA time; knn_batch.hip) and only
+ * the re-rank / certificate / fallback stay in fp64.
+ *   ac_knn_store_bytes       sizes of the two auxiliary buffers of a store of N rows
+ *   ac_knn_prepare_store     fills them from the fp32 rows: d_planes = bf16 (h, m) planes, k-slot-major;
+ *                            d_norms = |p|^2 per row (+ the maximum at [round_up(N,128)]).  Redo after any row changes.
+ *   ac_knn_l2_topk_batch     N >= 65536, k <= 100 (AC_EUNSUPPORTED otherwise: use ac_knn_l2_topk_x); d_stats as above
+ */
+int ac_knn_store_bytes(int64_t N, int D, size_t* planes_bytes, size_t* norms_bytes);
+int ac_knn_prepare_store(const float* d_P, int64_t N, int64_t ldP, int D,
+                         uint16_t* d_planes, float* d_norms, ac_stream_t stream);
+int ac_knn_l2_topk_batch_workspace(int64_t N, int D, int nq, int k, size_t* bytes);
+int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, int D,
+                         const uint16_t* d_planes, const float* d_norms,
+                         const float* d_Q, int nq, int64_t ldQ, int k,
+                         int64_t row_offset,
+                         float* d_outD, double* d_outD64, int64_t* d_outI,
+                         void* d_ws, size_t ws_bytes, int32_t* d_stats,
+                         ac_stream_t stream);
+
+/*
  * Optional profiling hook: when both events are non-NULL, every following
  * ac_knn_l2_topk call of THIS thread records `start` immediately before and
  * `stop` immediately after its sweep kernel (the HBM-bound kernel) on the

@@ -126,6 +126,12 @@ def test_cfg2_10M_k32_nq4096_subset_and_properties(cuda_dev):
     # the HBM-bound configuration the roofline is quoted on (16 resident queries, knn_sweep<1>) gives the same ids
     D16, I16 = ix.knn_l2_topk(P, N, D, Q[:16], k)
     assert torch.equal(I16, Id[:16]) and torch.equal(D16, Dd[:16])
+    # ... and so does the prepared-store batched path (bf16x2 GEMM-form proposals), all 4096 queries
+    prep = ix.prepare_store(P, N, D)
+    stb = torch.zeros(4, dtype=torch.int32, device=cuda_dev)
+    Db, Ib = ix.knn_l2_topk(P, N, D, Q, k, stats=stb, prepared=prep)
+    assert torch.equal(Ib, Id) and torch.equal(Db, Dd)
+    print("cfg2 batched path: exact-fallback queries =", int(stb[0].item()))
 
 
 def test_cfg4_2M_x1024_k32_nq1024_subset(cuda_dev):
@@ -143,3 +149,5 @@ def test_cfg4_2M_x1024_k32_nq1024_subset(cuda_dev):
     oD, oI = c_oracle.knn_l2_topk_chunked(_device_chunks(P, N, D, rows=500_000), Qh, k)
     assert np.array_equal(i[sel], oI), f"{(i[sel] != oI).sum()} id mismatches"
     assert _ulp_close(d[sel], oD)
+    Db, Ib = ix.knn_l2_topk(P, N, D, Q, k, prepared=ix.prepare_store(P, N, D))          # the batched path: identical
+    assert torch.equal(Ib, Id) and torch.equal(Db, Dd)

@@ -1,0 +1,123 @@
+"""The batched (prepared-store, GEMM-form bf16x2 proposal) kNN path -- ac_knn_prepare_store + ac_knn_l2_topk_batch --
+against the exact oracle and against the fp32 sweep path: same contract, ids bit-exact, distances = exact fp64 rounded
+once (1 ulp across summation orders).  The proposal arithmetic differs (bf16 split products), the answer may not."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import near_tie_store
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_close(a, b):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    return np.all(np.abs(a - b) <= np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)))
+
+
+def _store(Ph, dev):
+    N, D = Ph.shape
+    ld = (D + 3) // 4 * 4
+    P = torch.zeros((N, ld), dtype=torch.float32, device=dev)
+    P[:, :D] = torch.from_numpy(Ph).to(dev)
+    return P
+
+
+def _run(Ph, Qh, k, dev, row_offset=0):
+    from adaptive_classifier import index as ix
+    N, D = Ph.shape
+    P, Q = _store(Ph, dev), torch.from_numpy(Qh).to(dev)
+    prep = ix.prepare_store(P, N, D)
+    assert ix.batch_applies(N, Q.shape[0], k)
+    st = torch.zeros(4, dtype=torch.int32, device=dev)
+    ex = torch.empty((Q.shape[0], k), dtype=torch.float64, device=dev)
+    Db, Ib = ix.knn_l2_topk(P, N, D, Q, k, row_offset=row_offset, stats=st, exact_out=ex, prepared=prep)
+    Ds, Is = ix.knn_l2_topk(P, N, D, Q, k, row_offset=row_offset)              # the fp32 sweep path
+    torch.cuda.synchronize()
+    assert torch.equal(Ib, Is) and torch.equal(Db, Ds)
+    assert torch.equal(ex.float(), Db)
+    return Db.cpu().numpy(), Ib.cpu().numpy(), int(st[0].item())
+
+
+@pytest.mark.parametrize("N,D,nq,k", [
+    (200_000, 768, 256, 16),       # BASELINE configs[1] shape at twice the rows
+    (70_001, 100, 65, 8),          # D % 16 != 0 (zero-padded k-slots), ragged row / query tiles
+    (131_072, 1024, 128, 32),      # e5-large width, exact tile multiples
+    (65_536, 770, 64, 100),        # D % 4 != 0, the largest k of the batched path, the smallest store
+])
+def test_batched_path_matches_oracle(N, D, nq, k, cuda_dev):
+    from oracle import c_oracle, synth
+    Ph = synth.synth_unit_rows(N, D, 1)
+    Qh = synth.synth_unit_rows(nq, D, 2)
+    d, i, nfb = _run(Ph, Qh, k, cuda_dev, row_offset=7)
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, k, row_offset=7)
+    assert np.array_equal(i, oI), f"{(i != oI).sum()} id mismatches"
+    assert _ulp_close(d, oD)
+    assert nfb <= 2                                                   # uniform synthetic rows: the certificate holds
+
+
+def test_batched_path_unnormalised_and_scaled_rows(cuda_dev):
+    """Rows and queries far from unit norm (the error bound scales with (|p| + |q|)^2)."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(5)
+    Ph = (rng.standard_normal((80_000, 256)) * 3 + 0.5).astype(np.float32)
+    Qh = (rng.standard_normal((70, 256)) * 0.3).astype(np.float32)
+    d, i, _ = _run(Ph, Qh, 10, cuda_dev)
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, 10)
+    assert np.array_equal(i, oI) and _ulp_close(d, oD)
+
+
+def test_batched_path_near_ties_and_duplicates(cuda_dev):
+    """Stores full of fp32-unresolvable near-ties and exact duplicates: whatever the bf16 proposal orders, the result is
+    the exact-definition top-k (fp64 re-rank, certificate, exact fallback; ties to the lower id)."""
+    from oracle import c_oracle, synth
+    D, k = 768, 16
+    Ph, centres = near_tie_store(90_000, D, 7)
+    Ph[50_000:50_300] = Ph[100:400]                                    # exact duplicates of earlier rows
+    Qh = np.concatenate([(centres[:40] + synth.synth_unit_rows(40, D, 8) * 1e-3), Ph[100:124]]).astype(np.float32)
+    d, i, nfb = _run(Ph, Qh, k, cuda_dev)
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, k)
+    assert np.array_equal(i, oI) and _ulp_close(d, oD)
+    print("near-tie store, batched path: exact-fallback queries =", nfb)
+
+
+def test_batched_path_candidate_overflow_goes_to_exact_fallback(cuda_dev):
+    """One tight cluster: every row passes every query's sample threshold, the candidate buffers overflow, and all
+    queries must come back exact through the fp64 fallback."""
+    from oracle import c_oracle, synth
+    D, k, N = 128, 8, 70_000
+    c = synth.synth_unit_rows(1, D, 3)
+    rng = np.random.default_rng(1)
+    Ph = (c + rng.standard_normal((N, D)).astype(np.float32) * 1e-4).astype(np.float32)
+    Qh = (c + rng.standard_normal((64, D)).astype(np.float32) * 1e-4).astype(np.float32)
+    d, i, nfb = _run(Ph, Qh, k, cuda_dev)
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, k)
+    assert np.array_equal(i, oI) and _ulp_close(d, oD)
+    assert nfb == 64
+
+
+def test_index_uses_the_batched_path_and_invalidates_on_change(cuda_dev, request):
+    """HipFlatL2Index prepares the store lazily for many-query searches and drops the planes when rows change."""
+    from adaptive_classifier.index import HipFlatL2Index
+    from oracle import c_oracle, synth
+    D = 64
+    X = synth.synth_unit_rows(70_000, D, 11)
+    Q = synth.synth_unit_rows(80, D, 12)
+    idx = HipFlatL2Index(D, device=cuda_dev)
+    idx.add(X)
+    from adaptive_classifier import index as ixm
+    old = ixm.BATCH_MIN_PAIRS
+    ixm.BATCH_MIN_PAIRS = 1.0                                          # (the auto heuristic would keep this small case on the sweep)
+    request.addfinalizer(lambda: setattr(ixm, "BATCH_MIN_PAIRS", old))
+    d, i = idx.search(Q, 5)
+    assert idx._prepared is not None
+    assert np.array_equal(i, c_oracle.knn_l2_topk_batch(X, Q, 5)[1])
+    idx.update_rows([3], Q[:1])                                        # row 3 := query 0 -> must be found at distance 0
+    assert idx._prepared is None
+    d, i = idx.search(Q, 5)
+    assert i[0, 0] == 3 and d[0, 0] == 0.0
+    X2 = X.copy(); X2[3] = Q[0]
+    assert np.array_equal(i, c_oracle.knn_l2_topk_batch(X2, Q, 5)[1])
+    d1, i1 = idx.search(Q[:8], 5)                                      # few queries: the fp32 sweep path, same answer
+    assert np.array_equal(i1, i[:8]) and np.array_equal(d1, d[:8])
