@@ -363,3 +363,4 @@ def test_batched_device_prune_equals_per_example_host_logic(cap, D, stream, cuda
     a._rebuild_index(); b._rebuild_index()
     ra, rb = a.get_nearest_prototypes(q, 3), b.get_nearest_prototypes(q, 3)
     assert [l for l, _ in ra] == [l for l, _ in rb] and np.allclose([s for _, s in ra], [s for _, s in rb], atol=1e-6)
+
