@@ -58,6 +58,12 @@ class ac_modernbert_weights(ctypes.Structure):
         "wi", "wi_b", "wo2", "wo2_b", "zero_bias", "wqkv3", "wo3", "wi3", "wo23")] + [("wi_interleaved32", c_int)]
 
 
+class ac_wordpiece_vocab(ctypes.Structure):
+    _fields_ = [("keys", c_void_p), ("offs", c_void_p), ("ids", c_void_p), ("lens", c_void_p), ("blob", c_void_p),
+                ("slots", c_int), ("max_piece_bytes", c_int), ("unk_id", c_int), ("cls_id", c_int), ("sep_id", c_int),
+                ("pad_id", c_int), ("lower_case", c_int)]
+
+
 class ac_bert_weights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b",
@@ -133,6 +139,9 @@ _SIGNATURES = {
     "ac_modernbert_encode_cls": (c_int, [ctypes.POINTER(ac_modernbert_config), ctypes.POINTER(ac_modernbert_weights),
                                          c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
                                          c_void_p]),
+    "ac_wordpiece_hash": (c_uint64, [c_void_p, c_int, c_int]),
+    "ac_wordpiece_encode": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(ac_wordpiece_vocab), c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
     "ac_bert_workspace": (c_int, [ctypes.POINTER(ac_bert_config), c_int, c_int, ctypes.POINTER(c_size_t)]),
     "ac_bert_encode_cls": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,

@@ -67,6 +67,10 @@ class AdaptiveClassifier:
             if tokenizer is None:
                 tokenizer = AutoTokenizer.from_pretrained(model_name, trust_remote_code=trust_remote_code)
         self.model = encoder
+        if tokenizer is not None and (config or {}).get("device_tokenizer", True):
+            # BERT WordPiece vocabularies are tokenised on the device (ac_wordpiece_encode); anything else stays as given
+            from .tokenizer import maybe_device_tokenizer
+            tokenizer = maybe_device_tokenizer(tokenizer, self.device)
         self.tokenizer = tokenizer
         self.embedding_dim = self.model.config.hidden_size
         self.memory = PrototypeMemory(self.embedding_dim, config=self.config, device=self.device)

@@ -517,6 +517,40 @@ int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const ac_modernber
                              float* d_out_unit_cls, int64_t ldo,
                              void* d_ws, size_t ws_bytes, ac_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ *  T: tokenizer  (self.tokenizer(texts, max_length, truncation=True, padding=True), classifier.py:1259-1265)
+ * ------------------------------------------------------------------------- */
+
+/* A BERT WordPiece vocabulary as an open-addressing hash table in device memory (built by the host wrapper):
+ * slot of a piece = (h ^ (h >> 32)) & (slots - 1), linear probing, h = ac_wordpiece_hash(piece bytes, continuation). */
+typedef struct ac_wordpiece_vocab {
+    const uint64_t* keys;       /* [slots] stored hash, 0 = empty slot */
+    const uint32_t* offs;       /* [slots] offset of the piece's bytes in blob ("##" prefix stripped) */
+    const int32_t* ids;         /* [slots] token id, bit 30 set for continuation ("##...") pieces */
+    const uint16_t* lens;       /* [slots] byte length ("##" prefix stripped) */
+    const uint8_t* blob;        /* concatenated piece bytes */
+    int slots;                  /* power of two */
+    int max_piece_bytes;        /* longest piece */
+    int unk_id, cls_id, sep_id, pad_id;
+    int lower_case;             /* 1 = lower-case A-Z (uncased vocabularies) */
+} ac_wordpiece_vocab;
+
+/* FNV-1a 64 over the piece bytes ("##" folded into the initial state when continuation != 0); never returns 0. */
+uint64_t ac_wordpiece_hash(const uint8_t* bytes, int len, int continuation);
+
+/*
+ * Tokenise b ASCII texts on the device exactly as transformers' BertTokenizer does (BertNormalizer clean_text +
+ * lowercase, BertPreTokenizer, greedy longest-match WordPiece with [UNK] for unmatched / over-long words,
+ * [CLS] ... [SEP], truncation to max_length, padding with pad_id):
+ *   d_text / d_offsets  the texts' bytes back to back, int32 offsets [b + 1]; each text <= 4096 bytes, ASCII only,
+ *                       free of literal special-token strings (the caller routes other texts to the host tokenizer)
+ *   d_ids, d_mask       int64 [b, max_length] token ids (padded) and attention mask
+ *   d_lens              int32 [b] sequence lengths incl. [CLS] / [SEP]
+ */
+int ac_wordpiece_encode(const uint8_t* d_text, const int32_t* d_offsets, int b,
+                        const ac_wordpiece_vocab* vocab, int max_length,
+                        int64_t* d_ids, int64_t* d_mask, int32_t* d_lens, ac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -411,3 +411,27 @@ def test_mirrors_follow_direct_edits_of_examples_with_unchanged_length():
     assert sorted(e.text for e in mem.examples["a"]) == sorted(["new0", "far", "t2", "new3", "t4", "t5", "t6", "t7", "t8",
                                                                  "t9", "t10", "t11", "t12"][i] for i in keep.tolist())
     assert torch.allclose(mem.prototypes["a"], allr[keep].mean(0), atol=1e-6)
+
+
+def test_wordpiece_hash_and_tokenizer_recognition():
+    """CPU side of the device tokenizer: ac_wordpiece_hash is FNV-1a 64 with the "##" prefix folded in, and only BERT
+    WordPiece tokenizers (BertNormalizer + BertPreTokenizer + WordPiece) are taken over."""
+    import ctypes
+    from transformers import BertTokenizer
+    from adaptive_classifier import _native as nv
+    from adaptive_classifier.tokenizer import _wordpiece_spec
+
+    def fnv(b, cont):
+        h = 0xcbf29ce484222325
+        for c in (b"##" if cont else b"") + b:
+            h = ((h ^ c) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        return h or 1
+
+    for raw, cont in ((b"play", 0), (b"ing", 1), (b"a", 0), (b"x" * 40, 1)):
+        buf = (ctypes.c_uint8 * len(raw)).from_buffer_copy(raw)
+        assert nv.lib().ac_wordpiece_hash(buf, len(raw), cont) == fnv(raw, cont)
+    vocab = {t: i for i, t in enumerate(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "a", "##b"])}
+    spec = _wordpiece_spec(BertTokenizer(vocab=vocab, do_lower_case=False))
+    assert spec is not None and spec[0] == vocab and spec[1] is False and "[SEP]" in spec[2]
+    from helpers import HashTokenizer
+    assert _wordpiece_spec(HashTokenizer()) is None
