@@ -216,11 +216,15 @@ class AdaptiveClassifier:
             # but the last has batch_size rows (drop_last=False): one native call runs the whole epoch
             order = epoch_order.next_epoch().to(X.device)
             nb0 = min(batch_size, n_rows)
-            steps += trainer.fused_epoch(X, y, order, nb0, AdaptiveHead.DROPOUT_P, base_seed + steps,
+            # rows laid out in epoch order once (one device gather per epoch instead of one gather launch per step)
+            Xe = X.index_select(0, order)
+            ye = None if y is None else y.index_select(0, order)
+            te = None if targets is None else targets.index_select(0, order)
+            steps += trainer.fused_epoch(Xe, ye, None, nb0, AdaptiveHead.DROPOUT_P, base_seed + steps,
                                          fisher=None if ewc is None else ewc.fisher_flat,
                                          old_params=None if ewc is None else ewc.old_flat,
                                          lambda_B=0.0 if ewc is None else lambda_B, loss_kind=loss_kind,
-                                         targets_all=targets)
+                                         targets_all=te)
             total = trainer.loss_accum
             avg_loss = float(total.item()) / steps_per_epoch    # the only host sync of the epoch
             if sched is not None:
@@ -240,20 +244,22 @@ class AdaptiveClassifier:
         """classifier.py:1428-1522: retrain on everything stored, sorted by (label, text)."""
         if not self.memory.examples:
             return
-        blocks, labs = [], []
+        # The training matrix is assembled ON THE DEVICE from the memory's device-resident class matrices: per call only
+        # the row permutation (sorted labels, then sorted texts) crosses PCIe, not the stored embeddings.
+        dev = torch.device(self.device)
+        mats, perm, labs, off = [], [], [], 0
         for label in sorted(self.memory.examples.keys()):
             exs = self.memory.examples[label]
-            if not exs:
+            n = len(exs)
+            if not n:
                 continue
-            order = sorted(range(len(exs)), key=lambda i: exs[i].text)           # stable, like sorted(examples, key=text)
-            ent = self.memory._mats.get(label)
-            if ent is not None and ent[1] == len(exs) and self.memory._mirror_valid(label, len(exs)):
-                # the memory's class matrix mirrors the list: one gather instead of stacking n small tensors
-                blocks.append(ent[0][:len(exs)][torch.tensor(order, dtype=torch.long)])
-            else:
-                blocks.append(torch.stack([exs[i].embedding for i in order]).to(torch.float32))
-            labs.extend([self.label_to_id[label]] * len(exs))
-        X = l2_normalize_rows(torch.cat(blocks).to(self.device))                # :1450
+            order = sorted(range(n), key=lambda i: exs[i].text)                  # stable, like sorted(examples, key=text)
+            mats.append(self.memory.device_class_matrix(label, dev)[0][:n])
+            perm.extend(off + i for i in order)
+            off += n
+            labs.extend([self.label_to_id[label]] * n)
+        allm = mats[0] if len(mats) == 1 else torch.cat(mats)
+        X = l2_normalize_rows(allm[torch.tensor(perm, dtype=torch.long).to(dev)])                     # :1450
         y = torch.tensor(labs, dtype=torch.long, device=self.device)
         self._run_epochs(X, y, batch_size=min(32, X.shape[0]), epochs=epochs, use_scheduler=True)
 

@@ -50,6 +50,8 @@ class PrototypeMemory:
         self._sums = {}                      # label -> (fp64 running sum of the stored embeddings, count)
         self._mats = {}                      # label -> [host matrix of the stored embeddings, count]
         self._fps = {}                       # label -> (count, identity fingerprint) the two caches above describe
+        self._dmats = {}                     # label -> [DEVICE matrix of the stored embeddings, count, fingerprint]: input of the
+                                             # device prune and of the training-set assembly (no per-call re-upload)
         self._dirty = set()                  # labels whose index row is out of date
         self._lock = threading.RLock()       # add_example is called from threads (test_memory.py:226-256)
         self._row_labels = None              # int32 device tensor when load_rows() is in use
@@ -75,6 +77,27 @@ class PrototypeMemory:
         """True iff the caches of `label` describe exactly examples[label][:n]."""
         fp = self._fps.get(label)
         return fp is not None and fp[0] == n and fp[1] == self._fingerprint(self.examples[label], n)
+
+    def device_class_matrix(self, label, dev, room=0):
+        """[rows >= n + room, D] fp32 matrix on `dev` whose first n = len(examples[label]) rows are the class's stored
+        embeddings in list order.  Kept in step by add_examples_batch (appends / device prune write it in place); rebuilt
+        from the list whenever the list was edited from outside (identity fingerprint)."""
+        exs = self.examples[label]
+        n = len(exs)
+        dev = torch.device(dev)
+        ent = self._dmats.get(label)
+        fp = self._fingerprint(exs, n)
+        if ent is None or ent[0].device != dev or ent[1] != n or ent[2] != fp:
+            d = torch.empty((max(n + room, 64), self.embedding_dim), dtype=torch.float32, device=dev)
+            if n:
+                d[:n] = torch.stack([e.embedding.detach().to(torch.float32) for e in exs]).to(dev)
+            ent = [d, n, fp]
+        elif ent[0].shape[0] < n + room:
+            d = torch.empty((max(n + room, 2 * ent[0].shape[0]), self.embedding_dim), dtype=torch.float32, device=dev)
+            d[:n] = ent[0][:n]
+            ent[0] = d
+        self._dmats[label] = ent
+        return ent
 
     # ------------------------------------------------------------------ add / prune / prototype
     def _class_matrix(self, label, n_needed):
@@ -168,6 +191,24 @@ class PrototypeMemory:
                         self._add_one_no_counters(ex, label)
                     continue
                 fresh = torch.stack([e.embedding.detach().to(torch.float32) for e in new])
+                if dev is not None and dev.type == "cuda":
+                    # device-resident class matrix: only the k new rows cross PCIe
+                    trusted = self._mirror_valid(label, n0)
+                    dm = self.device_class_matrix(label, dev, room=k)
+                    cached = self._sums.get(label)
+                    total = (cached[0] if cached is not None and cached[1] == n0 and trusted
+                             else dm[0][:n0].double().sum(0).cpu())
+                    dm[0][n0:n0 + k] = fresh.to(dev, non_blocking=True)
+                    self._mats.pop(label, None)            # the host mirror is not maintained on this path
+                    if n0 + k <= cap:
+                        lst.extend(new)
+                        self._sums[label] = (total + fresh.double().sum(0), n0 + k)
+                        self._stamp(label)
+                        dm[1], dm[2] = n0 + k, self._fps[label][1]
+                        self._update_prototype(label)
+                    else:
+                        jobs.append((label, lst, new, dm, None, total, n0, k))
+                    continue
                 ent = self._mats.get(label)
                 trusted = self._mirror_valid(label, n0)
                 if ent is None or ent[1] != n0 or not trusted:   # (re)build the mirror of the stored rows
@@ -193,8 +234,7 @@ class PrototypeMemory:
                     self._stamp(label)
                     self._update_prototype(label)
                     continue
-                rows = torch.cat([ent[0][:n0], fresh])
-                jobs.append((label, lst, new, ent, rows, total, n0, k))
+                raise AssertionError("unreachable: an overflowing class without a GPU takes the per-example path above")
             if jobs:
                 self._run_prune_jobs(jobs, cap, D, dev)
             # the counter / lazy-rebuild state machine of memory.py:70-81, once per example
@@ -214,20 +254,20 @@ class PrototypeMemory:
                 self.updates_since_rebuild = pending
 
     def _run_prune_jobs(self, jobs, cap, D, dev):
-        """One `ac_memory_add_prune` launch for all overflowing classes of a call, then the host-side update of
-        each class (list in ascending-distance order, class matrix, fp64 sum, prototype)."""
+        """One `ac_memory_add_prune` launch for all overflowing classes of a call, reading the classes' DEVICE matrices
+        in place (old rows + the just-written new rows), then the update of each class: list in ascending-distance order,
+        device matrix compacted in that order, fp64 sum, prototype."""
         nj = len(jobs)
         ntot = sum(j[6] + j[7] for j in jobs)
-        d_rows = torch.cat([j[4] for j in jobs]).to(dev)                       # all classes' rows, one H2D
         d_sum = torch.stack([j[5] for j in jobs]).to(dev).contiguous()         # [nj, D] fp64
         d_alive = torch.empty(ntot, dtype=torch.uint8, device=dev)
         d_dist = torch.empty(ntot, dtype=torch.float64, device=dev)
         d_drop = torch.empty(sum(j[7] for j in jobs), dtype=torch.int32, device=dev)
         arr = (nv.ac_prune_job * nj)()
         off = doff = 0
-        for i, (_, _, _, _, rows, _, n0, k) in enumerate(jobs):
-            arr[i].rows = d_rows.data_ptr() + off * d_rows.stride(0) * 4
-            arr[i].ld = d_rows.stride(0)
+        for i, (_, _, _, dm, _, _, n0, k) in enumerate(jobs):
+            arr[i].rows = dm[0].data_ptr()
+            arr[i].ld = dm[0].stride(0)
             arr[i].n_old, arr[i].n_new, arr[i].cap, arr[i].reserved = n0, k, cap, 0
             arr[i].sum = d_sum.data_ptr() + i * D * 8
             arr[i].alive = d_alive.data_ptr() + off
@@ -244,7 +284,7 @@ class PrototypeMemory:
         dist_all = d_dist.cpu().numpy()
         sums = d_sum.cpu()
         off = 0
-        for i, (label, lst, new, ent, rows, _, n0, k) in enumerate(jobs):
+        for i, (label, lst, new, dm, _, _, n0, k) in enumerate(jobs):
             alive, dist = alive_all[off: off + n0 + k], dist_all[off: off + n0 + k]
             off += n0 + k
             kept = np.nonzero(alive)[0]
@@ -253,13 +293,11 @@ class PrototypeMemory:
             everything = lst + new
             self.examples[label] = [everything[i_] for i_ in order.tolist()]
             n = len(order)
-            if ent[0].shape[0] < n + 1:
-                ent = [torch.empty((max(n + 1, 64), D), dtype=torch.float32), 0]
-            ent[0][:n] = rows[torch.from_numpy(np.ascontiguousarray(order))]
-            ent[1] = n
-            self._mats[label] = ent
+            sel = torch.from_numpy(np.ascontiguousarray(order)).to(dev)
+            dm[0][:n] = dm[0][sel]                                   # (advanced indexing materialises the gather first)
             self._sums[label] = (sums[i].clone(), n)
             self._stamp(label)
+            dm[1], dm[2] = n, self._fps[label][1]
             self._update_prototype(label)
 
     def _add_one_no_counters(self, example: Example, label: str):
@@ -461,6 +499,7 @@ class PrototypeMemory:
             self.prototypes.clear()
             self._sums.clear()
             self._mats.clear()
+            self._dmats.clear()
             self._fps.clear()
             self._dirty.clear()
             self.index = self._new_index()
@@ -474,5 +513,6 @@ class PrototypeMemory:
         """Forget cached sums when the classifier deletes a label's examples (classifier.py:1396-1399)."""
         self._sums.pop(label, None)
         self._mats.pop(label, None)
+        self._dmats.pop(label, None)
         self._fps.pop(label, None)
         self._dirty.discard(label)

@@ -124,8 +124,9 @@ class HeadTrainer:
                     lambda_B=0.0, loss_kind=LOSS_CE, targets_all=None):
         """One call = one epoch of fused steps over consecutive `batch`-row slices of `order`
         (`ac_head_train_epoch`): step i uses dropout seed seed0 + i; EWC weight lambda_B / rows_i.
-        Returns the number of steps taken."""
-        n_total = int(order.numel())
+        order=None: X_all / y_all / targets_all are already in epoch order (batches = consecutive row slices, no
+        per-step gather).  Returns the number of steps taken."""
+        n_total = int(order.numel()) if order is not None else int(X_all.shape[0])
         ws = self._workspace(min(batch, max(n_total, 1)))
         done = ctypes.c_int(0)
         with torch.cuda.device(self.device):

@@ -119,4 +119,9 @@ int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const flo
              const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* gate,
              int64_t ldg, float gate_scale, hipStream_t stream);
 
+// The head's backward through one hidden layer in ONE launch (B <= 32): gW[Hout,Hin] = dY^T Aact, dA[B,Hin] = (dY W) gated by
+// Aact != 0 (x gate_scale), gb_in[Hin] = column sums of dA (rows ascending).  gemm.hip.
+int head_backward_pair(const float* dY, int64_t ldy, const float* Aact, int64_t lda_act, const float* W, int64_t ldw, int B,
+                       int Hout, int Hin, float gate_scale, float* gW, float* dA, float* gb_in, hipStream_t stream);
+
 }  // namespace ac

@@ -435,14 +435,15 @@ __device__ __forceinline__ f32x4 load_frag(const float* base, int64_t ld, int id
     return v;
 }
 
+// one 32 x 32 output tile at (m0, n0); `red` = the block's [4][16][64] LDS reduction buffer.
+// colsum != nullptr (requires M <= 32, m0 == 0): also colsum[col] = sum over the tile's rows of the stored values, rows
+// in ascending order (the bias gradient of the layer below: column sums of dA).
 template <bool AK, bool BKM>
-__global__ __launch_bounds__(256) void gemm_direct(const float* __restrict__ A, int64_t lda,
-                                                   const float* __restrict__ B, int64_t ldb,
-                                                   float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                   Epilogue epi) {
-    __shared__ float red[4][16][64];
+__device__ __forceinline__ void gemm_direct_tile(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                 int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                 const Epilogue& epi, int m0, int n0, float (*red)[16][64],
+                                                 float* __restrict__ colsum) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int i = lane & 31, h = lane >> 5;
     int arow = m0 + i; if (arow > M - 1) arow = M - 1;
     int bcol = n0 + i; if (bcol > N - 1) bcol = N - 1;
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(256) void gemm_direct(const float* __restrict__ A, 
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
     // 1024 outputs, 4 per thread; fixed summation order over the 4 K-slices
+    float outv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int o = tid + 256 * e;          // o = r * 64 + l
@@ -472,7 +474,52 @@ __global__ __launch_bounds__(256) void gemm_direct(const float* __restrict__ A, 
         const float v = ((red[0][r][l] + red[1][r][l]) + red[2][r][l]) + red[3][r][l];
         const int64_t row = m0 + acc_row32(r, l);
         const int col = n0 + (l & 31);
-        if (row < M && col < N) C[row * ldc + col] = apply_epilogue(epi, v, row, col, C, ldc, N);
+        outv[e] = 0.f;
+        if (row < M && col < N) { outv[e] = apply_epilogue(epi, v, row, col, C, ldc, N); C[row * ldc + col] = outv[e]; }
+    }
+    if (colsum) {
+        __syncthreads();                      // every K-slice sum has been read
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int o = tid + 256 * e; red[0][o >> 6][o & 63] = outv[e]; }
+        __syncthreads();
+        if (tid < 32 && n0 + tid < N) {
+            float sacc = 0.f;
+            for (int row = 0; row < 32; ++row) {                     // row = (r & 3) + 8 (r >> 2) + 4 h
+                const int hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+                sacc += red[0][r][tid + 32 * hh];                  // rows >= M hold 0
+            }
+            colsum[n0 + tid] = sacc;
+        }
+    }
+}
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(256) void gemm_direct(const float* __restrict__ A, int64_t lda,
+                                                   const float* __restrict__ B, int64_t ldb,
+                                                   float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                   Epilogue epi) {
+    __shared__ float red[4][16][64];
+    gemm_direct_tile<AK, BKM>(A, lda, B, ldb, C, ldc, M, N, K, epi, blockIdx.y * 32, blockIdx.x * 32, red, nullptr);
+}
+
+// Two independent small GEMMs in ONE launch (the head's backward through a hidden layer, head.hip):
+//   problem 1  dW[M1,N1] = dY^T A      (A element (m,k) at dY[k*lda + m], B element (k,n) at Aact[k*ldb + n])
+//   problem 2  dA[M2,N2] = (dY W) gated, M2 <= 32, + column sums of dA (the bias gradient of the layer below)
+// Blocks [0, nblk1) take tiles of problem 1 (column tiles fastest), the rest tiles of problem 2.
+struct DirectProblem {
+    const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int M, N, K; Epilogue epi; float* colsum;
+};
+__global__ __launch_bounds__(256) void gemm_direct_pair(DirectProblem p1, DirectProblem p2, int nblk1) {
+    __shared__ float red[4][16][64];
+    const int b = blockIdx.x;
+    if (b < nblk1) {
+        const int tn = (p1.N + 31) / 32;
+        gemm_direct_tile<false, false>(p1.A, p1.lda, p1.B, p1.ldb, p1.C, p1.ldc, p1.M, p1.N, p1.K, p1.epi, (b / tn) * 32, (b % tn) * 32,
+                                       red, nullptr);
+    } else {
+        const int t = b - nblk1, tn = (p2.N + 31) / 32;
+        gemm_direct_tile<true, false>(p2.A, p2.lda, p2.B, p2.ldb, p2.C, p2.ldc, p2.M, p2.N, p2.K, p2.epi, (t / tn) * 32, (t % tn) * 32,
+                                      red, p2.colsum);
     }
 }
 
@@ -727,6 +774,25 @@ int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const f
     e.mask = mask; e.mask_scale = mask_scale; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f;
     e.drop_p = mask ? 0.f : drop_p; e.drop_seed = drop_seed;
     return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream, Wp, N, Ap, M, Cp);
+}
+int head_backward_pair(const float* dY, int64_t ldy, const float* Aact, int64_t lda_act, const float* W, int64_t ldw, int B,
+                       int Hout, int Hin, float gate_scale, float* gW, float* dA, float* gb_in, hipStream_t stream) {
+    // problem 1: gW[Hout, Hin] = dY^T Aact (K = B);  problem 2: dA[B, Hin] = (dY W) gated by Aact != 0, K = Hout; gb_in = colsum(dA)
+    AC_REQUIRE(B >= 1 && B <= 32, AC_EUNSUPPORTED, "head_backward_pair: B=%d (<= 32)", B);
+    DirectProblem p1, p2;
+    Epilogue e;
+    e.bias = nullptr; e.residual = nullptr; e.ldr = 0; e.act = ACT_NONE; e.alpha = 1.f; e.beta = 0.f; e.mask = nullptr;
+    e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;
+    p1.A = dY; p1.lda = ldy; p1.B = Aact; p1.ldb = lda_act; p1.C = gW; p1.ldc = Hin; p1.M = Hout; p1.N = Hin; p1.K = B; p1.epi = e;
+    p1.colsum = nullptr;
+    Epilogue g = e;
+    g.gate = Aact; g.ldg = lda_act; g.gate_scale = gate_scale;
+    p2.A = dY; p2.lda = ldy; p2.B = W; p2.ldb = ldw; p2.C = dA; p2.ldc = Hin; p2.M = B; p2.N = Hin; p2.K = Hout; p2.epi = g;
+    p2.colsum = gb_in;
+    const int nblk1 = ((Hout + 31) / 32) * ((Hin + 31) / 32), nblk2 = (Hin + 31) / 32;
+    hipLaunchKernelGGL(gemm_direct_pair, dim3(nblk1 + nblk2), dim3(256), 0, stream, p1, p2, nblk1);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
 }
 int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
              const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* gate, int64_t ldg,

@@ -148,7 +148,11 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, const f
 constexpr int kTopMaxC = 16;
 constexpr int kTopMaxB = 256;
 
-__global__ __launch_bounds__(512) void head_top_kernel(const float* __restrict__ a2, int H2, const float* __restrict__ W3,
+// STAGE: a2 [B, H2] and W3 [C, H2] are first copied into LDS with coalesced 16-byte loads (the training batch: 32 x 384
+// + 4 x 384 floats = 54 KB); the dot products of steps 1 and 3 then read LDS instead of chasing L2 latencies.  Same
+// arithmetic, same order: bit-identical to the unstaged form.
+template <bool STAGE>
+__global__ __launch_bounds__(512) void head_top_kernel(const float* __restrict__ a2g, int H2, const float* __restrict__ W3g,
                                                        const float* __restrict__ b3, const int64_t* __restrict__ y,
                                                        const float* __restrict__ T, int64_t ldt, int B, int C, int kind,
                                                        float gate_scale, float* __restrict__ d2, float* __restrict__ gW3,
@@ -157,7 +161,19 @@ __global__ __launch_bounds__(512) void head_top_kernel(const float* __restrict__
     __shared__ float zs[kTopMaxB][kTopMaxC];
     __shared__ float dzs[kTopMaxB][kTopMaxC];
     __shared__ float rl[kTopMaxB];
+    extern __shared__ __attribute__((aligned(16))) float stage_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* a2 = a2g;
+    const float* W3 = W3g;
+    if (STAGE) {                                           // (H2 % 4 == 0 and 16-byte aligned sources: checked at launch)
+        float* sa = stage_lds;
+        float* sw = stage_lds + (size_t)B * H2;
+        const int na4 = B * H2 / 4, nw4 = C * H2 / 4;
+        for (int t = tid; t < na4; t += 512) reinterpret_cast<float4*>(sa)[t] = reinterpret_cast<const float4*>(a2g)[t];
+        for (int t = tid; t < nw4; t += 512) reinterpret_cast<float4*>(sw)[t] = reinterpret_cast<const float4*>(W3g)[t];
+        __syncthreads();
+        a2 = sa; W3 = sw;
+    }
     // 1. logits: four threads per (row, class) pair, each a strided quarter of the dot product, so the usual
     //    B * C = 128 pairs finish in one pass of the 512 threads with every load independent
     for (int p0 = 0; p0 < B * C; p0 += 128) {
@@ -460,8 +476,16 @@ int head_fwd_bwd(const ac_head_dims& d, const float* P, const float* X, int64_t 
     const bool top = d.C <= kTopMaxC && B <= kTopMaxB;
     if (top) {
         // logits + loss + dz + gW3 + gb3 + d2 + gb2 in one launch (see head_top_kernel)
-        hipLaunchKernelGGL(head_top_kernel, dim3(1), dim3(512), 0, stream, a2, d.H2, P + o.w3, P + o.b3, y, targets, ldt,
-                           B, d.C, loss_kind, s2, d2, G + o.w3, G + o.b3, G + o.b2, d_loss);
+        const size_t stage_bytes = ((size_t)B + d.C) * d.H2 * sizeof(float);
+        const bool stage = (d.H2 % 4) == 0 && stage_bytes <= 96 * 1024 && ((((uintptr_t)a2) | ((uintptr_t)(P + o.w3))) & 15) == 0;
+        if (stage) {
+            (void)hipFuncSetAttribute((const void*)head_top_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
+            hipLaunchKernelGGL(head_top_kernel<true>, dim3(1), dim3(512), stage_bytes, stream, a2, d.H2, P + o.w3, P + o.b3, y,
+                               targets, ldt, B, d.C, loss_kind, s2, d2, G + o.w3, G + o.b3, G + o.b2, d_loss);
+        } else {
+            hipLaunchKernelGGL(head_top_kernel<false>, dim3(1), dim3(512), 0, stream, a2, d.H2, P + o.w3, P + o.b3, y, targets,
+                               ldt, B, d.C, loss_kind, s2, d2, G + o.w3, G + o.b3, G + o.b2, d_loss);
+        }
         AC_LAUNCH_CHECK();
     } else {
         rc = ac::linear_f32(a2, d.H2, P + o.w3, d.H2, P + o.b3, nullptr, 0, z, d.C, B, d.C, d.H2, 0, nullptr, 1.f, stream);
@@ -475,6 +499,12 @@ int head_fwd_bwd(const ac_head_dims& d, const float* P, const float* X, int64_t 
         if (rc) return rc;
         rc = ac::gemm_f32(0, 0, B, d.H2, d.C, 1.f, dz, d.C, P + o.w3, d.H2, 0.f, d2, d.H2, a2, d.H2, s2, stream);
         if (rc) return rc;
+    }
+    if (top && B <= 32) {
+        // the training batch (32 rows): gW2, d1 (gated) and gb1 in ONE launch, then gW1 -- no bias-gradient launch
+        rc = ac::head_backward_pair(d2, d.H2, a1, d.H1, P + o.w2, d.H1, B, d.H2, d.H1, s1, G + o.w2, d1, G + o.b1, stream);
+        if (rc) return rc;
+        return ac::gemm_f32(1, 0, d.H1, d.D, B, 1.f, d1, d.H1, X, ldx, 0.f, G + o.w1, d.D, nullptr, 0, 1.f, stream);
     }
     rc = ac::gemm_f32(1, 0, d.H2, d.H1, B, 1.f, d2, d.H2, a1, d.H1, 0.f, G + o.w2, d.H1, nullptr, 0, 1.f, stream);
     if (rc) return rc;
@@ -667,12 +697,16 @@ extern "C" int ac_head_train_epoch(const ac_head_dims* dims, float* d_params, fl
                                    float lambda_B, float max_grad_norm, float lr, float beta1, float beta2, float eps,
                                    float weight_decay, int step0, float* d_out, float* d_loss_accum, void* d_ws,
                                    size_t ws_bytes, int* steps_done, ac_stream_t stream) {
-    AC_REQUIRE(d_order && n_total >= 0 && batch >= 1 && step0 >= 1, AC_EINVAL, "head_train_epoch: bad arguments");
+    AC_REQUIRE(n_total >= 0 && batch >= 1 && step0 >= 1, AC_EINVAL, "head_train_epoch: bad arguments");
     int n = 0;
     for (int64_t off = 0; off < n_total; off += batch, ++n) {
         const int nb = (int)((n_total - off) < batch ? (n_total - off) : batch);
-        const int rc = ac_head_train_step(dims, d_params, d_m, d_v, d_grads, d_X, ldx, d_y, d_targets, ldt, loss_kind,
-                                          d_order + off, nb, dropout_p, seed0 + (uint64_t)n, d_fisher, d_old,
+        // d_order == NULL: the caller already laid the rows out in epoch order -> batches are consecutive row slices
+        // (no per-step gather launch); identical arithmetic either way
+        const int rc = ac_head_train_step(dims, d_params, d_m, d_v, d_grads, d_order ? d_X : d_X + off * ldx, ldx,
+                                          (d_order || !d_y) ? d_y : d_y + off,
+                                          (d_order || !d_targets) ? d_targets : d_targets + off * ldt, ldt, loss_kind,
+                                          d_order ? d_order + off : nullptr, nb, dropout_p, seed0 + (uint64_t)n, d_fisher, d_old,
                                           d_fisher ? (float)((double)lambda_B / nb) : 0.f, max_grad_norm, lr, beta1, beta2, eps,
                                           weight_decay, step0 + n, d_out, d_loss_accum, d_ws, ws_bytes, stream);
         if (rc) return rc;

@@ -378,6 +378,12 @@ def bench_add_examples(dev, args):
     cls[n:] = C
     E = torch.nn.functional.normalize(cent[cls] + 0.5 * noise, dim=1).cpu()
     out = {}
+    # untimed warm-up (the contract's W): a 256-example loop on a throwaway classifier loads every kernel once
+    wclf = AdaptiveClassifier("precomputed", device=str(dev), encoder=_NoEncoder(), tokenizer=None)
+    for s in range(0, 256, 32):
+        wclf.add_embeddings([f"w{i}" for i in range(s, s + 32)], [E[i] for i in range(s, s + 32)], [f"c{i % C}" for i in range(s, s + 32)])
+    wclf.add_embeddings([f"wn{i}" for i in range(8)], [E[n + i] for i in range(8)], ["znew"] * 8)
+    del wclf
     for mode in ("as_wired", "intended"):
         clf = AdaptiveClassifier("precomputed", device=str(dev), config={"ewc_mode": mode}, encoder=_NoEncoder(), tokenizer=None)
         T = {"memory": 0.0, "train": 0.0, "rebuild": 0.0}

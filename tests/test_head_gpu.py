@@ -258,8 +258,12 @@ def test_fused_epoch_equals_the_step_loop(with_ewc, cuda_dev):
                             lambda_over_B=(5.0 / nb) if with_ewc else 0.0)
             off += nb
             i += 1
-        done = tr_b.fused_epoch(Xd, yd, order, B, 0.1, seed0, fisher=fisher, old_params=old,
-                                lambda_B=5.0 if with_ewc else 0.0)
+        if epoch == 0:
+            done = tr_b.fused_epoch(Xd, yd, order, B, 0.1, seed0, fisher=fisher, old_params=old,
+                                    lambda_B=5.0 if with_ewc else 0.0)
+        else:      # rows pre-arranged in epoch order, order=None (what the classifier's loop does): same bits
+            done = tr_b.fused_epoch(Xd.index_select(0, order), yd.index_select(0, order), None, B, 0.1, seed0,
+                                    fisher=fisher, old_params=old, lambda_B=5.0 if with_ewc else 0.0)
         assert done == i == 3 and tr_a.t == tr_b.t
         assert torch.equal(tr_a.flat, tr_b.flat) and torch.equal(tr_a.m, tr_b.m) and torch.equal(tr_a.v, tr_b.v)
         assert tr_a.loss_accum.item() == tr_b.loss_accum.item()
