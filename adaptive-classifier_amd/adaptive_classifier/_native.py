@@ -143,6 +143,10 @@ _SIGNATURES = {
     "ac_wordpiece_encode": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(ac_wordpiece_vocab), c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     "ac_bert_workspace": (c_int, [ctypes.POINTER(ac_bert_config), c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "ac_bert_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ac_bert_encode_cls_packed": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p, c_void_p,
+                                          c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
+                                          c_void_p]),
     "ac_bert_encode_cls": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
                                    c_void_p]),

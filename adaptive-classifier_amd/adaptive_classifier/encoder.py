@@ -31,8 +31,12 @@ class _Cfg:
 
 
 class HipBertEncoder:
-    def __init__(self, hf_bert, device=None):
+    def __init__(self, hf_bert, device=None, unpad=True):
+        """unpad: leave the padding tokens out of the forward (ac_bert_pack + ac_bert_encode_cls_packed) whenever the
+        attention mask is right-padded -- same CLS vectors from sum(len) token rows instead of b * S."""
         nv.require_gpu()
+        self.unpad = bool(unpad)
+        self.last_tokens = 0                  # token rows the last encode_cls call actually ran (roofline accounting)
         cfg = hf_bert.config
         mtype = getattr(cfg, "model_type", "bert")
         if mtype not in ("bert", "distilbert"):
@@ -148,23 +152,49 @@ class HipBertEncoder:
         need = self.workspace_bytes(min(b, cb), S)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.last_tokens = 0
         with torch.cuda.device(self.device):
             for r0 in range(0, b, cb):
                 r1 = min(b, r0 + cb)
+                nb = r1 - r0
+                if self.unpad and mk is not None and S > 1:
+                    # padding-free path: pack on the device, read back {rows, prefix flag, longest} (one 16-byte D2H)
+                    cu = torch.empty(nb + 1, dtype=torch.int32, device=self.device)
+                    src = torch.empty(nb * S, dtype=torch.int32, device=self.device)
+                    info = torch.empty(4, dtype=torch.int32, device=self.device)
+                    nv.check(nv.lib().ac_bert_pack(nv.ptr(mk[r0:r1]), nb, S, nv.ptr(cu), nv.ptr(src), nv.ptr(info),
+                                                   nv.stream_ptr(self.device)), "ac_bert_pack")
+                    total, not_prefix, longest, _ = info.tolist()
+                    if not not_prefix and total < nb * S:
+                        nv.check(nv.lib().ac_bert_encode_cls_packed(
+                            ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
+                            nv.ptr(None if tt is None else tt[r0:r1]), nb, S, nv.ptr(cu), nv.ptr(src), total, longest,
+                            nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(),
+                            nv.stream_ptr(self.device)), "ac_bert_encode_cls_packed")
+                        self.last_tokens += total
+                        continue
                 nv.check(nv.lib().ac_bert_encode_cls(
                     ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
-                    nv.ptr(None if tt is None else tt[r0:r1]), nv.ptr(None if mk is None else mk[r0:r1]), r1 - r0, S,
+                    nv.ptr(None if tt is None else tt[r0:r1]), nv.ptr(None if mk is None else mk[r0:r1]), nb, S,
                     nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
                     "ac_bert_encode_cls")
+                self.last_tokens += nb * S
         return out
 
-    def flops(self, b, S, executed=True):
+    def flops(self, b, S, executed=True, tokens=None, sum_len_sq=None):
         """FLOPs of one forward (dense projections + attention), for roofline reports.
         executed=True counts what the kernels run (the last layer's output projection / FFN and its
-        attention only touch the b CLS rows); executed=False is the full BertModel.forward count."""
+        attention only touch the b CLS rows); executed=False is the full BertModel.forward count.
+        tokens / sum_len_sq: the padding-free path's row count and sum of squared sequence lengths (attention)."""
         c = self.ccfg
         H, I, L = c.hidden, c.intermediate, c.layers
         T = b * S
+        if tokens is not None and executed:
+            per_tok = 2.0 * (4.0 * H * H + 2.0 * H * I)
+            ssq = float(sum_len_sq if sum_len_sq is not None else tokens * tokens / max(b, 1))
+            attn_layer = 4.0 * c.heads * ssq * (H // c.heads)
+            last = 2.0 * tokens * 3.0 * H * H + 2.0 * b * (H * H + 2.0 * H * I) + 4.0 * c.heads * tokens * (H // c.heads)
+            return per_tok * tokens * (L - 1) + attn_layer * (L - 1) + last
         per_tok = 2.0 * (4.0 * H * H + 2.0 * H * I)
         attn_layer = 4.0 * b * c.heads * S * S * (H // c.heads)
         if not executed:

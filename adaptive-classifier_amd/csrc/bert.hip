@@ -71,16 +71,19 @@ __device__ __forceinline__ void layernorm_store(f32x4 (&x)[kMaxVec], int H, int 
 }
 
 // word + position + token_type embeddings -> LayerNorm (modeling_bert.py:85-107)
+// tok_src (packed / padding-free mode): row t of the output is token tok_src[t] = seq * S + pos of the [b, S] inputs
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const int64_t* type_ids, int T, int S,
                                                        int H, const float* word, const float* pos,
                                                        const float* type, const float* g, const float* b,
-                                                       float eps, float* out, uint16_t* planes) {
+                                                       float eps, float* out, uint16_t* planes,
+                                                       const int32_t* __restrict__ tok_src = nullptr) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
-    const int64_t id = ids[t];
-    const int64_t tt = type_ids ? type_ids[t] : 0;
-    const int p = t % S;
+    const int src = tok_src ? tok_src[t] : t;
+    const int64_t id = ids[src];
+    const int64_t tt = type_ids ? type_ids[src] : 0;
+    const int p = src % S;
     const int nv = H >> 2;
     f32x4 x[kMaxVec];
 #pragma unroll
@@ -166,15 +169,21 @@ __device__ __forceinline__ void rope_rotate(f32x4 (&x)[8], const float* cs, cons
 //   [position][32] computed on the host exactly as transformers does).  Both halves of a pair sit in the same
 //   lane (fragment k-blocks kb and kb + 4), so the rotation is register-local.
 // window >= 0 (sliding-window layers, masking_utils.py:141-151): key k is visible to query q iff |q - k| <= window.
+// cu (packed / padding-free mode): sequence bi owns rows [cu[bi], cu[bi+1]) of qkv / ctx, all of them real tokens
+// (no mask); total_rows = cu[batch] is the row count of the planes output.  cu == nullptr: rows bi*S .. bi*S+S-1.
 template <bool ROPE>
-__global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, const int64_t* mask, int S, int H,
+__global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, const int64_t* mask, int S_, int H,
                                                             float scale, float* ctx, uint16_t* ctx_planes,
                                                             const float* rope_cos, const float* rope_sin,
-                                                            int window) {
+                                                            int window, const int32_t* __restrict__ cu = nullptr,
+                                                            int64_t total_rows = 0) {
     const int lane = threadIdx.x;
     const int qt = blockIdx.x, head = blockIdx.y, bi = blockIdx.z;
     const int64_t ld = 3 * (int64_t)H;
-    const float* base = qkv + (int64_t)bi * S * ld + head * DH;
+    const int64_t row0 = cu ? (int64_t)cu[bi] : (int64_t)bi * S_;
+    const int S = cu ? cu[bi + 1] - cu[bi] : S_;
+    if (qt * 32 >= S) return;                                        // (packed mode: short sequence)
+    const float* base = qkv + row0 * ld + head * DH;
     const int j = lane & 31, h = lane >> 5;
     const int qi = qt * 32 + j;
     const bool qvalid = qi < S;
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         // key validity as a 32-bit mask shared by the wave
         const int kj = k0 + j;
-        const bool kv = kj < S && (!mask || mask[(int64_t)bi * S + kj] != 0);
+        const bool kv = kj < S && (!mask || mask[(int64_t)bi * S_ + kj] != 0);
         const unsigned vmask = (unsigned)(__ballot(kv && h == 0) & 0xffffffffull);
         if (vmask == 0u) { load_k(k0 + 32); continue; }              // wave-uniform
         f32x16 st;
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
         if (ctx_planes) {
             // registers 4g .. 4g+3 are dims 8g + 4h .. +3: half of k-slot (head * 8 + 4t + g); the partner lane
             // (h ^ 1) writes the other half
-            const int64_t rows = (int64_t)gridDim.z * S, row = (int64_t)bi * S + qi, plane = rows * H;
+            const int64_t rows = cu ? total_rows : (int64_t)gridDim.z * S, row = row0 + qi, plane = rows * H;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
                     *reinterpret_cast<uint2*>(p + 2 * plane) = Ll;
                 }
         } else {
-            float* dst = ctx + ((int64_t)bi * S + qi) * H + head * DH;
+            float* dst = ctx + (row0 + qi) * H + head * DH;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 dst[crow32(r, h)] = o0[r] * inv;
@@ -297,9 +306,10 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
 // ROPE (ModernBERT): the CLS query is at position 0, whose rotation is the identity, so only the keys rotate;
 // window >= 0: only keys at positions <= window are visible to it.
 template <bool ROPE>
-__global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, const int64_t* mask, int S, int H,
+__global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, const int64_t* mask, int S_, int H,
                                                            float scale, float* ctx_cls, const float* rope_cos,
-                                                           const float* rope_sin, int window) {
+                                                           const float* rope_sin, int window,
+                                                           const int32_t* __restrict__ cu = nullptr) {
     __shared__ float Ks[KT][DH + 1];
     __shared__ __attribute__((aligned(16))) float Vs[KT][DH];
     __shared__ float qs[DH];
@@ -307,7 +317,9 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
     const int lane = threadIdx.x;
     const int head = blockIdx.x, bi = blockIdx.y;
     const int64_t ld = 3 * (int64_t)H;
-    const float* base = qkv + (int64_t)bi * S * ld + head * DH;
+    const int64_t row0 = cu ? (int64_t)cu[bi] : (int64_t)bi * S_;
+    const int S = cu ? cu[bi + 1] - cu[bi] : S_;
+    const float* base = qkv + row0 * ld + head * DH;
     qs[lane] = base[lane] * scale;              // CLS token = row 0 of the sequence
     float m = -INFINITY, l = 0.f, o = 0.f;      // o: output dim `lane`
     const int Svis = (window >= 0 && window + 1 < S) ? window + 1 : S;     // keys the CLS query can see
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
             *reinterpret_cast<f32x4*>(&Vs[r][c]) = vv;
         }
         __syncthreads();
-        const bool valid = lane < nk && (!mask || mask[(int64_t)bi * S + k0 + lane] != 0);
+        const bool valid = lane < nk && (!mask || mask[(int64_t)bi * S_ + k0 + lane] != 0);
         float sc = 0.f;
         if (ROPE) {
             const int pos = (k0 + lane < S) ? k0 + lane : S - 1;
@@ -397,6 +409,70 @@ __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ u,
     }
 }
 
+// ---- padding-free ("packed") mode ---------------------------------------------------------------------------
+// The reference pads every text to the longest of the batch and runs the encoder over the padding too
+// (classifier.py:1259-1271); padded positions never influence real ones (additive -inf mask, row-wise LayerNorm /
+// FFN) and only the CLS rows are consumed, so the padding rows can simply be left out: tokens are laid out
+// sequence after sequence, [sum(len), H], and attention works per sequence on its own rows.
+// pack_lens_kernel: len[s] = sum(mask[s, :]); flags a row whose ones are not a prefix (then the caller keeps the
+// padded path).  pack_scan_kernel: cu = exclusive scan of len (one workgroup), info = {total rows, not-prefix flag,
+// longest sequence}.  pack_fill_kernel: tok_src[cu[s] + p] = s * S + p.
+__global__ __launch_bounds__(256) void pack_lens_kernel(const int64_t* __restrict__ mask, int b, int S, int32_t* __restrict__ lens,
+                                                        int32_t* __restrict__ info) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= b) return;
+    int n = 0, bad = 0;
+    for (int p0 = 0; p0 < S; p0 += 64) {
+        const int p = p0 + lane;
+        const bool on = p < S && mask[(int64_t)s * S + p] != 0;
+        const uint64_t m = __ballot(on);
+        // a prefix inside this chunk: ones then zeros, and no ones after an earlier zero
+        const int ones = __popcll(m);
+        const uint64_t want = ones == 64 ? ~0ull : ((1ull << ones) - 1);
+        if (m != want || (ones > 0 && n != p0)) bad = 1;
+        n += ones;
+    }
+    if (lane == 0) { lens[s] = n; if (bad || n == 0) atomicOr(&info[1], 1); }
+}
+__global__ __launch_bounds__(1024) void pack_scan_kernel(const int32_t* __restrict__ lens, int b, int32_t* __restrict__ cu,
+                                                         int32_t* __restrict__ info) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (b + 1023) / 1024;
+    int sum = 0, mx = 0;
+    for (int i = tid * per; i < (tid + 1) * per && i < b; ++i) { sum += lens[i]; mx = lens[i] > mx ? lens[i] : mx; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                           // inclusive Hillis-Steele scan of the partial sums
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int i = tid * per; i < (tid + 1) * per && i < b; ++i) { cu[i] = run; run += lens[i]; }
+    if (tid == 1023) { cu[b] = part[1023]; info[0] = part[1023]; }
+    atomicMax(&info[2], mx);
+}
+__global__ __launch_bounds__(256) void pack_fill_kernel(const int32_t* __restrict__ cu, int b, int S, int32_t* __restrict__ tok_src) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= b) return;
+    const int r0 = cu[s], n = cu[s + 1] - r0;
+    for (int p = lane; p < n; p += 64) tok_src[r0 + p] = s * S + p;
+}
+// out[i, :] = in[rows[i], :]   (the CLS rows of the packed layout)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ rows, int n, int H,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(in + (int64_t)rows[i] * H);
+    f32x4* dst = reinterpret_cast<f32x4*>(out + (int64_t)i * H);
+    for (int c = lane; c < (H >> 2); c += 64) dst[c] = src[c];
+}
+
 struct BertWs {
     size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
 };
@@ -439,15 +515,14 @@ extern "C" int ac_bert_workspace(const ac_bert_config* cfg, int b, int S, size_t
     return AC_OK;
 }
 
-extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids,
-                                  const int64_t* d_type_ids, const int64_t* d_mask, int b, int S,
-                                  float* d_out, int64_t ldo, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
-    int rc = check_cfg(cfg);
-    if (rc) return rc;
-    hipStream_t stream = (hipStream_t)stream_;
-    if (b == 0) return AC_OK;
-    AC_REQUIRE(w && d_ids && d_out && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden, AC_EINVAL,
-               "bert_encode_cls: bad arguments (b=%d S=%d max_pos=%d)", b, S, cfg->max_pos);
+namespace {
+
+// shared body of ac_bert_encode_cls (cu == nullptr: the [b, S] rows incl. padding, T = b * S) and
+// ac_bert_encode_cls_packed (cu / tok_src from ac_bert_pack: T = cu[b] real-token rows, no mask)
+int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids, const int64_t* d_type_ids,
+                     const int64_t* d_mask, int b, int S, const int32_t* cu, const int32_t* tok_src, int T, int Smax,
+                     float* d_out, int64_t ldo, void* d_ws, size_t ws_bytes, hipStream_t stream) {
+    int rc;
     const ac_bert_config& c = *cfg;
     const BertWs ws = bert_ws(c, b, S);
     AC_REQUIRE(d_ws && ws_bytes >= ws.total, AC_EWORKSPACE, "bert_encode_cls: workspace %zu < %zu", ws_bytes, ws.total);
@@ -457,7 +532,7 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
     float* ctx = (float*)(base + ws.ctx);
     float* y = (float*)(base + ws.y);
     float* ffn = (float*)(base + ws.ffn);
-    const int T = b * S, H = c.hidden, I = c.intermediate;
+    const int H = c.hidden, I = c.intermediate;
     const int tok_blocks = (T + 3) / 4;
 
     uint16_t* xp = (uint16_t*)(base + ws.xp);
@@ -472,7 +547,7 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
 
     hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, T, S, H,
                        w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x,
-                       pl ? xp : nullptr);
+                       pl ? xp : nullptr, tok_src);
     AC_LAUNCH_CHECK();
     const float scale = 1.0f / sqrtf((float)DH);
     for (int l = 0; l < c.layers; ++l) {
@@ -489,13 +564,19 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
         const int Ml = last ? b : T;
         const bool lp = pl && !last;                   // this layer's post-attention GEMMs run on planes
         const float* resid = x;                        // residual = layer input
-        const int64_t ldres = last ? (int64_t)S * H : H;   // CLS rows of x are S*H apart
+        int64_t ldres = last ? (int64_t)S * H : H;     // CLS rows of x are S*H apart (padded layout)
         if (last) {
             hipLaunchKernelGGL(attention_cls_kernel<false>, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale,
-                               ctx, nullptr, nullptr, -1);
+                               ctx, nullptr, nullptr, -1, cu);
+            if (cu) {                                  // packed layout: the CLS rows sit at cu[s]; gather them
+                AC_LAUNCH_CHECK();
+                hipLaunchKernelGGL(gather_rows_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, cu, b, H, ffn);
+                resid = ffn;                           // compact CLS rows, staged in ffn (free until FFN1 writes it)
+                ldres = H;
+            }
         } else {
-            hipLaunchKernelGGL(attention_mfma_kernel<false>, dim3((S + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv,
-                               d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1);
+            hipLaunchKernelGGL(attention_mfma_kernel<false>, dim3((Smax + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv,
+                               d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1, cu, (int64_t)T);
         }
         AC_LAUNCH_CHECK();
         const int lblocks = (Ml + 3) / 4;
@@ -522,6 +603,49 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
     hipLaunchKernelGGL(cls_normalize_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, b, 1, H, d_out, ldo);
     AC_LAUNCH_CHECK();
     return AC_OK;
+}
+
+}  // namespace
+
+extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids,
+                                  const int64_t* d_type_ids, const int64_t* d_mask, int b, int S,
+                                  float* d_out, int64_t ldo, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (b == 0) return AC_OK;
+    AC_REQUIRE(w && d_ids && d_out && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden, AC_EINVAL,
+               "bert_encode_cls: bad arguments (b=%d S=%d max_pos=%d)", b, S, cfg->max_pos);
+    return bert_encode_impl(cfg, w, d_ids, d_type_ids, d_mask, b, S, nullptr, nullptr, b * S, S, d_out, ldo, d_ws, ws_bytes,
+                            (hipStream_t)stream_);
+}
+
+extern "C" int ac_bert_pack(const int64_t* d_mask, int b, int S, int32_t* d_cu, int32_t* d_tok_src, int32_t* d_info,
+                            ac_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_REQUIRE(d_mask && d_cu && d_tok_src && d_info && b >= 1 && S >= 1, AC_EINVAL, "bert_pack: bad arguments");
+    AC_HIP_CHECK(hipMemsetAsync(d_info, 0, 4 * sizeof(int32_t), stream));
+    int32_t* lens = d_tok_src;                         // scratch: the lengths live in tok_src until the fill pass
+    hipLaunchKernelGGL(pack_lens_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, d_mask, b, S, lens, d_info);
+    AC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, stream, lens, b, d_cu, d_info);
+    AC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pack_fill_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, d_cu, b, S, d_tok_src);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_bert_encode_cls_packed(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids,
+                                         const int64_t* d_type_ids, int b, int S, const int32_t* d_cu,
+                                         const int32_t* d_tok_src, int total_tokens, int longest, float* d_out, int64_t ldo,
+                                         void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (b == 0) return AC_OK;
+    AC_REQUIRE(w && d_ids && d_out && d_cu && d_tok_src && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden &&
+                   total_tokens >= b && total_tokens <= b * S && longest >= 1 && longest <= S,
+               AC_EINVAL, "bert_encode_cls_packed: bad arguments (b=%d S=%d tokens=%d longest=%d)", b, S, total_tokens, longest);
+    return bert_encode_impl(cfg, w, d_ids, d_type_ids, nullptr, b, S, d_cu, d_tok_src, total_tokens, longest, d_out, ldo, d_ws,
+                            ws_bytes, (hipStream_t)stream_);
 }
 
 // ------------------------------------------------------------------------------------------------

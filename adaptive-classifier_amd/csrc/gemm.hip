@@ -665,12 +665,15 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         // EXPERIMENT, opt-in (ac_gemm_set_variant(2)): the persistent stream-K ring kernel of gemm_ring.hip.  Measured and
         // rejected as default: +6 % at 8192^3 and +12 % on an isolated FFN1, but slower inside the encoder
         // pass (-3 % end to end) and on every shape whose tiles are cut between workgroups.
-        if (planes && Ap && ac::gemm_variant() == 2 && ac::ring_takes(M, N, K, cls, Cp != nullptr, true))
+        if (planes && Ap && ac::gemm_variant() >= 2 && ac::ring_takes(M, N, K, cls, Cp != nullptr, ac::gemm_variant() == 2))
             return ac::launch_gemm_ring(Ap, a_rows, Bp, b_rows, C, ldc, Cp, M, N, K, cls, epi, stream);
         // 8-wave 256 x 128 tile when both operands are pre-split and the grid has >= 1.5 rounds of such tiles
         const int64_t b256 = (int64_t)((M + 255) / 256) * ntn;
         static const int tile256_env = getenv("AC_GEMM_TILE256") ? atoi(getenv("AC_GEMM_TILE256")) : -1;
-        const bool big = planes && Ap && (tile256_env >= 0 ? tile256_env != 0 : b256 >= 3 * (int64_t)cus) &&
+        // ... or when the 256-row tiles make (almost) exactly ONE residency round (2 workgroups per CU) while the 128-row tiles
+        // would spill > 10 % into a second one (FFN1 at ~5000 packed token rows: 504 vs 984 tiles, 154 vs 173-196 us)
+        const bool one_round256 = b256 <= 2 * (int64_t)cus && 10 * b256 >= 17 * (int64_t)cus && 10 * b128 > 33 * (int64_t)cus;
+        const bool big = planes && Ap && (tile256_env >= 0 ? tile256_env != 0 : (b256 >= 3 * (int64_t)cus || one_round256)) &&
                          (cls == EPI_BIAS || cls == EPI_BIAS_GELU || cls == EPI_BIAS_RES || cls == EPI_GEGLU32) &&
                          !(cls == EPI_GEGLU32 && !Cp) && !(cls == EPI_BIAS_RES && Cp);
         if (big) {
@@ -832,7 +835,7 @@ extern "C" int ac_gemm_set_arith(int mode) {
 }
 extern "C" int ac_gemm_get_arith(void) { return ac::gemm_arith(); }
 extern "C" int ac_gemm_set_variant(int v) {
-    AC_REQUIRE(v == 0 || v == 2, AC_EINVAL, "gemm variant: unknown value %d", v);
+    AC_REQUIRE(v == 0 || v == 2 || v == 3, AC_EINVAL, "gemm variant: unknown value %d", v);
     ac::g_gemm_variant.store(v, std::memory_order_relaxed);
     return AC_OK;
 }

@@ -364,7 +364,8 @@ int launch_gemm_ring(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int
     p.partials = g_ring_ws.partials;
     p.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(g_ring_ws.partials) + (size_t)nblk * 2 * RBM * RBN * sizeof(float));
     p.epi = epi;
-    AC_HIP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)nblk * sizeof(int), stream));
+    if (p.tiles % nblk != 0)          // whole tiles per block: no partial hand-offs, the flags are never read
+        AC_HIP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)nblk * sizeof(int), stream));
     const dim3 grid(nblk), block(kRingThreads);
 #define AC_RING(E, RR, CP)                                                                                         \
     do {                                                                                                          \

@@ -530,7 +530,10 @@ def main():
         cfg2 = sharded_cfg2(dev, rank, world, args.sweep_rows)
     enc_peak = BF16_MFMA_PEAK_TF / 6.0 if arith == 1 else F32_MFMA_PEAK_TF
     if rank == 0:
-        enc_flops = clf.model.flops(BATCH, SEQ)
+        lens_h = mask.sum(1).double().cpu()
+        unpadded = getattr(clf.model, "last_tokens", BATCH * SEQ) < BATCH * SEQ
+        enc_flops = (clf.model.flops(BATCH, SEQ, tokens=float(lens_h.sum()), sum_len_sq=float((lens_h ** 2).sum()))
+                     if unpadded else clf.model.flops(BATCH, SEQ))
         rows_local = clf.memory.index.ntotal
         knn_flops = 2.0 * (BATCH * world) * rows_local * DIM
         line = {
@@ -555,8 +558,12 @@ def main():
                                  "flops_per_step": enc_flops,
                                  "peak_note": ("fp32-equivalent: bf16 MFMA dense peak 2500 / 6 products" if arith == 1
                                                else "fp32-input MFMA dense peak"),
-                                 "note": "executed FLOPs (last layer runs its post-attention part on the CLS rows only); "
-                                         "full BertModel.forward would be %.4g" % clf.model.flops(BATCH, SEQ, executed=False)},
+                                 "tokens_per_step": int(getattr(clf.model, "last_tokens", BATCH * SEQ)),
+                                 "tokens_per_step_padded": BATCH * SEQ,
+                                 "note": "executed FLOPs: the padding tokens of the ragged batch (lengths ~U[8,32], SURVEY 8d) are left "
+                                         "out of the forward (ac_bert_encode_cls_packed: identical CLS vectors), and the last layer runs "
+                                         "its post-attention part on the CLS rows only; the padded BertModel.forward the reference runs "
+                                         "would be %.4g" % clf.model.flops(BATCH, SEQ, executed=False)},
             "roofline_knn_batch": {"bound": "mfma", "achieved": knn_flops / stages["knn_ms"] / 1e9,
                                    "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                    "frac": knn_flops / stages["knn_ms"] / 1e9 / F32_MFMA_PEAK_TF,

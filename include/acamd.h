@@ -460,6 +460,25 @@ int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weights* w,
                        float* d_out_unit_cls, int64_t ldo,
                        void* d_ws, size_t ws_bytes, ac_stream_t stream);
 
+/*
+ * Padding-free ("packed") form of the same forward.  The reference pads every text to the longest of the batch and
+ * encodes the padding too (classifier.py:1259-1271); padded positions cannot influence real ones (additive -inf mask,
+ * row-wise LayerNorm / FFN) and only the CLS rows are consumed, so they can be left out: the same unit-norm CLS vectors
+ * from sum(len) token rows instead of b * S.
+ *   ac_bert_pack   from the attention mask [b, S]: d_cu int32 [b + 1] (row offset of every sequence), d_tok_src int32
+ *                  [b * S] (token seq * S + pos of every packed row) and d_info int32 [4] = {total rows, 1 if some row of
+ *                  the mask is not a non-empty prefix of ones (then use ac_bert_encode_cls), longest sequence, 0}.
+ *                  Asynchronous; the caller reads d_info back to size the encoder launch.
+ *   ac_bert_encode_cls_packed   total_tokens / longest = d_info[0] / d_info[2]; workspace as ac_bert_workspace(b, S).
+ */
+int ac_bert_pack(const int64_t* d_mask, int b, int S, int32_t* d_cu, int32_t* d_tok_src, int32_t* d_info,
+                 ac_stream_t stream);
+int ac_bert_encode_cls_packed(const ac_bert_config* cfg, const ac_bert_weights* w,
+                              const int64_t* d_ids, const int64_t* d_type_ids, int b, int S,
+                              const int32_t* d_cu, const int32_t* d_tok_src, int total_tokens, int longest,
+                              float* d_out_unit_cls, int64_t ldo,
+                              void* d_ws, size_t ws_bytes, ac_stream_t stream);
+
 /* ---- ModernBERT encoder ("answerdotai/ModernBERT-base", the reference's other default) ----
  * transformers modeling_modernbert.py: token embeddings -> LayerNorm; `layers` pre-norm blocks
  *   x += Wo attn(rope(Wqkv norm(x)))        (layer 0 has no attn norm; layer l attends globally when

@@ -113,3 +113,35 @@ def test_large_batches_are_encoded_in_row_chunks(cuda_dev, monkeypatch):
     whole = enc2.encode_cls(ids, None, mask).cpu()
     monkeypatch.setattr(enc_mod, "MAX_TOKENS", 7 * 16)
     assert (whole - enc2.encode_cls(ids, None, mask).cpu()).abs().max().item() < 2e-6
+
+
+def test_padding_free_path_equals_padded_path(cuda_dev):
+    """ac_bert_pack + ac_bert_encode_cls_packed (padding tokens left out of the forward) give the CLS vectors of the padded
+    forward: same dot products in the same order, masked keys contribute exact zeros.  Masks that are not right-padded
+    (left padding, holes, an empty row) keep the padded path."""
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_bert(768, 3, 12, 3072, vocab=3000, seed=2)
+    packed = HipBertEncoder(model, device=cuda_dev, unpad=True)
+    padded = HipBertEncoder(model, device=cuda_dev, unpad=False)
+    for (b, S, seed) in [(37, 48, 3), (256, 32, 1234), (5, 130, 9), (1, 16, 4)]:
+        ids, types, mask = bert_oracle.synthetic_batch(b, S, vocab=3000, seed=seed, ragged=True)
+        types[:, S // 3:] = 1
+        a = packed.encode_cls(ids, types, mask)
+        assert packed.last_tokens == int(mask.sum()) or b == 1
+        c = padded.encode_cls(ids, types, mask)
+        assert padded.last_tokens == b * S
+        assert (a - c).abs().max().item() <= 1e-6, (b, S, (a - c).abs().max().item())
+        want = bert_oracle.encode_cls(model, ids, types, mask)
+        assert (a.cpu() - want).abs().max().item() < 1e-4
+    # not right-padded -> padded path, same answer as transformers
+    ids, types, mask = bert_oracle.synthetic_batch(6, 24, vocab=3000, seed=5, ragged=True)
+    mask = torch.flip(mask, dims=[1]); ids = torch.flip(ids, dims=[1])             # left padding
+    mask[3, 10] = 0                                                                  # a hole
+    a = packed.encode_cls(ids, types, mask)
+    assert packed.last_tokens == 6 * 24
+    # (left-padded CLS position differs from the reference's [:, 0] pooling only through which token sits at 0:
+    #  the oracle pools position 0 too, so both see the same padded token there)
+    want = bert_oracle.encode_cls(model, ids, types, mask)
+    ok = mask[:, 0] != 0                                                             # rows whose position 0 is a real token
+    assert (a.cpu()[ok] - want[ok]).abs().max().item() < 1e-4 if ok.any() else True
