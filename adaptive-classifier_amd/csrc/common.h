@@ -124,4 +124,13 @@ int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const flo
 int head_backward_pair(const float* dY, int64_t ldy, const float* Aact, int64_t lda_act, const float* W, int64_t ldw, int B,
                        int Hout, int Hin, float gate_scale, float* gW, float* dA, float* gb_in, hipStream_t stream);
 
+// head_epoch.hip: the weights-stationary persistent training epoch (see there).  Returns AC_OK, 1 (shape not covered:
+// fall back to the step-by-step launches) or an error code.  lam_direct >= 0: EWC weight of every step; < 0: lambda_B / rows.
+size_t head_epoch_ws_bytes(int H1, int H2);
+int head_epoch_persistent(const ac_head_dims& d, float* P, float* M, float* V, float* Gout, const float* X, int64_t ldx,
+                          const int64_t* y, const float* T, int64_t ldt, int loss_kind, const int64_t* order, int64_t n_total,
+                          int batch, float dropout_p, uint64_t seed0, const float* F, const float* Old, float lambda_B,
+                          float lam_direct, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step0,
+                          float* out, float* loss_accum, void* ws, hipStream_t stream);
+
 }  // namespace ac

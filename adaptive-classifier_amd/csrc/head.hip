@@ -29,7 +29,7 @@ HeadOffsets head_offsets(const ac_head_dims& d) {
 }
 
 struct HeadWs {
-    size_t a1, a2, z, dz, d2, d1, rowloss, xg, yg, tg, scratch, total;
+    size_t a1, a2, z, dz, d2, d1, rowloss, xg, yg, tg, scratch, epoch, total;
 };
 
 HeadWs head_ws(const ac_head_dims& d, int B) {
@@ -47,6 +47,7 @@ HeadWs head_ws(const ac_head_dims& d, int B) {
     w.yg = take((size_t)B * 2);            // int64 labels
     w.tg = take((size_t)B * d.C);          // gathered multi-hot targets (BCE)
     w.scratch = take(AC_REDUCE_SCRATCH_BYTES / sizeof(float));
+    w.epoch = take(ac::head_epoch_ws_bytes(d.H1, d.H2) / sizeof(float));      // persistent epoch: a1 / a2 exchange, partials, barrier
     w.total = off;
     return w;
 }
@@ -606,6 +607,13 @@ extern "C" int ac_head_train_step(const ac_head_dims* dims, float* d_params, flo
     const HeadWs w = head_ws(d, B);
     AC_REQUIRE(d_ws && ws_bytes >= w.total, AC_EWORKSPACE, "head_train_step: workspace %zu < %zu", ws_bytes, w.total);
     char* ws = (char*)d_ws;
+    {   // one step of the persistent epoch kernel when the shape fits (the same code path as ac_head_train_epoch)
+        const int prc = ac::head_epoch_persistent(d, d_params, d_m, d_v, d_grads, d_X, ldx, d_y, d_targets, ldt, loss_kind, d_index, B, B,
+                                                  dropout_p, dropout_seed, d_fisher, d_old, 0.f, d_fisher ? lambda_over_B : 0.f,
+                                                  max_grad_norm, lr, beta1, beta2, eps, weight_decay, step, d_out, d_loss_accum,
+                                                  ws + w.epoch, stream);
+        if (prc != 1) return prc;
+    }
     const float* X = d_X;
     const int64_t* y = d_y;
     const float* T = d_targets;
@@ -699,6 +707,22 @@ extern "C" int ac_head_train_epoch(const ac_head_dims* dims, float* d_params, fl
                                    size_t ws_bytes, int* steps_done, ac_stream_t stream) {
     AC_REQUIRE(n_total >= 0 && batch >= 1 && step0 >= 1, AC_EINVAL, "head_train_epoch: bad arguments");
     int n = 0;
+    if (n_total > 0 && dims && d_params && d_m && d_v && d_grads && d_X && d_out && d_ws) {
+        int rc = check_dims(dims);
+        if (rc) return rc;
+        AC_REQUIRE(loss_kind >= AC_LOSS_CE && loss_kind <= AC_LOSS_CE_SIGMOID, AC_EINVAL, "head_train_epoch: loss_kind=%d", loss_kind);
+        AC_REQUIRE(loss_kind == AC_LOSS_BCE_SIGMOID ? (d_targets && ldt >= dims->C) : (d_y != nullptr), AC_EINVAL,
+                   "head_train_epoch: BCE needs float targets [rows, C]; CE needs int64 labels");
+        AC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f && ldx >= dims->D, AC_EINVAL, "head_train_epoch: bad dropout_p / ldx");
+        AC_REQUIRE((d_fisher == nullptr) == (d_old == nullptr), AC_EINVAL, "head_train_epoch: fisher and old params must be given together");
+        const HeadWs w = head_ws(*dims, (int)(n_total < batch ? n_total : batch));
+        AC_REQUIRE(ws_bytes >= w.total, AC_EWORKSPACE, "head_train_epoch: workspace %zu < %zu", ws_bytes, w.total);
+        rc = ac::head_epoch_persistent(*dims, d_params, d_m, d_v, d_grads, d_X, ldx, d_y, d_targets, ldt, loss_kind, d_order, n_total,
+                                       batch, dropout_p, seed0, d_fisher, d_old, lambda_B, -1.f, max_grad_norm, lr, beta1, beta2, eps,
+                                       weight_decay, step0, d_out, d_loss_accum, (char*)d_ws + w.epoch, (hipStream_t)stream);
+        if (rc == AC_OK) { if (steps_done) *steps_done = (int)((n_total + batch - 1) / batch); return AC_OK; }
+        if (rc != 1) return rc;
+    }
     for (int64_t off = 0; off < n_total; off += batch, ++n) {
         const int nb = (int)((n_total - off) < batch ? (n_total - off) : batch);
         // d_order == NULL: the caller already laid the rows out in epoch order -> batches are consecutive row slices
