@@ -30,6 +30,9 @@ class _Cfg:
         self._name_or_path = name_or_path
 
 
+SMALL_TOKENS = 32     # up to here ac_bert_encode_cls runs the whole forward as one persistent launch (bert_small.hip): no packing
+
+
 class HipBertEncoder:
     def __init__(self, hf_bert, device=None, unpad=True):
         """unpad: leave the padding tokens out of the forward (ac_bert_pack + ac_bert_encode_cls_packed) whenever the
@@ -157,7 +160,7 @@ class HipBertEncoder:
             for r0 in range(0, b, cb):
                 r1 = min(b, r0 + cb)
                 nb = r1 - r0
-                if self.unpad and mk is not None and S > 1:
+                if self.unpad and mk is not None and S > 1 and nb * S > SMALL_TOKENS:
                     # padding-free path: pack on the device, read back {rows, prefix flag, longest} (one 16-byte D2H)
                     cu = torch.empty(nb + 1, dtype=torch.int32, device=self.device)
                     src = torch.empty(nb * S, dtype=torch.int32, device=self.device)

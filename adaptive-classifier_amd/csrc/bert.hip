@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 struct BertWs {
-    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
+    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
 };
 BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     BertWs w;
@@ -490,6 +490,9 @@ BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     w.xp = take16(3 * T * c.hidden);
     w.ctxp = take16(3 * T * c.hidden);
     w.ffnp = take16(3 * T * c.intermediate);
+    // the one-launch small-batch path (bert_small.hip) works on 32 padded rows of its own
+    w.small = off;
+    if (T <= 32) off += ac::bert_small_ws_bytes(c.hidden, c.intermediate);
     w.total = off;
     return w;
 }
@@ -615,6 +618,12 @@ extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weigh
     if (b == 0) return AC_OK;
     AC_REQUIRE(w && d_ids && d_out && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden, AC_EINVAL,
                "bert_encode_cls: bad arguments (b=%d S=%d max_pos=%d)", b, S, cfg->max_pos);
+    if (b * S <= 32) {          // a handful of token rows (single-query predict): every layer in ONE persistent launch
+        const BertWs ws = bert_ws(*cfg, b, S);
+        AC_REQUIRE(d_ws && ws_bytes >= ws.total, AC_EWORKSPACE, "bert_encode_cls: workspace %zu < %zu", ws_bytes, ws.total);
+        rc = ac::bert_small_encode(*cfg, *w, d_ids, d_type_ids, d_mask, b, S, d_out, ldo, (char*)d_ws + ws.small, (hipStream_t)stream_);
+        if (rc != 1) return rc;
+    }
     return bert_encode_impl(cfg, w, d_ids, d_type_ids, d_mask, b, S, nullptr, nullptr, b * S, S, d_out, ldo, d_ws, ws_bytes,
                             (hipStream_t)stream_);
 }

@@ -133,4 +133,9 @@ int head_epoch_persistent(const ac_head_dims& d, float* P, float* M, float* V, f
                           float lam_direct, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step0,
                           float* out, float* loss_accum, void* ws, hipStream_t stream);
 
+// bert_small.hip: BERT forward of <= 32 token rows in one persistent launch.  AC_OK, 1 (shape not covered) or an error.
+size_t bert_small_ws_bytes(int H, int I);
+int bert_small_encode(const ac_bert_config& c, const ac_bert_weights& w, const int64_t* ids, const int64_t* type_ids,
+                      const int64_t* mask, int b, int S, float* out, int64_t ldo, void* ws, hipStream_t stream);
+
 }  // namespace ac

@@ -24,6 +24,7 @@
 // tiles), which is inside the tolerance the head tests hold against torch.  ac_head_train_step and
 // ac_head_train_epoch both route here when the shape fits, so "epoch == step loop" stays bit-identical.
 #include "common.h"
+#include "grid_sync.h"
 
 #include <math.h>
 
@@ -33,18 +34,13 @@
 
 namespace {
 
+using namespace acp;
+
 constexpr int kT = 512;               // threads per workgroup
 constexpr int kR1 = 4, kR2 = 2;       // most rows of layer 1 / layer 2 one workgroup owns
 constexpr int kKU = 2;                // D, H1 <= kT * kKU (four columns per thread of a four-wave team)
 constexpr int kMaxC = 16, kMaxB = 32;
 constexpr int kMaxG = 512;
-
-struct EpochCtl {
-    unsigned xcd[8][32];              // arrivals per XCD group (one 128-byte line each)
-    unsigned top;                     // completed groups
-    unsigned abort_;
-    unsigned pad[30];
-};
 
 struct EpochParams {
     int D, H1, H2, C, G, r1, r2;
@@ -56,39 +52,10 @@ struct EpochParams {
     float lambda_B, lam_direct, max_norm, lr, beta1, beta2, eps, wd; int step0;     // lam_direct >= 0: EWC weight given per step
 
     float* out; float* loss_accum;
-    float* a1g; float* a2g; float* partials; EpochCtl* ctl;
+    float* a1g; float* a2g; float* partials; acp::GridCtl* ctl;
     unsigned long long* dbg;          // AC_HEAD_EPOCH_DEBUG: s_memtime stamps of workgroup 0, [step < 16][16]
     int64_t o_w1, o_b1, o_w2, o_b2, o_w3, o_b3;
 };
-
-__device__ __forceinline__ void st_sc1(float* p, float v) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_sc1(const float* p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ float2 ld2_sc1(const float* p) {          // p 8-byte aligned
-    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
-}
-
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-// sc1 (agent-coherent, write-through / L2-bypassing) accesses through a buffer descriptor: ordinary loads to the
-// compiler, so a batch of them is issued back to back and waited for once (relaxed atomics are kept in program order
-// with a wait after each group).  Offsets beyond `bytes` read as zero.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
-__device__ __forceinline__ float4 ld4_buf(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {      // plain (L2-cached) 16-byte load
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
 
 // kAcquireB1: barrier B1 ends with an acquire and a1 / W3 are read with plain (L2-cached) loads; otherwise every exchanged
 // word is read with sc1 loads and no barrier fences (A/B on MI355X: see DESIGN)
@@ -96,59 +63,6 @@ constexpr bool kAcquireB1 = AC_EPOCH_ACQUIRE_B1;
 template <bool PLAIN>
 __device__ __forceinline__ float4 ld4_x(__amdgpu_buffer_rsrc_t r, unsigned byte_off) { return PLAIN ? ld4_buf(r, byte_off) : ld4_sc1(r, byte_off); }
 
-// Fence-free grid barrier: every wave drains its stores; thread 0 counts its workgroup into one of eight counters
-// (128-byte lines apart) with a relaxed agent-scope atomic; lanes 0-7 of wave 0 then poll the eight counters until each
-// has seen all of its workgroups.  One atomic + one poll round trip: 1.8 us for 256 workgroups, against 2.4 us for a
-// two-level counter and 4.1 us for a single one (tools/gridbar_probe.hip).  `n` = 1, 2, 3 ... over the launch.
-// false = gave up (a workgroup never arrived: cannot happen with a cooperative launch; bounded so a bug cannot hang
-// the GPU).  The exchanged data itself is written with sc1 stores and read with sc1 loads: no cache maintenance here.
-template <bool ACQUIRE>
-__device__ __forceinline__ bool grid_barrier(EpochCtl* c, unsigned n, unsigned G, unsigned* lds_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const unsigned lane = threadIdx.x;
-        if (lane == 0) __hip_atomic_fetch_add(&c->xcd[blockIdx.x & 7][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned grp = lane & 7, target = n * ((G + 7 - grp) / 8);
-        unsigned ok = 1;
-        for (long spins = 0;; ++spins) {
-            const unsigned v = __hip_atomic_load(&c->xcd[grp][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(v >= target)) break;
-            __builtin_amdgcn_s_sleep(2);                 // (polling flat out slows the stragglers' own memory traffic)
-            if ((spins & 1023) == 1023) {
-                if (__hip_atomic_load(&c->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins > (1l << 24)) {
-                    if (lane == 0) __hip_atomic_store(&c->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-            }
-        }
-        if (ACQUIRE && lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (lane == 0) *lds_flag = ok;
-    }
-    __syncthreads();
-    return *lds_flag != 0;
-}
-
-// Sums over the wave without LDS traffic: four DPP butterflies inside each row of 16 lanes (every lane of a row then
-// holds the row sum), the four row sums combined in a fixed order.  ~60 cycles against ~600 for six ds_bpermute steps.
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);      // row_half_mirror
-    v = dpp_add<0x140>(v);      // row_mirror
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v = row16_sum(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (r0 + r1) + (r2 + r3);
-}
 // Sums of N <= 8 per-lane values over the wave through a wave-private LDS tile [64][9]: lane writes its N partials, lane
 // (v, q) = (lane >> 3, lane & 7) adds the partials of value v from lanes 8q .. 8q+7 in order, three DPP butterflies finish.
 // Lanes 8v .. 8v+7 return the sum of value v.  ~30 instructions per call instead of ~60 per VALUE with wave_sum(); both
@@ -805,7 +719,7 @@ namespace ac {
 
 size_t head_epoch_ws_bytes(int H1, int H2) {
     return align_up((size_t)kMaxB * H1 * sizeof(float), 256) + align_up((size_t)kMaxB * H2 * sizeof(float), 256) +
-           align_up(2 * kMaxG * sizeof(float), 256) + align_up(sizeof(EpochCtl), 256) + 16 * 16 * sizeof(unsigned long long);
+           align_up(2 * kMaxG * sizeof(float), 256) + align_up(sizeof(acp::GridCtl), 256) + 16 * 16 * sizeof(unsigned long long);
 }
 
 // AC_OK: the epoch ran.  1: shape / alignment outside what the persistent kernel covers (caller falls back to the
@@ -838,12 +752,12 @@ int head_epoch_persistent(const ac_head_dims& d, float* P, float* M, float* V, f
     p.a1g = (float*)w; w += align_up((size_t)kMaxB * d.H1 * sizeof(float), 256);
     p.a2g = (float*)w; w += align_up((size_t)kMaxB * d.H2 * sizeof(float), 256);
     p.partials = (float*)w; w += align_up(2 * kMaxG * sizeof(float), 256);
-    p.ctl = (EpochCtl*)w; w += align_up(sizeof(EpochCtl), 256);
+    p.ctl = (acp::GridCtl*)w; w += align_up(sizeof(acp::GridCtl), 256);
     static const int debug = [] { const char* e = getenv("AC_HEAD_EPOCH_DEBUG"); return e ? atoi(e) : 0; }();
     p.dbg = debug ? (unsigned long long*)w : nullptr;
     if (debug) AC_HIP_CHECK(hipMemsetAsync(p.dbg, 0, 16 * 16 * sizeof(unsigned long long), stream));
     p.o_w1 = o_w1; p.o_b1 = o_b1; p.o_w2 = o_w2; p.o_b2 = o_b2; p.o_w3 = o_w3; p.o_b3 = o_b3;
-    AC_HIP_CHECK(hipMemsetAsync(p.ctl, 0, sizeof(EpochCtl), stream));
+    AC_HIP_CHECK(hipMemsetAsync(p.ctl, 0, sizeof(acp::GridCtl), stream));
     const int variant = (d.C <= 4 ? 0 : 1) + (r32 ? 0 : 2);
     const void* fns[4] = {(const void*)head_epoch_kernel<4, 3, 2>, (const void*)head_epoch_kernel<kMaxC, 3, 2>,
                           (const void*)head_epoch_kernel<4, 4, 2>, (const void*)head_epoch_kernel<kMaxC, 4, 2>};

@@ -32,6 +32,34 @@ def test_encoder_cls_matches_transformers(hidden, layers, heads, inter, b, S, ra
     assert abs(got.norm(dim=1) - 1).max().item() < 1e-5
 
 
+@pytest.mark.parametrize("hidden,layers,heads,inter,b,S,ragged", [
+    (768, 12, 12, 3072, 1, 11, False),    # a single short query: the predict(text) case, bert-base
+    (768, 12, 12, 3072, 1, 32, False),    # 32 token rows = both MFMA row tiles
+    (768, 3, 12, 3072, 2, 16, True),      # two sequences in one launch: attention stays inside each, ragged key masks
+    (768, 2, 12, 3072, 3, 9, True),       # 27 rows, odd sizes
+    (384, 6, 6, 1536, 1, 20, False),      # MiniLM-L6 width (H = 384: three k-blocks per wave)
+    (128, 2, 2, 512, 4, 8, True),         # bert-tiny
+])
+def test_small_batch_one_launch_path_matches_transformers(hidden, layers, heads, inter, b, S, ragged, cuda_dev):
+    """b * S <= 32 token rows: ac_bert_encode_cls runs every layer inside ONE persistent launch (bert_small.hip, strict
+    fp32 MFMA).  Same 1e-4 bar against transformers fp32, and against the layer-by-layer kernels on the same texts
+    (the batch replicated until it exceeds 32 rows takes that path)."""
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    vocab = 2000
+    model = bert_oracle.make_bert(hidden, layers, heads, inter, vocab=vocab, seed=0)
+    ids, types, mask = bert_oracle.synthetic_batch(b, S, vocab=vocab, seed=4321, ragged=ragged)
+    types[:, S // 2:] = 1
+    want = bert_oracle.encode_cls(model, ids, types, mask)
+    enc = HipBertEncoder(model, device=cuda_dev)
+    got = enc.encode_cls(ids, types, mask).cpu()
+    assert (got - want).abs().max().item() < 1e-4
+    assert abs(got.norm(dim=1) - 1).max().item() < 1e-5
+    rep = 32 // (b * S) + 1
+    big = enc.encode_cls(ids.repeat(rep, 1), types.repeat(rep, 1), mask.repeat(rep, 1)).cpu()[:b]
+    assert (got - big).abs().max().item() < 2e-5
+
+
 def test_encoder_no_mask_and_large_batch(cuda_dev):
     from adaptive_classifier.encoder import HipBertEncoder
     from oracle import bert_oracle

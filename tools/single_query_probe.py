@@ -15,3 +15,10 @@ e0.record()
 for _ in range(50): enc.encode_cls(ids)
 e1.record(); torch.cuda.synchronize()
 print(f"b=1 S=16: {e0.elapsed_time(e1)/50*1e3:.0f} us per encode")
+for S in (8, 32):
+    ids = torch.randint(1000, 30000, (1, S)).to(dev)
+    for _ in range(5): enc.encode_cls(ids)
+    e0.record()
+    for _ in range(50): enc.encode_cls(ids)
+    e1.record(); torch.cuda.synchronize()
+    print(f"b=1 S={S}: {e0.elapsed_time(e1)/50*1e3:.0f} us per encode")
