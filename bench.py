@@ -422,7 +422,10 @@ def bench_add_examples(dev, args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: add_examples() loop, %d pre-computed 768-d examples in chunks of 32, 4 classes, "
                                "cap 1000/class, head retrained per call (<= 10 epochs), then a 5th class (EWC path)" % n,
-                   "dim": DIM, "chunk": 32, "max_examples_per_class": 1000},
+                   "dim": DIM, "chunk": 32, "max_examples_per_class": 1000,
+                   "training": "ac_head_train_epoch: ONE persistent launch per epoch (head_epoch.hip: weights + AdamW moments "
+                               "stationary in LDS, 3 grid barriers per step) + 1 memset; one host sync per epoch (early stopping)",
+                   "launches_per_epoch": 2},
         "modes": out}), flush=True)
 
 
