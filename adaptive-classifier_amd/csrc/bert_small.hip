@@ -92,19 +92,24 @@ __device__ __forceinline__ void row_totals(float& s0, float& s1, const Lds& L, i
 struct WPre { float4 w[kKBmax]; };
 
 struct GemmGeom {
-    int ngroups, g_lo, g_hi, nkb, kw, nchunks, nactive, rot;
+    int ngroups, g_lo, g_hi, nkb, kw, nchunks, nactive, rot, ks;
 };
 template <int KB>
-__device__ __forceinline__ GemmGeom gemm_geom(int N, int K, int groups_per_block, int blk, int tid) {
+__device__ __forceinline__ GemmGeom gemm_geom(int N, int K, int groups_per_block, int blk, int tid, int ksplit = 1) {
     GemmGeom g;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     g.ngroups = N / 16;
-    g.g_lo = blk * groups_per_block;
+    // ksplit > 1 (one group per workgroup): workgroup blk takes column group blk % ngroups and the ks-th part of K; the
+    // parts' partial results go to separate buffers that the CONSUMER adds up while it loads them
+    g.ks = ksplit > 1 ? blk / g.ngroups : 0;
+    const int bg = ksplit > 1 ? blk - g.ks * g.ngroups : blk;
+    g.g_lo = (ksplit > 1 && g.ks >= ksplit) ? g.ngroups : bg * groups_per_block;
     g.g_hi = min(g.ngroups, g.g_lo + groups_per_block);
-    g.nkb = K / 128;                                   // k-blocks of 16 per wave
+    const int Kb = K / ksplit;
+    g.nkb = Kb / 128;                                  // k-blocks of 16 per wave
     // which eighth of K a wave takes, and (below) the order of its chunks, rotate with the workgroup: dozens of workgroups
     // read the SAME activation rows at the same moment, and in lock step they would queue on the same memory channels
-    g.kw = ((wave + blk) & 7) * (K / 8) + 4 * (lane >> 4);           // + 16 * kb
+    g.kw = g.ks * Kb + ((wave + blk) & 7) * (Kb / 8) + 4 * (lane >> 4);           // + 16 * kb
     g.rot = blk;
     g.nchunks = (g.nkb + KB - 1) / KB;
     g.nactive = (g.ngroups + groups_per_block - 1) / groups_per_block;
@@ -119,26 +124,28 @@ __device__ __forceinline__ void load_w(float4 (&w)[NW], __amdgpu_buffer_rsrc_t r
         w[kb] = ld4_buf(rW, (live && kb0 + kb < g.nkb) ? (unsigned)(((size_t)(gi * 16 + m) * K + g.kw + 16 * (kb0 + kb)) * 4) : 0xffffff00u);
 }
 template <int KB>
-__device__ __forceinline__ WPre prefetch_w(const float* W, int N, int K, int groups_per_block, int blk, int tid) {
+__device__ __forceinline__ WPre prefetch_w(const float* W, int N, int K, int groups_per_block, int blk, int tid, int ksplit = 1) {
     WPre p;
-    const GemmGeom g = gemm_geom<KB>(N, K, groups_per_block, blk, tid);
+    const GemmGeom g = gemm_geom<KB>(N, K, groups_per_block, blk, tid, ksplit);
     load_w<KB>(p.w, make_rsrc(W, (unsigned)((size_t)N * K * sizeof(float))), g, K, 0, tid & 15);
     return p;
 }
 
-template <bool LN, int ACT, bool RES, int KB, bool TWO>
+template <bool LN, int ACT, bool RES, int KB, bool TWO, int NSUM = 1>
 __device__ __forceinline__ void gemm_phase(const float* A, int K, const float* g_ln, const float* b_ln, float eps, float* xn_out,
                                            const float* W, const float* bias, const float* R, float* out, int N, int T,
-                                           int groups_per_block, const Lds& L, int tid, int blk, const WPre& pre, unsigned long long* dbgp = nullptr, int mode = 0) {
+                                           int groups_per_block, const Lds& L, int tid, int blk, const WPre& pre, unsigned long long* dbgp = nullptr, int mode = 0,
+                                           int ksplit = 1) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15;
     auto st = [&](int q) { if (dbgp && tid == 0) dbgp[q] = __builtin_readcyclecounter(); };
     st(0);
-    const GemmGeom g = gemm_geom<KB>(N, K, groups_per_block, blk, tid);
+    const GemmGeom g = gemm_geom<KB>(N, K, groups_per_block, blk, tid, ksplit);
     if (g.g_lo >= g.ngroups) return;
+    out += (size_t)g.ks * kTok * N;                 // (K split: this part's partial-result buffer)
     constexpr bool two = TWO;
     constexpr int KB1 = TWO ? KB : 1;       // (the second row tile's fragments exist only when it does)
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (mode & 1) ? 0u : (unsigned)((two ? kTok : 16) * K * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (mode & 1) ? 0u : (unsigned)((NSUM > 1 ? NSUM * kTok : two ? kTok : 16) * K * sizeof(float)));
     const __amdgpu_buffer_rsrc_t rW = make_rsrc(W, (mode & 2) ? 0u : (unsigned)((size_t)N * K * sizeof(float)));
     auto load_a = [&](float4 (&a0)[KB], float4 (&a1)[KB1], int unit) {
         const int kb0 = ((unit % g.nchunks + g.rot) % g.nchunks) * KB;
@@ -146,8 +153,19 @@ __device__ __forceinline__ void gemm_phase(const float* A, int K, const float* g
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const bool in = live && kb0 + kb < g.nkb;
-            a0[kb] = ld4_sc1(rA, in ? (unsigned)((m * K + g.kw + 16 * (kb0 + kb)) * 4) : 0xffffff00u);
-            if (TWO) a1[kb < KB1 ? kb : 0] = ld4_sc1(rA, in ? (unsigned)(((16 + m) * K + g.kw + 16 * (kb0 + kb)) * 4) : 0xffffff00u);
+            float4 p0[NSUM], p1[NSUM];
+#pragma unroll
+            for (int sp = 0; sp < NSUM; ++sp) {            // (NSUM > 1: the producer split K; its partial buffers are added here, in order)
+                p0[sp] = ld4_sc1(rA, in ? (unsigned)(((sp * kTok + m) * K + g.kw + 16 * (kb0 + kb)) * 4) : 0xffffff00u);
+                if (TWO) p1[sp] = ld4_sc1(rA, in ? (unsigned)(((sp * kTok + 16 + m) * K + g.kw + 16 * (kb0 + kb)) * 4) : 0xffffff00u);
+            }
+#pragma unroll
+            for (int sp = 1; sp < NSUM; ++sp) {
+                p0[0].x += p0[sp].x; p0[0].y += p0[sp].y; p0[0].z += p0[sp].z; p0[0].w += p0[sp].w;
+                if (TWO) { p1[0].x += p1[sp].x; p1[0].y += p1[sp].y; p1[0].z += p1[sp].z; p1[0].w += p1[sp].w; }
+            }
+            a0[kb] = p0[0];
+            if (TWO) a1[kb < KB1 ? kb : 0] = p1[0];
         }
     };
     // epilogue operands of the first group, requested now: thread (tt, l, i) owns token 16 tt + 4 (l >> 4) + i, column l & 15
@@ -156,7 +174,7 @@ __device__ __forceinline__ void gemm_phase(const float* A, int K, const float* g
     float rv = 0.f, bv = 0.f;
     auto load_epi = [&](int gi) {
         const int n = gi * 16 + ecol;
-        if (token < T && gi < g.g_hi) { bv = bias[n]; if (RES) rv = ld_sc1(R + (size_t)token * N + n); }
+        if (token < T && gi < g.g_hi && g.ks == 0) { bv = bias[n]; if (RES) rv = ld_sc1(R + (size_t)token * N + n); }
     };
     load_epi(g.g_lo);
     float4 a0A[KB], a1A[KB1], a0B[KB], a1B[KB1], wA[KB], wB[KB];
@@ -265,7 +283,8 @@ __device__ __forceinline__ void gemm_phase(const float* A, int K, const float* g
 
 template <bool TWO>       // TWO: 17 .. 32 token rows (two MFMA row tiles); otherwise one
 __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) {
-    constexpr int kKBE = TWO ? kKB : kKBmax;        // operand chunk of the K = I phase
+    constexpr int kSplitE = TWO ? 2 : 4;            // FFN2 (K = I): K split over 2 / 4 workgroups per column group; its consumers add the parts
+    constexpr int kKBE = kKB;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const int tid0 = threadIdx.x, blk = blockIdx.x;
@@ -281,12 +300,13 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
         const int64_t id = ka->ids[blk];
         const int64_t tt = ka->type_ids ? ka->type_ids[blk] : 0;
         const int p = blk % S;
-        const __amdgpu_buffer_rsrc_t rY = make_rsrc(ka->y0, (unsigned)(kTok * H * sizeof(float)));
+        const __amdgpu_buffer_rsrc_t rY = make_rsrc(ka->y0, (unsigned)(4 * kTok * H * sizeof(float)));
         for (int c4 = tid0; c4 < H / 4; c4 += kT) {
             const float4 w = *reinterpret_cast<const float4*>(ka->word + id * H + 4 * c4);
             const float4 ty = *reinterpret_cast<const float4*>(ka->type + tt * H + 4 * c4);
             const float4 po = *reinterpret_cast<const float4*>(ka->pos + (int64_t)p * H + 4 * c4);
             st4_sc1(rY, (unsigned)((blk * H + 4 * c4) * 4), make_float4((w.x + ty.x) + po.x, (w.y + ty.y) + po.y, (w.z + ty.z) + po.z, (w.w + ty.w) + po.w));
+            for (int sp = 1; sp < kSplitE; ++sp) st4_sc1(rY, (unsigned)(((sp * kTok + blk) * H + 4 * c4) * 4), make_float4(0.f, 0.f, 0.f, 0.f));
         }
     }
     grid_arrive(ka->ctl);
@@ -304,7 +324,7 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
         const float* g_in = l == 0 ? prm->emb_g : prm->layer[l - 1].ln2_g;
         const float* b_in = l == 0 ? prm->emb_b : prm->layer[l - 1].ln2_b;
         // ---- PA: x = LN(y0); qkv = x Wqkv^T + b ----
-        gemm_phase<true, 0, false, kKB, TWO>(prm->y0, H, g_in, b_in, eps, prm->xn, prm->layer[l].qkv_w, prm->layer[l].qkv_b, nullptr, prm->qkv,
+        gemm_phase<true, 0, false, kKB, TWO, kSplitE>(prm->y0, H, g_in, b_in, eps, prm->xn, prm->layer[l].qkv_w, prm->layer[l].qkv_b, nullptr, prm->qkv,
                                    3 * H, T, 1, L, tid, blk, wpre);
         stamp(1);
         grid_arrive(prm->ctl);
@@ -382,12 +402,12 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
                                    prm->layer[l].ff1_b, nullptr, prm->ffn, I, T, 1, L, tid, blk, wpre);
         stamp(7);
         grid_arrive(prm->ctl);
-        wpre = prefetch_w<kKBE>(prm->layer[l].ff2_w, H, I, 1, blk, tid);
+        wpre = prefetch_w<kKBE>(prm->layer[l].ff2_w, H, I, 1, blk, tid, kSplitE);
         if (!grid_wait<false>(prm->ctl, ++bar, G, L.flag)) return;
         stamp(8);
         // ---- PE: y0 = ffn W2^T + b + x1 ----
         gemm_phase<false, 0, true, kKBE, TWO>(prm->ffn, I, nullptr, nullptr, eps, nullptr, prm->layer[l].ff2_w, prm->layer[l].ff2_b, prm->x1, prm->y0,
-                                   H, T, 1, L, tid, blk, wpre, nullptr, prm->dbg_mode);
+                                   H, T, 1, L, tid, blk, wpre, nullptr, prm->dbg_mode, kSplitE);
         stamp(9);
         grid_arrive(prm->ctl);
         if (l + 1 < nlayers) wpre = prefetch_w<kKB>(prm->layer[l + 1].qkv_w, 3 * H, H, 1, blk, tid);
@@ -403,7 +423,12 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
         float x[16];                                                       // H <= 1024
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const int c = lane + 64 * e; x[e] = c < H ? ld_sc1(src + c) : 0.f; s += x[e]; }
+        for (int e = 0; e < 16; ++e) {
+            const int c = lane + 64 * e;
+            x[e] = 0.f;
+            if (c < H) for (int sp = 0; sp < kSplitE; ++sp) x[e] += ld_sc1(src + (size_t)sp * kTok * H + c);
+            s += x[e];
+        }
         const float mean = wave_sum(s) / (float)H;
         float q = 0.f;
 #pragma unroll
@@ -424,7 +449,7 @@ size_t small_lds_bytes() {
     return (size_t)(kRed + kStat + 64 + 3 * kTok * kAttnLd + kTok * (kTok + 1)) * sizeof(float) + 16;
 }
 
-size_t small_act_floats(int H, int I) { return (size_t)kTok * ((size_t)5 * H + 3 * (size_t)H + I); }
+size_t small_act_floats(int H, int I) { return (size_t)kTok * ((size_t)8 * H + 3 * (size_t)H + I); }       // y0 x 4 parts
 
 }  // namespace
 
@@ -443,14 +468,14 @@ int bert_small_encode(const ac_bert_config& c, const ac_bert_weights& w, const i
     if (c.hidden > 768 || (c.hidden % 128) || (c.intermediate % 128) || c.layers > kMaxLayers || c.hidden != c.heads * kDH) return 1;
     if (!w.type_emb || !w.pos_emb) return 1;
     const int G = 192 < dev_info().cus ? 192 : dev_info().cus;
-    if (G < c.intermediate / 16 || G < 3 * c.hidden / 16 || G < c.heads) return 1;      // one 16-column group per workgroup in every phase
+    if (G < c.intermediate / 16 || G < 3 * c.hidden / 16 || G < c.heads || G < 4 * (c.hidden / 16) || (c.intermediate % 512)) return 1;      // one 16-column group per workgroup in every phase
     SmallParams p;
     p.H = c.hidden; p.I = c.intermediate; p.L = c.layers; p.heads = c.heads; p.T = T; p.b = b; p.S = S; p.G = G; p.eps = c.ln_eps;
     p.ids = ids; p.type_ids = type_ids; p.mask = mask;
     p.word = w.word_emb; p.pos = w.pos_emb; p.type = w.type_emb; p.emb_g = w.emb_ln_g; p.emb_b = w.emb_ln_b;
     float* f = (float*)ws;
     const size_t H = c.hidden, I = c.intermediate;
-    p.y0 = f; f += kTok * H; p.xn = f; f += kTok * H; p.qkv = f; f += kTok * 3 * H; p.ctx = f; f += kTok * H;
+    p.y0 = f; f += 4 * kTok * H; p.xn = f; f += kTok * H; p.qkv = f; f += kTok * 3 * H; p.ctx = f; f += kTok * H;
     p.y1 = f; f += kTok * H; p.x1 = f; f += kTok * H; p.ffn = f; f += kTok * I;
     p.ctl = (GridCtl*)((char*)ws + align_up(small_act_floats(c.hidden, c.intermediate) * sizeof(float), 256));
     p.out = out; p.ldo = ldo;
