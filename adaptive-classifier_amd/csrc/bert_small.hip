@@ -295,6 +295,8 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
     const int H = ka->H, I = ka->I, T = ka->T, S = ka->S, G = ka->G, nlayers = ka->L, heads = ka->heads;
     const float eps = ka->eps;
     unsigned bar = 0;
+    // a barrier that gave up (a workgroup never arrived: the grid was not co-resident): poison the output, do not hang
+    auto bail = [&]() { if (blk < ka->b) for (int c = tid0; c < ka->ldo; c += kT) ka->out[(size_t)blk * ka->ldo + c] = __builtin_nanf(""); };
     // ---- P0: embeddings (pre-LayerNorm), one workgroup per token row ----
     if (blk < T) {
         const int64_t id = ka->ids[blk];
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
     }
     grid_arrive(ka->ctl);
     WPre wpre = prefetch_w<kKB>(ka->layer[0].qkv_w, 3 * H, H, 1, blk, tid0);
-    if (!grid_wait<false>(ka->ctl, ++bar, G, L.flag)) return;
+    if (!grid_wait<false>(ka->ctl, ++bar, G, L.flag)) { bail(); return; }
     const float scale = 1.0f / sqrtf((float)kDH);
 #pragma unroll 1
     for (int l = 0; l < nlayers; ++l) {
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
         stamp(1);
         grid_arrive(prm->ctl);
         wpre = prefetch_w<kKB>(prm->layer[l].ao_w, H, H, 1, blk, tid);                 // (PC's first W chunk: in flight across PB)
-        if (!grid_wait<false>(prm->ctl, ++bar, G, L.flag)) return;
+        if (!grid_wait<false>(prm->ctl, ++bar, G, L.flag)) { bail(); return; }
         stamp(2);
         // ---- PB: attention, one workgroup per head ----
         if (blk < heads) {
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
             }
         }
         stamp(3);
-        if (!grid_barrier<false>(prm->ctl, ++bar, G, L.flag)) return;
+        if (!grid_barrier<false>(prm->ctl, ++bar, G, L.flag)) { bail(); return; }
         stamp(4);
         // ---- PC: y1 = ctx Wo^T + b + x ----
         gemm_phase<false, 0, true, kKB, TWO>(prm->ctx, H, nullptr, nullptr, eps, nullptr, prm->layer[l].ao_w, prm->layer[l].ao_b, prm->xn, prm->y1,
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
         stamp(5);
         grid_arrive(prm->ctl);
         wpre = prefetch_w<kKB>(prm->layer[l].ff1_w, I, H, 1, blk, tid);
-        if (!grid_wait<false>(prm->ctl, ++bar, G, L.flag)) return;
+        if (!grid_wait<false>(prm->ctl, ++bar, G, L.flag)) { bail(); return; }
         stamp(6);
         // ---- PD: x1 = LN(y1); ffn = gelu(x1 W1^T + b) ----
         gemm_phase<true, 2, false, kKB, TWO>(prm->y1, H, prm->layer[l].ln1_g, prm->layer[l].ln1_b, eps, prm->x1, prm->layer[l].ff1_w,
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
         stamp(7);
         grid_arrive(prm->ctl);
         wpre = prefetch_w<kKBE>(prm->layer[l].ff2_w, H, I, 1, blk, tid, kSplitE);
-        if (!grid_wait<false>(prm->ctl, ++bar, G, L.flag)) return;
+        if (!grid_wait<false>(prm->ctl, ++bar, G, L.flag)) { bail(); return; }
         stamp(8);
         // ---- PE: y0 = ffn W2^T + b + x1 ----
         gemm_phase<false, 0, true, kKBE, TWO>(prm->ffn, I, nullptr, nullptr, eps, nullptr, prm->layer[l].ff2_w, prm->layer[l].ff2_b, prm->x1, prm->y0,
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
         stamp(9);
         grid_arrive(prm->ctl);
         if (l + 1 < nlayers) wpre = prefetch_w<kKB>(prm->layer[l + 1].qkv_w, 3 * H, H, 1, blk, tid);
-        if (!grid_wait<false>(prm->ctl, ++bar, G, L.flag)) return;
+        if (!grid_wait<false>(prm->ctl, ++bar, G, L.flag)) { bail(); return; }
         stamp(10);
     }
     // ---- end: LN of the CLS rows, L2-normalise (F.normalize eps 1e-12), one workgroup (its first wave) per sequence ----
@@ -495,8 +497,21 @@ int bert_small_encode(const ac_bert_config& c, const ac_bert_weights& w, const i
         AC_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[T > 16] = true;
     }
-    void* args[] = {&p};
-    AC_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(G), dim3(kT), args, (unsigned)lds, stream));
+    // 192 workgroups of one per CU (LDS / registers) on 256 CUs: co-resident by construction whenever the device is not shared
+    // with another compute process; a plain launch then has the same residency as a cooperative one and saves its ~30 us of
+    // launch overhead -- 5 % of a single-query predict().  AC_BERT_SMALL_COOP=1 asks for the checked cooperative launch; a
+    // barrier that cannot complete gives up after a bounded spin and poisons the output with NaNs.
+    static const int coop = [] { const char* e = getenv("AC_BERT_SMALL_COOP"); return e ? atoi(e) : 0; }();
+    if (coop) {
+        void* args[] = {&p};
+        AC_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(G), dim3(kT), args, (unsigned)lds, stream));
+    } else if (T > 16) {
+        hipLaunchKernelGGL(bert_small_kernel<true>, dim3(G), dim3(kT), lds, stream, p);
+        AC_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(bert_small_kernel<false>, dim3(G), dim3(kT), lds, stream, p);
+        AC_LAUNCH_CHECK();
+    }
     if (debug) {
         static unsigned long long h[3 * kMaxLayers * 12 + 16];
         AC_HIP_CHECK(hipStreamSynchronize(stream));
