@@ -464,9 +464,8 @@ size_t bert_small_ws_bytes(int H, int I) {
 // AC_OK: encoded.  1: shape outside what the persistent kernel covers (caller runs the layer-by-layer path).
 int bert_small_encode(const ac_bert_config& c, const ac_bert_weights& w, const int64_t* ids, const int64_t* type_ids,
                       const int64_t* mask, int b, int S, float* out, int64_t ldo, void* ws, hipStream_t stream) {
-    static const int enabled = [] { const char* e = getenv("AC_BERT_SMALL"); return e ? atoi(e) : 1; }();
     const int T = b * S;
-    if (!enabled || T < 1 || T > kTok) return 1;
+    if (!(persistent_mask() & 2) || T < 1 || T > kTok) return 1;
     if (c.hidden > 768 || (c.hidden % 128) || (c.intermediate % 128) || c.layers > kMaxLayers || c.hidden != c.heads * kDH) return 1;
     if (!w.type_emb || !w.pos_emb) return 1;
     const int G = 192 < dev_info().cus ? 192 : dev_info().cus;

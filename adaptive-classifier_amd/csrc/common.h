@@ -124,6 +124,10 @@ int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const flo
 int head_backward_pair(const float* dY, int64_t ldy, const float* Aact, int64_t lda_act, const float* W, int64_t ldw, int B,
                        int Hout, int Hin, float gate_scale, float* gW, float* dA, float* gb_in, hipStream_t stream);
 
+// bit 0: head_epoch.hip, bit 1: bert_small.hip (ac_set_persistent_kernels; common.hip)
+int persistent_mask();
+int set_persistent_mask(int m);
+
 // head_epoch.hip: the weights-stationary persistent training epoch (see there).  Returns AC_OK, 1 (shape not covered:
 // fall back to the step-by-step launches) or an error code.  lam_direct >= 0: EWC weight of every step; < 0: lambda_B / rows.
 size_t head_epoch_ws_bytes(int H1, int H2);

@@ -14,6 +14,15 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static int g_persistent = [] {
+    int m = 3;
+    if (const char* e = getenv("AC_HEAD_PERSISTENT")) if (atoi(e) == 0) m &= ~1;
+    if (const char* e = getenv("AC_BERT_SMALL")) if (atoi(e) == 0) m &= ~2;
+    return m;
+}();
+int persistent_mask() { return g_persistent; }
+int set_persistent_mask(int m) { const int old = g_persistent; if (m >= 0) g_persistent = m & 3; return old; }
+
 const DevInfo& dev_info() {
     static thread_local DevInfo info = {0, 0, 0};
     static thread_local int cached_dev = -1;
@@ -48,3 +57,5 @@ extern "C" int ac_device_info(int* cu_count, int* lds_bytes_per_block, size_t* h
     if (hbm_bytes) *hbm_bytes = d.hbm_bytes;
     return AC_OK;
 }
+
+extern "C" int ac_set_persistent_kernels(int mask) { return ac::set_persistent_mask(mask); }

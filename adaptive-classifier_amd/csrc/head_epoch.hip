@@ -729,8 +729,7 @@ int head_epoch_persistent(const ac_head_dims& d, float* P, float* M, float* V, f
                           int batch, float dropout_p, uint64_t seed0, const float* F, const float* Old, float lambda_B,
                           float lam_direct, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step0, float* out,
                           float* loss_accum, void* ws, hipStream_t stream) {
-    static const int enabled = [] { const char* e = getenv("AC_HEAD_PERSISTENT"); return e ? atoi(e) : 1; }();
-    if (!enabled || n_total <= 0) return 1;
+    if (!(persistent_mask() & 1) || n_total <= 0) return 1;
     const int G = dev_info().cus < kMaxG ? dev_info().cus : kMaxG;
     if (G < 8) return 1;
     const int r1 = (d.H1 + G - 1) / G, r2 = (d.H2 + G - 1) / G;

@@ -207,6 +207,13 @@ int ac_gemm_get_arith(void);
  * where it applies.  Env AC_GEMM_VARIANT sets the initial value. */
 int ac_gemm_set_variant(int variant);
 
+/* The persistent one-launch kernels of the latency-bound ends of the path are chosen automatically when the shape fits;
+ * this switch (A/B tests, diagnosis) turns them off or on process-wide.  mask bit 0: ac_head_train_step / _epoch through
+ * head_epoch.hip (otherwise the step-by-step launches); bit 1: ac_bert_encode_cls with <= 32 token rows through
+ * bert_small.hip (otherwise the layer-by-layer kernels).  Returns the previous mask; mask < 0 only queries.
+ * Initial value 3, or env AC_HEAD_PERSISTENT / AC_BERT_SMALL = 0 to clear a bit. */
+int ac_set_persistent_kernels(int mask);
+
 /* Diagnostic: resident workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor) of the LDS-tiled
  * GEMM kernels.  kernel: 0 = fp32-MFMA tile, 1 = bf16x3 split-in-kernel, 2 = bf16x3 planes; tm: 1 = 64-row,
  * 2 = 128-row tile. */

@@ -270,6 +270,41 @@ def test_fused_epoch_equals_the_step_loop(with_ewc, cuda_dev):
         assert torch.equal(tr_a.out3, tr_b.out3)
 
 
+@pytest.mark.parametrize("D,C,n,with_ewc", [(768, 4, 109, False), (768, 4, 77, True), (768, 13, 96, False), (128, 3, 70, True)])
+def test_persistent_epoch_kernel_agrees_with_the_launch_by_launch_path(D, C, n, with_ewc, cuda_dev):
+    """head_epoch.hip (weights + AdamW moments stationary in LDS, one launch per epoch) against the step-by-step kernels of
+    head.hip on the same batches, dropout seeds and optimizer state: the two differ only in summation order (fma chains /
+    wave-strided dots vs MFMA tiles), so parameters, moments and the epoch loss agree to fp32 round-off -- not bit for bit."""
+    from adaptive_classifier import _native as nv
+    B = 32
+    _, _, head_a, tr_a = _make_pair(D, C, cuda_dev)
+    _, _, head_b, tr_b = _make_pair(D, C, cuda_dev)
+    Xall, yall = _data(n, D, C, seed=33)
+    Xd, yd = Xall.to(cuda_dev), yall.to(cuda_dev)
+    fisher = old = None
+    if with_ewc:
+        g = torch.Generator().manual_seed(6)
+        fisher = torch.rand(tr_a.flat.numel(), generator=g).to(cuda_dev)
+        old = (tr_a.flat + 0.01 * torch.randn(tr_a.flat.numel(), generator=g).to(cuda_dev)).contiguous()
+    order = torch.randperm(n, generator=torch.Generator().manual_seed(10)).to(cuda_dev)
+    prev = nv.lib().ac_set_persistent_kernels(-1)
+    try:
+        for tr, mask in ((tr_a, prev | 1), (tr_b, prev & ~1)):
+            nv.lib().ac_set_persistent_kernels(mask)
+            tr.loss_accum.zero_()
+            for epoch in range(1):      # (a few steps: AdamW turns round-off on near-zero gradients into O(lr) differences over time)
+                tr.fused_epoch(Xd, yd, order, B, 0.1, 500 + epoch, fisher=fisher, old_params=old, lambda_B=5.0 if with_ewc else 0.0)
+            torch.cuda.synchronize()
+    finally:
+        nv.lib().ac_set_persistent_kernels(prev)
+    assert tr_a.t == tr_b.t
+    assert (tr_a.flat - tr_b.flat).abs().max().item() < 5e-5
+    assert (tr_a.m - tr_b.m).abs().max().item() < 1e-5 and (tr_a.v - tr_b.v).abs().max().item() < 1e-6
+    assert abs(tr_a.loss_accum.item() - tr_b.loss_accum.item()) < 1e-3 * max(1.0, abs(tr_b.loss_accum.item()))
+    assert (tr_a.out3 - tr_b.out3).abs().max().item() < 1e-4
+    assert (tr_a.grads - tr_b.grads).abs().max().item() < 1e-5          # raw gradients of the last step
+
+
 def test_linear_randomised_shapes(cuda_dev):
     """Random (M, N, K, act, residual) through ac_linear_f32: exercises the small-M weight-streaming kernel,
     the direct kernel and both LDS tile heights, with ragged edges."""
