@@ -592,7 +592,11 @@ def main():
                                  "note": "executed FLOPs: the padding tokens of the ragged batch (lengths ~U[8,32], SURVEY 8d) are left "
                                          "out of the forward (ac_bert_encode_cls_packed: identical CLS vectors), and the last layer runs "
                                          "its post-attention part on the CLS rows only; the padded BertModel.forward the reference runs "
-                                         "would be %.4g" % clf.model.flops(BATCH, SEQ, executed=False)},
+                                         "would be %.4g" % clf.model.flops(BATCH, SEQ, executed=False),
+                                 "reference_flops_rate": {"TFLOPs": clf.model.flops(BATCH, SEQ, executed=False) / stages["encode_ms"] / 1e9,
+                                                          "of_peak": clf.model.flops(BATCH, SEQ, executed=False) / stages["encode_ms"] / 1e9 / enc_peak,
+                                                          "note": "NOT a roofline fraction: the FLOPs the reference's padded forward spends on this "
+                                                                  "batch divided by the time this path takes for the same outputs"}},
             "roofline_knn_batch": {"bound": "mfma", "achieved": knn_flops / stages["knn_ms"] / 1e9,
                                    "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                    "frac": knn_flops / stages["knn_ms"] / 1e9 / F32_MFMA_PEAK_TF,
