@@ -220,13 +220,27 @@ class AdaptiveClassifier:
             Xe = X.index_select(0, order)
             ye = None if y is None else y.index_select(0, order)
             te = None if targets is None else targets.index_select(0, order)
-            steps += trainer.fused_epoch(Xe, ye, None, nb0, AdaptiveHead.DROPOUT_P, base_seed + steps,
-                                         fisher=None if ewc is None else ewc.fisher_flat,
-                                         old_params=None if ewc is None else ewc.old_flat,
-                                         lambda_B=0.0 if ewc is None else lambda_B, loss_kind=loss_kind,
-                                         targets_all=te)
-            total = trainer.loss_accum
-            avg_loss = float(total.item()) / steps_per_epoch    # the only host sync of the epoch
+            def run_epoch():
+                return trainer.fused_epoch(Xe, ye, None, nb0, AdaptiveHead.DROPOUT_P, base_seed + steps,
+                                           fisher=None if ewc is None else ewc.fisher_flat,
+                                           old_params=None if ewc is None else ewc.old_flat,
+                                           lambda_B=0.0 if ewc is None else lambda_B, loss_kind=loss_kind,
+                                           targets_all=te)
+            done = run_epoch()
+            avg_loss = float(trainer.loss_accum.item()) / steps_per_epoch    # the only host sync of the epoch
+            if avg_loss != avg_loss and (nv.lib().ac_set_persistent_kernels(-1) & 1):
+                # a NaN epoch loss with the persistent kernel on: either the run diverged or a grid barrier gave up (device
+                # shared with another process).  Put the parameters back and repeat the epoch launch by launch, once.
+                logger.warning("training epoch returned NaN through the persistent kernel; repeating it with the step-by-step launches")
+                trainer.restore_epoch()
+                trainer.loss_accum.zero_()
+                prev = nv.lib().ac_set_persistent_kernels(nv.lib().ac_set_persistent_kernels(-1) & ~1)
+                try:
+                    done = run_epoch()
+                    avg_loss = float(trainer.loss_accum.item()) / steps_per_epoch
+                finally:
+                    nv.lib().ac_set_persistent_kernels(prev)
+            steps += done
             if sched is not None:
                 sched.step(avg_loss)
                 trainer.lr = dummy.param_groups[0]["lr"]
@@ -432,10 +446,22 @@ class AdaptiveClassifier:
         history-keyed weights (0.3/0.7 vs 0.7/0.3), stable sort, normalise, top-k.
         (Replaying this ~90-kernel single-query chain as one captured HIP graph was measured and dropped: 1.013 vs
         1.014 ms -- the chain is paced by the GPU's dependent-dispatch interval, not by host enqueue)"""
-        emb = self._embed_device([text])
-        max_classes = len(self.id_to_label) if self.id_to_label else k
-        S, I, P = self._device_stage(emb, max_classes)
-        return self._finish(S, I, P, k, regular=True, b=1)[0]
+        def run():
+            emb = self._embed_device([text])
+            max_classes = len(self.id_to_label) if self.id_to_label else k
+            S, I, P = self._device_stage(emb, max_classes)
+            return self._finish(S, I, P, k, regular=True, b=1)[0]
+        res = run()
+        if any(s != s for _, s in res) and (nv.lib().ac_set_persistent_kernels(-1) & 2):
+            # NaN scores with the one-launch encoder on: one of its grid barriers gave up (device shared with another compute
+            # process poisons the embedding with NaNs rather than hanging).  Repeat through the layer-by-layer kernels.
+            logger.warning("single-query encoder returned NaN through the persistent kernel; repeating layer by layer")
+            prev = nv.lib().ac_set_persistent_kernels(nv.lib().ac_set_persistent_kernels(-1) & ~2)
+            try:
+                res = run()
+            finally:
+                nv.lib().ac_set_persistent_kernels(prev)
+        return res
 
     def predict_batch(self, texts: List[str], k: int = 5, batch_size: int = 32) -> List[List[Tuple[str, float]]]:
         """classifier.py:1308-1388: top-k prototypes + top-k head classes, fixed 0.7/0.3 weights."""

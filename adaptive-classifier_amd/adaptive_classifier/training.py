@@ -39,6 +39,8 @@ class HeadTrainer:
         self.out3 = torch.zeros(3, dtype=torch.float32, device=dev)     # fused step: [ce, ewc penalty, grad norm]
         self.loss_accum = torch.zeros(1, dtype=torch.float32, device=dev)   # epoch running sum (device)
         self._ws = None
+        self._snap = None
+        self._snap_t = 0
 
     def _workspace(self, B):
         need = ctypes.c_size_t(0)
@@ -129,6 +131,12 @@ class HeadTrainer:
         n_total = int(order.numel()) if order is not None else int(X_all.shape[0])
         ws = self._workspace(min(batch, max(n_total, 1)))
         done = ctypes.c_int(0)
+        # the persistent epoch kernel publishes the output layer step by step; should one of its grid barriers give up (a GPU
+        # shared with another compute process), the epoch is void and `restore_epoch()` puts the parameters back
+        if self._snap is None:
+            self._snap = torch.empty_like(self.flat)
+        self._snap.copy_(self.flat)
+        self._snap_t = self.t
         with torch.cuda.device(self.device):
             nv.check(nv.lib().ac_head_train_epoch(
                 ctypes.byref(self.dims), nv.ptr(self.flat), nv.ptr(self.m), nv.ptr(self.v), nv.ptr(self.grads),
@@ -140,3 +148,8 @@ class HeadTrainer:
                 nv.stream_ptr(self.device)), "ac_head_train_epoch")
         self.t += done.value
         return done.value
+
+    def restore_epoch(self):
+        """Undo the last fused_epoch (parameters and step counter; the moments are only written when an epoch completes)."""
+        self.flat.copy_(self._snap)
+        self.t = self._snap_t

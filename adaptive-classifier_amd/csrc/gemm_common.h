@@ -38,7 +38,7 @@ __device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, in
     float v = e.alpha * acc;
     if (e.beta != 0.f) v = fmaf(e.beta, C[row * ldc + col], v);
     if (e.bias) v += e.bias[col];
-    if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
+    if (e.act == ACT_RELU) v = v < 0.f ? 0.f : v;            // (torch.relu semantics: NaN stays NaN, unlike fmaxf)
     else if (e.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     if (e.mask) v = e.mask[row * (int64_t)N + col] ? v * e.mask_scale : 0.f;
     else if (e.drop_p > 0.f) v = ac::dropout_keep(e.drop_seed, (uint64_t)(row * (int64_t)N + col), e.drop_p) ? v * e.mask_scale : 0.f;
@@ -57,7 +57,7 @@ template <int EPI>
 __device__ __forceinline__ float fast_epilogue(float acc, float bias, float res) {
     float v = acc + bias;
     if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+    if (EPI == EPI_BIAS_RELU) v = v < 0.f ? 0.f : v;
     if (EPI == EPI_BIAS_RES) v += res;
     return v;
 }

@@ -69,7 +69,7 @@ __device__ __forceinline__ bool grid_wait(GridCtl* c, unsigned n, unsigned G, un
             if (__all(v >= target)) break;
             __builtin_amdgcn_s_sleep(2);                 // (polling flat out slows the stragglers' own memory traffic)
             if ((spins & 1023) == 1023) {
-                if (__hip_atomic_load(&c->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins > (1l << 24)) {
+                if (__hip_atomic_load(&c->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins > (1l << 21)) {
                     if (lane == 0) __hip_atomic_store(&c->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = 0;
                     break;

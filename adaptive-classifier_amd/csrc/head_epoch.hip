@@ -207,6 +207,16 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
     const int64_t n_total = ka->n_total;
     const int batch = ka->batch;
     unsigned bar = 0;
+    // a barrier that gave up (the grid was not co-resident -- a device shared with another compute process): nothing is
+    // written back; the epoch loss and the step outputs are poisoned with NaNs so that the host notices and re-runs the epoch
+    // through the step-by-step launches (training.py / classifier.py)
+    auto bail = [&]() {
+        if (g == 0 && tid0 == 0) {
+            const float nanv = __builtin_nanf("");
+            ka->out[0] = nanv; ka->out[1] = nanv; ka->out[2] = nanv;
+            if (ka->loss_accum) *ka->loss_accum = nanv;
+        }
+    };
     int step_i = 0;
 #pragma unroll 1
     for (int64_t off = 0; off < n_total; off += batch, ++step_i) {
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
                 const int h = lane & 7, v = lane >> 3, q = 2 * h + (v >> 2), ii = v & 3, b = wave + 8 * q;
                 if (b < nb && ii < n1) {
                     float val = (h == 0 ? mine[0] : mine[1]) + Ps[oB1 + ii];
-                    val = fmaxf(val, 0.f);
+                    val = val < 0.f ? 0.f : val;
                     if (drop_p > 0.f)
                         val = ac::dropout_keep(prm->seed0 + (uint64_t)step_i, (uint64_t)((int64_t)b * H1 + i0 + ii), drop_p) ? val * sc.s1 : 0.f;
                     a1own[b * 4 + ii] = val;
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
             }
         }
         stamp(1);
-        if (!grid_barrier<kAcquireB1>(prm->ctl, ++bar, G, flag)) return;
+        if (!grid_barrier<kAcquireB1>(prm->ctl, ++bar, G, flag)) { bail(); return; }
         stamp(2);
 
         // ================= P2: a2[:, own2] = drop(relu(a1 W2r^T + b2)) =================
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
                 const int v = lane >> 3, q = v >> 1, jj = v & 1, b = wave + 8 * q;
                 if (b < nb && jj < n2) {
                     float val = mine + Ps[oB2 + jj];
-                    val = fmaxf(val, 0.f);
+                    val = val < 0.f ? 0.f : val;
                     if (drop_p > 0.f)
                         val = ac::dropout_keep((prm->seed0 + (uint64_t)step_i) ^ 0xA5A5A5A5A5A5A5A5ull, (uint64_t)((int64_t)b * H2 + j0 + jj), drop_p) ? val * sc.s2 : 0.f;
                     a2own[b * 2 + jj] = val;
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
             if (tid < C) b3s[tid] = kAcquireB1 ? prm->P[prm->o_b3 + tid] : ld_sc1(prm->P + prm->o_b3 + tid);
         }
         stamp(3);
-        if (!grid_barrier<false>(prm->ctl, ++bar, G, flag)) return;
+        if (!grid_barrier<false>(prm->ctl, ++bar, G, flag)) { bail(); return; }
         stamp(4);
 
         // ================= P3: logits, loss, dz, d2 (every workgroup, identically) =================
@@ -664,7 +674,7 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
         block_sum8x2(sg, se, red);
         if (tid == 0) { st_sc1(prm->partials + g, sg); st_sc1(prm->partials + kMaxG + g, se); }
         stamp(12);
-        if (!grid_barrier<false>(prm->ctl, ++bar, G, flag)) return;
+        if (!grid_barrier<false>(prm->ctl, ++bar, G, flag)) { bail(); return; }
         stamp(13);
 
         // ================= P5: clip + AdamW on the owned elements =================

@@ -364,3 +364,60 @@ def test_batched_device_prune_equals_per_example_host_logic(cap, D, stream, cuda
     ra, rb = a.get_nearest_prototypes(q, 3), b.get_nearest_prototypes(q, 3)
     assert [l for l, _ in ra] == [l for l, _ in rb] and np.allclose([s for _, s in ra], [s for _, s in rb], atol=1e-6)
 
+
+
+def test_void_persistent_launches_are_repeated_launch_by_launch(cuda_dev, monkeypatch, caplog):
+    """The one-launch kernels poison their outputs with NaNs when a grid barrier gives up (a device shared with another
+    compute process) instead of hanging; the host notices and repeats the work through the ordinary launches.  Simulated
+    here by corrupting what the persistent launches return: training and predict() must come out finite and equal to a
+    run that never used them."""
+    import logging
+    from adaptive_classifier import AdaptiveClassifier, _native as nv
+    from adaptive_classifier.encoder import HipBertEncoder
+    from adaptive_classifier.training import HeadTrainer
+    enc = HipBertEncoder(small_bert(), device=cuda_dev)
+
+    def build():
+        c = AdaptiveClassifier("synthetic-bert-tiny", device="cuda:0", encoder=enc, tokenizer=HashTokenizer())
+        c.add_examples(TEXTS, LABELS)
+        return c
+
+    prev = nv.lib().ac_set_persistent_kernels(0)          # reference run: launch-by-launch everywhere
+    try:
+        want_clf = build()
+        want = want_clf.predict("great product", k=3)
+    finally:
+        nv.lib().ac_set_persistent_kernels(prev)
+
+    real_epoch = HeadTrainer.fused_epoch
+    calls = {"n": 0}
+
+    def void_epoch(self, *a, **k):
+        m0, v0 = self.m.clone(), self.v.clone()
+        done = real_epoch(self, *a, **k)
+        if nv.lib().ac_set_persistent_kernels(-1) & 1:    # a "void" persistent epoch: NaN loss, the output layer half-written,
+            calls["n"] += 1                               # the moments untouched (they are only written when an epoch completes)
+            self.loss_accum.fill_(float("nan"))
+            self.flat[-16:] += 1.0
+            self.m.copy_(m0); self.v.copy_(v0)
+        return done
+
+    monkeypatch.setattr(HeadTrainer, "fused_epoch", void_epoch)
+    real_encode = enc.encode_cls
+
+    def void_encode(ids, *a, **k):
+        out = real_encode(ids, *a, **k)
+        if ids.shape[0] * ids.shape[1] <= 32 and (nv.lib().ac_set_persistent_kernels(-1) & 2):
+            calls["n"] += 1
+            out = out * float("nan")
+        return out
+
+    with caplog.at_level(logging.WARNING):
+        got_clf = build()
+        monkeypatch.setattr(enc, "encode_cls", void_encode)
+        got = got_clf.predict("great product", k=3)
+    assert calls["n"] >= 2 and "persistent kernel" in caplog.text
+    assert nv.lib().ac_set_persistent_kernels(-1) == prev                      # the switch is put back
+    assert np.isfinite(got_clf.last_train_info["final_loss"])
+    assert torch.allclose(got_clf.adaptive_head.flat_params(), want_clf.adaptive_head.flat_params(), atol=1e-6)
+    assert [l for l, _ in got] == [l for l, _ in want] and np.allclose([s for _, s in got], [s for _, s in want], atol=1e-6)
