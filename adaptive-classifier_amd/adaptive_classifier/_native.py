@@ -140,6 +140,9 @@ _SIGNATURES = {
     "ac_modernbert_encode_cls": (c_int, [ctypes.POINTER(ac_modernbert_config), ctypes.POINTER(ac_modernbert_weights),
                                          c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
                                          c_void_p]),
+    "ac_modernbert_encode_cls_packed": (c_int, [ctypes.POINTER(ac_modernbert_config), ctypes.POINTER(ac_modernbert_weights),
+                                                c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
+                                                c_void_p, c_size_t, c_void_p]),
     "ac_wordpiece_hash": (c_uint64, [c_void_p, c_int, c_int]),
     "ac_wordpiece_encode": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(ac_wordpiece_vocab), c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),

@@ -218,8 +218,10 @@ def _split_planes(t, device):
 class HipModernBertEncoder:
     """ModernBERT (transformers modeling_modernbert.py) behind the same surface as HipBertEncoder."""
 
-    def __init__(self, hf_model, device=None):
+    def __init__(self, hf_model, device=None, unpad=True):
         nv.require_gpu()
+        self.unpad = bool(unpad)            # leave the padding tokens of ragged batches out of the forward
+        self.last_tokens = 0
         cfg = hf_model.config
         if getattr(cfg, "model_type", "") != "modernbert":
             raise nv.NativeError(f"HipModernBertEncoder needs a ModernBERT model, got {getattr(cfg, 'model_type', None)!r}")
@@ -338,9 +340,27 @@ class HipModernBertEncoder:
         need = self.workspace_bytes(min(b, cb), S)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.last_tokens = 0
         with torch.cuda.device(self.device):
             for r0 in range(0, b, cb):
                 r1 = min(b, r0 + cb)
+                nb = r1 - r0
+                if self.unpad and mk is not None and S > 1:
+                    # padding-free path (same packing kernels as the BERT encoder): RoPE positions stay per sequence
+                    cu = torch.empty(nb + 1, dtype=torch.int32, device=self.device)
+                    src = torch.empty(nb * S, dtype=torch.int32, device=self.device)
+                    info = torch.empty(4, dtype=torch.int32, device=self.device)
+                    nv.check(nv.lib().ac_bert_pack(nv.ptr(mk[r0:r1]), nb, S, nv.ptr(cu), nv.ptr(src), nv.ptr(info),
+                                                   nv.stream_ptr(self.device)), "ac_bert_pack")
+                    total, not_prefix, longest, _ = info.tolist()
+                    if not not_prefix and total < nb * S:
+                        nv.check(nv.lib().ac_modernbert_encode_cls_packed(
+                            ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]), nb, S, nv.ptr(cu),
+                            nv.ptr(src), total, longest, nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws),
+                            self._ws.numel(), nv.stream_ptr(self.device)), "ac_modernbert_encode_cls_packed")
+                        self.last_tokens += total
+                        continue
+                self.last_tokens += nb * S
                 nv.check(nv.lib().ac_modernbert_encode_cls(
                     ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
                     nv.ptr(None if mk is None else mk[r0:r1]), r1 - r0, S, nv.ptr(out[r0:r1]), out.stride(0),

@@ -701,15 +701,14 @@ extern "C" int ac_modernbert_workspace(const ac_modernbert_config* cfg, int b, i
     return AC_OK;
 }
 
-extern "C" int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const ac_modernbert_weights* w,
-                                        const int64_t* d_ids, const int64_t* d_mask, int b, int S, float* d_out,
-                                        int64_t ldo, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
-    int rc = check_mb(cfg);
-    if (rc) return rc;
-    hipStream_t stream = (hipStream_t)stream_;
-    if (b == 0) return AC_OK;
-    AC_REQUIRE(w && d_ids && d_out && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden, AC_EINVAL,
-               "modernbert_encode_cls: bad arguments (b=%d S=%d max_pos=%d)", b, S, cfg->max_pos);
+namespace {
+
+// shared body of ac_modernbert_encode_cls (cu == nullptr: the [b, S] rows incl. padding, T = b * S) and
+// ac_modernbert_encode_cls_packed (cu / tok_src from ac_bert_pack: T real-token rows, no mask)
+int modernbert_encode_impl(const ac_modernbert_config* cfg, const ac_modernbert_weights* w, const int64_t* d_ids,
+                           const int64_t* d_mask, int b, int S, const int32_t* cu, const int32_t* tok_src, int T, int Smax,
+                           float* d_out, int64_t ldo, void* d_ws, size_t ws_bytes, hipStream_t stream) {
+    int rc;
     AC_REQUIRE(w->tok_emb && w->emb_norm_g && w->final_norm_g && w->zero_bias && w->rope_cos_global &&
                    w->rope_sin_global && w->rope_cos_local && w->rope_sin_local && w->attn_norm_g && w->wqkv && w->wo &&
                    w->mlp_norm_g && w->wi && w->wo2,
@@ -728,7 +727,7 @@ extern "C" int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const a
     uint16_t* xnp = (uint16_t*)(base + ws.xnp);
     uint16_t* ctxp = (uint16_t*)(base + ws.ctxp);
     uint16_t* gp = (uint16_t*)(base + ws.gp);
-    const int T = b * S, H = c.hidden, I = c.intermediate;
+    const int H = c.hidden, I = c.intermediate;
     const int tok_blocks = (T + 3) / 4;
     const float* zb = w->zero_bias;
     auto opt = [&](const float* const* arr, int l) -> const float* { return (arr && arr[l]) ? arr[l] : zb; };
@@ -738,7 +737,7 @@ extern "C" int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const a
     // embeddings -> LayerNorm: this IS the input of layer 0's attention (attn_norm = Identity there)
     hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, d_ids, (const int64_t*)nullptr, T, S, H,
                        w->tok_emb, (const float*)nullptr, (const float*)nullptr, w->emb_norm_g,
-                       w->emb_norm_b ? w->emb_norm_b : zb, c.norm_eps, x, pl ? xnp : nullptr);
+                       w->emb_norm_b ? w->emb_norm_b : zb, c.norm_eps, x, pl ? xnp : nullptr, tok_src);
     AC_LAUNCH_CHECK();
     const float scale = 1.0f / sqrtf((float)DH);
     for (int l = 0; l < c.layers; ++l) {
@@ -762,16 +761,24 @@ extern "C" int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const a
         // the CLS-query attention, the output projection, the MLP and the final norm run on b rows, not b*S.
         const int Ml = last ? b : T;
         const bool lp = last ? (wplanes && ac::linear_takes_planes(b, H, H) && ac::linear_takes_planes(b, H, I) && (H % 8) == 0) : pl;
+        const float* resid = x;
+        int64_t ldres = last ? (int64_t)S * H : H;
         if (last) {
             hipLaunchKernelGGL(attention_cls_kernel<true>, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale, ctx,
-                               rc_, rs_, win);
+                               rc_, rs_, win, cu);
+            if (cu) {                                  // packed layout: the CLS rows sit at cu[s]; gather them (g is free until GeGLU)
+                AC_LAUNCH_CHECK();
+                hipLaunchKernelGGL(gather_rows_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, cu, b, H, g);
+                resid = g;
+                ldres = H;
+            }
         } else {
-            hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((S + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv, d_mask,
-                               S, H, scale, ctx, pl ? ctxp : nullptr, rc_, rs_, win);
+            hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((Smax + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv, d_mask,
+                               S, H, scale, ctx, pl ? ctxp : nullptr, rc_, rs_, win, cu, (int64_t)T);
         }
         AC_LAUNCH_CHECK();
-        // y = x + ctx Wo^T   (last layer: ctx is b compact rows, the residual rows of x are S*H apart)
-        rc = ac::linear_f32(ctx, H, w->wo[l], H, opt(w->wo_b, l), x, last ? (int64_t)S * H : H, y, H, Ml, H, H, 0, nullptr, 1.f,
+        // y = x + ctx Wo^T   (last layer: ctx is b compact rows, the residual rows of x are S*H apart / gathered)
+        rc = ac::linear_f32(ctx, H, w->wo[l], H, opt(w->wo_b, l), resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f,
                             stream, 0.f, 0, wplanes ? w->wo3[l] : nullptr, (pl && !last) ? ctxp : nullptr);
         if (rc) return rc;
         hipLaunchKernelGGL(ln_kernel, dim3((Ml + 3) / 4), dim3(256), 0, stream, y, Ml, H, w->mlp_norm_g[l],
@@ -803,4 +810,32 @@ extern "C" int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const a
     hipLaunchKernelGGL(cls_normalize_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, xn, b, 1, H, d_out, ldo);
     AC_LAUNCH_CHECK();
     return AC_OK;
+}
+
+}  // namespace
+
+extern "C" int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const ac_modernbert_weights* w,
+                                        const int64_t* d_ids, const int64_t* d_mask, int b, int S, float* d_out,
+                                        int64_t ldo, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    int rc = check_mb(cfg);
+    if (rc) return rc;
+    if (b == 0) return AC_OK;
+    AC_REQUIRE(w && d_ids && d_out && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden, AC_EINVAL,
+               "modernbert_encode_cls: bad arguments (b=%d S=%d max_pos=%d)", b, S, cfg->max_pos);
+    return modernbert_encode_impl(cfg, w, d_ids, d_mask, b, S, nullptr, nullptr, b * S, S, d_out, ldo, d_ws, ws_bytes,
+                                  (hipStream_t)stream_);
+}
+
+extern "C" int ac_modernbert_encode_cls_packed(const ac_modernbert_config* cfg, const ac_modernbert_weights* w,
+                                               const int64_t* d_ids, int b, int S, const int32_t* d_cu,
+                                               const int32_t* d_tok_src, int total_tokens, int longest, float* d_out,
+                                               int64_t ldo, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    int rc = check_mb(cfg);
+    if (rc) return rc;
+    if (b == 0) return AC_OK;
+    AC_REQUIRE(w && d_ids && d_out && d_cu && d_tok_src && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden &&
+                   total_tokens >= b && total_tokens <= b * S && longest >= 1 && longest <= S,
+               AC_EINVAL, "modernbert_encode_cls_packed: bad arguments (b=%d S=%d tokens=%d longest=%d)", b, S, total_tokens, longest);
+    return modernbert_encode_impl(cfg, w, d_ids, nullptr, b, S, d_cu, d_tok_src, total_tokens, longest, d_out, ldo, d_ws, ws_bytes,
+                                  (hipStream_t)stream_);
 }

@@ -543,6 +543,15 @@ int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const ac_modernber
                              float* d_out_unit_cls, int64_t ldo,
                              void* d_ws, size_t ws_bytes, ac_stream_t stream);
 
+/* Padding-free form (see ac_bert_encode_cls_packed): d_cu / d_tok_src / total_tokens / longest from ac_bert_pack on the
+ * attention mask; RoPE positions are positions inside each sequence; identical CLS vectors.  Workspace as
+ * ac_modernbert_workspace(b, S). */
+int ac_modernbert_encode_cls_packed(const ac_modernbert_config* cfg, const ac_modernbert_weights* w,
+                                    const int64_t* d_ids, int b, int S,
+                                    const int32_t* d_cu, const int32_t* d_tok_src, int total_tokens, int longest,
+                                    float* d_out_unit_cls, int64_t ldo,
+                                    void* d_ws, size_t ws_bytes, ac_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  *  T: tokenizer  (self.tokenizer(texts, max_length, truncation=True, padding=True), classifier.py:1259-1265)
  * ------------------------------------------------------------------------- */

@@ -173,3 +173,27 @@ def test_padding_free_path_equals_padded_path(cuda_dev):
     want = bert_oracle.encode_cls(model, ids, types, mask)
     ok = mask[:, 0] != 0                                                             # rows whose position 0 is a real token
     assert (a.cpu()[ok] - want[ok]).abs().max().item() < 1e-4 if ok.any() else True
+
+
+@pytest.mark.parametrize("hidden,layers,heads,inter,local,b,S", [
+    (128, 4, 2, 192, 16, 9, 40),          # windows of +-8 cut inside the ragged sequences; T = 360 -> planes
+    (768, 3, 12, 1152, 128, 5, 70),       # ModernBERT-base width, two key tiles
+    (128, 3, 2, 192, 128, 3, 12),         # small-M GEMM path
+])
+def test_modernbert_padding_free_path_equals_padded_path(hidden, layers, heads, inter, local, b, S, cuda_dev):
+    """ac_modernbert_encode_cls_packed (padding tokens left out; RoPE positions per sequence) gives the CLS vectors of the
+    padded forward, and both match transformers within the 1e-4 bar."""
+    from adaptive_classifier.encoder import HipModernBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_modernbert(hidden, layers, heads, inter, vocab=2000, max_pos=1024, local_attention=local, seed=3,
+                                        init_scale=4.0)
+    ids, _, mask = bert_oracle.synthetic_batch(b, S, vocab=2000, seed=77, ragged=True)
+    ids[:, 0] = 1
+    want = bert_oracle.encode_cls_modernbert(model, ids, mask)
+    packed = HipModernBertEncoder(model, device=cuda_dev, unpad=True)
+    padded = HipModernBertEncoder(model, device=cuda_dev, unpad=False)
+    got_p = packed.encode_cls(ids, None, mask).cpu()
+    got_f = padded.encode_cls(ids, None, mask).cpu()
+    assert packed.last_tokens == int(mask.sum()) < b * S == padded.last_tokens
+    assert (got_p - got_f).abs().max().item() < 2e-6
+    assert (got_p - want).abs().max().item() < 1e-4
