@@ -105,6 +105,7 @@ struct BatchParams {
     int Kp;
     int G;                                   // row groups per query tile
     int nqt;                                 // query tiles of 128
+    int map_by_xcd;                          // workgroup -> (query tile, row group) mapping, see the kernel
     int64_t ntiles;                          // row tiles of 256
     float* cand_d; int32_t* cand_i; int32_t* cand_cnt; int cap;
 };
@@ -116,8 +117,17 @@ __global__ __launch_bounds__(kBatchThreads, 4) void knn_batch_sweep(BatchParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;                        // 4 x 2 waves of 64 rows x 64 queries
     const int i32 = lane & 31, kg = lane >> 5;
-    const int v = xcd_tile_id(blockIdx.x, gridDim.x);               // blocks of one query tile neighbour each other on an XCD
-    const int qt = v % prm.nqt, g = v / prm.nqt;
+    const int v = xcd_tile_id(blockIdx.x, gridDim.x);               // XCD-contiguous virtual id
+    // Default: the nqt query-tile workgroups of one row group are neighbours on an XCD and share that row stream through
+    // its L2.  Alternative (AC_KNN_BATCH_MAP=1, measured and rejected: 198 vs 187 ms at 4096 x 10M, 14.6 vs 13.3 ms at
+    // 1024 x 2M): each XCD takes nqt / 8 query tiles against all row groups, which keeps its query tiles L2-resident and
+    // reads the store 8 times in all, but leaves only nqt / 8 workgroups sharing a row stream.
+    int qt, g;
+    if (prm.map_by_xcd) {
+        const int per_xcd = (int)(gridDim.x >> 3), qpx = prm.nqt >> 3;
+        const int x = v / per_xcd, u = v - x * per_xcd;
+        qt = x * qpx + u % qpx; g = u / qpx;
+    } else { qt = v % prm.nqt; g = v / prm.nqt; }
     const int64_t my_tiles = prm.ntiles > g ? (prm.ntiles - 1 - g) / prm.G + 1 : 0;
     if (my_tiles == 0) return;
     const int nk = prm.Kp / BSBK;
@@ -274,6 +284,8 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
     if (G > p.ntiles / 2) G = p.ntiles / 2;
     if (G < 1) G = 1;
     p.G = (int)G;
+    static const int map_env = getenv("AC_KNN_BATCH_MAP") ? atoi(getenv("AC_KNN_BATCH_MAP")) : -1;      // A/B switch
+    p.map_by_xcd = (p.nqt % 8 == 0) && map_env == 1;
     p.cand_d = cand_d; p.cand_i = cand_i; p.cand_cnt = cand_cnt; p.cap = cap;
     hipLaunchKernelGGL(knn_batch_sweep, dim3((unsigned)(p.G * p.nqt)), dim3(kBatchThreads), 0, stream, p);
     AC_LAUNCH_CHECK();
