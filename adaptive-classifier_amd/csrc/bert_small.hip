@@ -46,7 +46,6 @@ struct SmallParams {
     float *y0, *xn, *qkv, *ctx, *y1, *x1, *ffn;      // [kTok, .] activations
     float* out; int64_t ldo;
     GridCtl* ctl;
-    int dbg_mode;                  // timing experiments only: 1 = PE reads no activations, 2 = PE reads no weights
     unsigned long long* dbg;       // AC_BERT_SMALL_DEBUG: s_memtime stamps, [workgroup < 4][layer][12]
     LayerPtrs layer[kMaxLayers];
 };
@@ -134,7 +133,7 @@ __device__ __forceinline__ WPre prefetch_w(const float* W, int N, int K, int gro
 template <bool LN, int ACT, bool RES, int KB, bool TWO, int NSUM = 1>
 __device__ __forceinline__ void gemm_phase(const float* A, int K, const float* g_ln, const float* b_ln, float eps, float* xn_out,
                                            const float* W, const float* bias, const float* R, float* out, int N, int T,
-                                           int groups_per_block, const Lds& L, int tid, int blk, const WPre& pre, unsigned long long* dbgp = nullptr, int mode = 0,
+                                           int groups_per_block, const Lds& L, int tid, int blk, const WPre& pre, unsigned long long* dbgp = nullptr,
                                            int ksplit = 1) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15;
@@ -145,8 +144,8 @@ __device__ __forceinline__ void gemm_phase(const float* A, int K, const float* g
     out += (size_t)g.ks * kTok * N;                 // (K split: this part's partial-result buffer)
     constexpr bool two = TWO;
     constexpr int KB1 = TWO ? KB : 1;       // (the second row tile's fragments exist only when it does)
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (mode & 1) ? 0u : (unsigned)((NSUM > 1 ? NSUM * kTok : two ? kTok : 16) * K * sizeof(float)));
-    const __amdgpu_buffer_rsrc_t rW = make_rsrc(W, (mode & 2) ? 0u : (unsigned)((size_t)N * K * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (unsigned)((NSUM > 1 ? NSUM * kTok : two ? kTok : 16) * K * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(W, (unsigned)((size_t)N * K * sizeof(float)));
     auto load_a = [&](float4 (&a0)[KB], float4 (&a1)[KB1], int unit) {
         const int kb0 = ((unit % g.nchunks + g.rot) % g.nchunks) * KB;
         const bool live = g.g_lo + unit / g.nchunks < g.g_hi;
@@ -409,7 +408,7 @@ __global__ __launch_bounds__(kT) void bert_small_kernel(const SmallParams prm_) 
         stamp(8);
         // ---- PE: y0 = ffn W2^T + b + x1 ----
         gemm_phase<false, 0, true, kKBE, TWO>(prm->ffn, I, nullptr, nullptr, eps, nullptr, prm->layer[l].ff2_w, prm->layer[l].ff2_b, prm->x1, prm->y0,
-                                   H, T, 1, L, tid, blk, wpre, nullptr, prm->dbg_mode, kSplitE);
+                                   H, T, 1, L, tid, blk, wpre, nullptr, kSplitE);
         stamp(9);
         grid_arrive(prm->ctl);
         if (l + 1 < nlayers) wpre = prefetch_w<kKB>(prm->layer[l + 1].qkv_w, 3 * H, H, 1, blk, tid);
@@ -481,7 +480,6 @@ int bert_small_encode(const ac_bert_config& c, const ac_bert_weights& w, const i
     p.ctl = (GridCtl*)((char*)ws + align_up(small_act_floats(c.hidden, c.intermediate) * sizeof(float), 256));
     p.out = out; p.ldo = ldo;
     static const int debug = [] { const char* e = getenv("AC_BERT_SMALL_DEBUG"); return e ? atoi(e) : 0; }();
-    p.dbg_mode = debug >> 4;
     p.dbg = debug ? (unsigned long long*)((char*)p.ctl + align_up(sizeof(GridCtl), 256)) : nullptr;
     for (int l = 0; l < c.layers; ++l) {
         LayerPtrs& q = p.layer[l];
