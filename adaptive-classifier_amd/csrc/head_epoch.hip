@@ -105,18 +105,23 @@ struct StepScalars {
     float lam, two_lam, lr_wd, one_m_b1, one_m_b2, step_size, bc2_sqrt, s1, s2;
 };
 
-// one element's AdamW update in LDS (formulas of ewc_adamw_kernel, head.hip)
+// one element's AdamW update on register values (formulas of ewc_adamw_kernel, head.hip).  The W2 duplicate must stay
+// bit-identical to the row copy although the two are updated at different places in the code, so the contraction of every
+// multiply-add is written out (fmaf) and the compiler may not choose its own.
+__device__ __forceinline__ void adamw_vals(float& pi, float& mi, float& vi, float g_tot, float coef, const StepScalars& sc, float beta2,
+                                           float eps) {
+#pragma clang fp contract(off)
+    const float gi = g_tot * coef;
+    pi = pi * (1.f - sc.lr_wd);
+    mi = fmaf(gi - mi, sc.one_m_b1, mi);
+    vi = fmaf(sc.one_m_b2 * gi, gi, vi * beta2);
+    const float denom = sqrtf(vi) / sc.bc2_sqrt + eps;
+    pi = fmaf(-sc.step_size, mi / denom, pi);
+}
 __device__ __forceinline__ void adamw_elem(float* Ps, float* Ms, float* Vs, int e, float g_tot, float coef, const StepScalars& sc,
                                            float beta2, float eps) {
-    float pi = Ps[e];
-    const float gi = g_tot * coef;
-    pi *= (1.f - sc.lr_wd);
-    float mi = Ms[e];
-    mi = mi + (gi - mi) * sc.one_m_b1;
-    float vi = Vs[e] * beta2;
-    vi = vi + sc.one_m_b2 * gi * gi;
-    const float denom = sqrtf(vi) / sc.bc2_sqrt + eps;
-    pi = pi - sc.step_size * (mi / denom);
+    float pi = Ps[e], mi = Ms[e], vi = Vs[e];
+    adamw_vals(pi, mi, vi, g_tot, coef, sc, beta2, eps);
     Ps[e] = pi; Ms[e] = mi; Vs[e] = vi;
 }
 
@@ -633,18 +638,17 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
         const int e_row0 = teamA ? oW1 + tcol : oW2r + tcol;
         const int e_stride = teamA ? D : H1;
         const int64_t gi_row0 = teamA ? prm->o_w1 + (int64_t)i0 * D + tcol : prm->o_w2 + (int64_t)j0 * H1 + tcol;
-        auto for_owned = [&](auto&& f) {
+        // rows of the big matrices as 16-byte vectors (4 consecutive columns per thread: float4 LDS / global accesses, no bank
+        // conflicts -- scalar accesses at a 16-byte lane stride were 4-way conflicted, 23 % of the kernel's LDS cycles), the
+        // W2 duplicate and the small tensors element by element
+        auto for_rows = [&](auto&& f4) {
             if (gw_active) {
 #pragma unroll
-                for (int r = 0; r < R1; ++r) {
-                    if (r < (teamA ? R1 : R2)) {
-                        const int e = e_row0 + r * e_stride;
-                        const int64_t gi = gi_row0 + (int64_t)r * e_stride;
-                        const bool real = r < nrow;
-                        f(e, gi, real, true, gw[r].x); f(e + 1, gi + 1, real, true, gw[r].y); f(e + 2, gi + 2, real, true, gw[r].z); f(e + 3, gi + 3, real, true, gw[r].w);
-                    }
-                }
+                for (int r = 0; r < R1; ++r)
+                    if (r < (teamA ? R1 : R2)) f4(e_row0 + r * e_stride, gi_row0 + (int64_t)r * e_stride, r < nrow, gw[r]);
             }
+        };
+        auto for_scalars = [&](auto&& f) {
             if (tid < H2) {
 #pragma unroll
                 for (int ii = 0; ii < R1; ++ii) f(oW2c + ii * H2 + tid, prm->o_w2 + (int64_t)tid * H1 + i0 + ii, ii < n1, false, gwc[ii]);
@@ -654,7 +658,8 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
         // raw gradients of the last step -> d_grads (what the step-by-step path leaves there)
         if (last_step && prm->Gout) {
             float* Gout = prm->Gout;
-            for_owned([&](int, int64_t gi, bool real, bool primary, float& gval) { if (real && primary) Gout[gi] = gval; });
+            for_rows([&](int, int64_t gi, bool real, float4& g4) { if (real) *reinterpret_cast<float4*>(Gout + gi) = g4; });
+            for_scalars([&](int, int64_t gi, bool real, bool primary, float& gval) { if (real && primary) Gout[gi] = gval; });
         }
         // EWC term and the partial sums of |g_tot|^2 and F (p - p*)^2 over the PRIMARY elements
         float sg = 0.f, se = 0.f;
@@ -662,15 +667,27 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
             const unsigned nparam_bytes = (unsigned)((prm->o_b3 + C) * sizeof(float));
             const __amdgpu_buffer_rsrc_t rold = make_rsrc(prm->Old, nparam_bytes);
             const __amdgpu_buffer_rsrc_t rfis = make_rsrc(prm->F, nparam_bytes);
-            for_owned([&](int e, int64_t gi, bool real, bool primary, float& gval) {
+            for_rows([&](int e, int64_t gi, bool real, float4& g4) {
                 const unsigned o = real ? (unsigned)gi * 4u : 0xffffff00u;            // (slots without a parameter read zeros)
+                const float4 pv = *reinterpret_cast<const float4*>(Ps + e), ov = ld4_buf(rold, o), fv = ld4_buf(rfis, o);
+                const float d0 = pv.x - ov.x, d1 = pv.y - ov.y, d2 = pv.z - ov.z, d3 = pv.w - ov.w;
+                const float f0 = fv.x * d0, f1 = fv.y * d1, f2 = fv.z * d2, f3 = fv.w * d3;
+                se = fmaf(f0, d0, se); se = fmaf(f1, d1, se); se = fmaf(f2, d2, se); se = fmaf(f3, d3, se);
+                g4.x = fmaf(sc.two_lam, f0, g4.x); g4.y = fmaf(sc.two_lam, f1, g4.y);
+                g4.z = fmaf(sc.two_lam, f2, g4.z); g4.w = fmaf(sc.two_lam, f3, g4.w);
+            });
+            for_scalars([&](int e, int64_t gi, bool real, bool primary, float& gval) {
+                const unsigned o = real ? (unsigned)gi * 4u : 0xffffff00u;
                 const float dlt = Ps[e] - __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rold, o, 0, 0));
                 const float fd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rfis, o, 0, 0)) * dlt;
                 if (primary) se = fmaf(fd, dlt, se);
                 gval = fmaf(sc.two_lam, fd, gval);
             });
         }
-        for_owned([&](int, int64_t, bool, bool primary, float& gval) { if (primary) sg = fmaf(gval, gval, sg); });
+        for_rows([&](int, int64_t, bool, float4& g4) {
+            sg = fmaf(g4.x, g4.x, sg); sg = fmaf(g4.y, g4.y, sg); sg = fmaf(g4.z, g4.z, sg); sg = fmaf(g4.w, g4.w, sg);
+        });
+        for_scalars([&](int, int64_t, bool, bool primary, float& gval) { if (primary) sg = fmaf(gval, gval, sg); });
         block_sum8x2(sg, se, red);
         if (tid == 0) { st_sc1(prm->partials + g, sg); st_sc1(prm->partials + kMaxG + g, se); }
         stamp(12);
@@ -692,7 +709,14 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
         }
         {
             const float beta2 = prm->beta2, eps = prm->eps;
-            for_owned([&](int e, int64_t, bool, bool, float& gval) { adamw_elem(Ps, Ms, Vs, e, gval, coef, sc, beta2, eps); });
+            for_rows([&](int e, int64_t, bool, float4& g4) {
+                float4 pv = *reinterpret_cast<const float4*>(Ps + e), mv = *reinterpret_cast<const float4*>(Ms + e),
+                       vv = *reinterpret_cast<const float4*>(Vs + e);
+                adamw_vals(pv.x, mv.x, vv.x, g4.x, coef, sc, beta2, eps); adamw_vals(pv.y, mv.y, vv.y, g4.y, coef, sc, beta2, eps);
+                adamw_vals(pv.z, mv.z, vv.z, g4.z, coef, sc, beta2, eps); adamw_vals(pv.w, mv.w, vv.w, g4.w, coef, sc, beta2, eps);
+                *reinterpret_cast<float4*>(Ps + e) = pv; *reinterpret_cast<float4*>(Ms + e) = mv; *reinterpret_cast<float4*>(Vs + e) = vv;
+            });
+            for_scalars([&](int e, int64_t, bool, bool, float& gval) { adamw_elem(Ps, Ms, Vs, e, gval, coef, sc, beta2, eps); });
         }
         if (sm_e >= oW3) st_sc1(prm->P + sm_gi, Ps[sm_e]);        // W3 / b3 travel: every workgroup reads them in P3
         stamp(14);
@@ -744,7 +768,8 @@ int head_epoch_persistent(const ac_head_dims& d, float* P, float* M, float* V, f
     if (G < 8) return 1;
     const int r1 = (d.H1 + G - 1) / G, r2 = (d.H2 + G - 1) / G;
     if (batch > kMaxB || d.C > kMaxC || r1 > kR1 || r2 > kR2 || d.D > kT * kKU || d.H1 > kT * kKU || d.H2 > kT - 128) return 1;
-    if ((d.D & 3) || (d.H1 & 3) || (d.H2 & 3) || (ldx & 3) || (((uintptr_t)X) & 15) || (((uintptr_t)P) & 7)) return 1;
+    if ((d.D & 3) || (d.H1 & 3) || (d.H2 & 3) || (ldx & 3) || (((uintptr_t)X) & 15) || (((uintptr_t)P) & 15) ||
+        (((uintptr_t)Gout) & 15) || (((uintptr_t)F) & 15) || (((uintptr_t)Old) & 15)) return 1;
     const int64_t o_w1 = 0, o_b1 = o_w1 + (int64_t)d.H1 * d.D, o_w2 = o_b1 + d.H1, o_b2 = o_w2 + (int64_t)d.H2 * d.H1, o_w3 = o_b2 + d.H2,
                   o_b3 = o_w3 + (int64_t)d.C * d.H2;
     if (o_w3 & 3) return 1;
