@@ -58,6 +58,8 @@ struct Shape {
     static __device__ __forceinline__ int acc_row(int r, int lane) { return 4 * (lane >> 4) + r; }
 };
 
+__device__ __attribute__((aligned(16))) float g_knn_zeros[64];     // zero-initialised; tail-group loads of the sweep read it
+
 struct SweepParams {
     const float* P;
     int64_t N;
@@ -77,6 +79,8 @@ struct SweepParams {
     int32_t* part_i;  // [nqt*TQ][G][kp]
     float* part_maxnorm;  // [G * nqt]
     const float* zeros;   // >= 16 B of zeros, 16-byte aligned (tail-group loads)
+    int32_t* clear_ctr;   // [64] the merge / fallback kernels' slot counter and ...
+    int32_t* clear_stats; // [4] the caller's d_stats (or NULL): zeroed by workgroup 0 here instead of by two memset launches
 };
 
 // monotone map float -> uint32 (ascending float order == ascending unsigned order)
@@ -161,6 +165,10 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
     const int v = xcd_remap(blockIdx.x, nblk);
     const int qt = v % prm.nqt;
     const int g = v / prm.nqt;
+    if (blockIdx.x == 0 && tid < 64) {          // consumed by the kernels launched after this one
+        prm.clear_ctr[tid] = 0;
+        if (tid < 4 && prm.clear_stats) prm.clear_stats[tid] = 0;
+    }
 
     // ---- LDS carve-up (all offsets multiples of 16) ----
     const int nslots = J * prm.ng * kGroup * 64;      // float4 slots of the query tile
@@ -374,6 +382,15 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
 // --------------------------------------------------------------------------------------
 // merge + exact re-rank + certificate.  One block (256 threads) per query.
 // --------------------------------------------------------------------------------------
+const float* zeros_device() {                 // (the symbol has one address per device)
+    static const float* cache[64] = {nullptr};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!cache[dev]) { void* q = nullptr; (void)hipGetSymbolAddress(&q, HIP_SYMBOL(g_knn_zeros)); cache[dev] = (const float*)q; }
+    return cache[dev];
+}
+
 struct MergeParams {
     const float* P;
     int64_t N;
@@ -1013,7 +1030,7 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
         AC_REQUIRE((((uintptr_t)d_P) & 15) == 0, AC_EINVAL, "knn: d_P must be 16-byte aligned");
     }
     char* ws = (char*)d_ws;
-    if (d_stats) AC_HIP_CHECK(hipMemsetAsync(d_stats, 0, 4 * sizeof(int32_t), stream));
+    if (d_stats && (pl.small || N == 0)) AC_HIP_CHECK(hipMemsetAsync(d_stats, 0, 4 * sizeof(int32_t), stream));
     if (pl.small) {
         MergeParams sp;
         memset(&sp, 0, sizeof(sp));
@@ -1042,7 +1059,7 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
     mp.fb_d = (double*)(ws + pl.off_fb_d);
     mp.fb_i = (int32_t*)(ws + pl.off_fb_i);
     mp.fb_slotctr = (int32_t*)(ws + pl.off_fb_ctr);
-    AC_HIP_CHECK(hipMemsetAsync(ws + pl.off_fb_ctr, 0, 256, stream));
+    if (N == 0) AC_HIP_CHECK(hipMemsetAsync(ws + pl.off_fb_ctr, 0, 256, stream));      // (otherwise the sweep's workgroup 0 clears it)
 
     if (N == 0) {
         // empty shard: everything is padding; reuse the merge kernel with all-padding partials
@@ -1056,8 +1073,9 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
         sp.part_d = (float*)(ws + pl.off_part_d);
         sp.part_i = (int32_t*)(ws + pl.off_part_i);
         sp.part_maxnorm = (float*)(ws + pl.off_maxnorm);
-        sp.zeros = (const float*)(ws + pl.off_zeros);
-        AC_HIP_CHECK(hipMemsetAsync(ws + pl.off_zeros, 0, 256, stream));
+        sp.zeros = zeros_device();                    // a zero-initialised __device__ array: no memset launch per call
+        sp.clear_ctr = (int32_t*)(ws + pl.off_fb_ctr);
+        sp.clear_stats = d_stats;
         const int nblk = pl.G * pl.nqt;
         if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
         if (pl.TQ == 32) {
