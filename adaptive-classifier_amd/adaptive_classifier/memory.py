@@ -19,6 +19,7 @@ int32 row->class map behind the same search API (N >> #classes, BASELINE configs
 """
 import ctypes
 import logging
+import operator
 import threading
 from collections import defaultdict
 from typing import Any, Dict, List, Optional, Tuple
@@ -31,6 +32,9 @@ from .index import HipFlatL2Index, proto_scores
 from .models import Example, ModelConfig
 
 logger = logging.getLogger(__name__)
+
+
+_EMBEDDING_OF = operator.attrgetter("embedding")
 
 
 class PrototypeMemory:
@@ -67,7 +71,8 @@ class PrototypeMemory:
     # embedding tensors in the same order (identity fingerprint), not merely the same NUMBER of entries.
     @staticmethod
     def _fingerprint(exs, n):
-        return hash(tuple(id(e.embedding) for e in exs[:n]))
+        # (C-level loops: this runs a few times per class and call over up to max_examples_per_class entries)
+        return hash(tuple(map(id, map(_EMBEDDING_OF, exs if n == len(exs) else exs[:n]))))
 
     def _stamp(self, label):
         exs = self.examples[label]
@@ -78,7 +83,7 @@ class PrototypeMemory:
         fp = self._fps.get(label)
         return fp is not None and fp[0] == n and fp[1] == self._fingerprint(self.examples[label], n)
 
-    def device_class_matrix(self, label, dev, room=0):
+    def device_class_matrix(self, label, dev, room=0, fp=None):
         """[rows >= n + room, D] fp32 matrix on `dev` whose first n = len(examples[label]) rows are the class's stored
         embeddings in list order.  Kept in step by add_examples_batch (appends / device prune write it in place); rebuilt
         from the list whenever the list was edited from outside (identity fingerprint)."""
@@ -86,7 +91,8 @@ class PrototypeMemory:
         n = len(exs)
         dev = torch.device(dev)
         ent = self._dmats.get(label)
-        fp = self._fingerprint(exs, n)
+        if fp is None:                      # (callers that just computed the list's fingerprint pass it in)
+            fp = self._fingerprint(exs, n)
         if ent is None or ent[0].device != dev or ent[1] != n or ent[2] != fp:
             d = torch.empty((max(n + room, 64), self.embedding_dim), dtype=torch.float32, device=dev)
             if n:
@@ -193,8 +199,9 @@ class PrototypeMemory:
                 fresh = torch.stack([e.embedding.detach().to(torch.float32) for e in new])
                 if dev is not None and dev.type == "cuda":
                     # device-resident class matrix: only the k new rows cross PCIe
-                    trusted = self._mirror_valid(label, n0)
-                    dm = self.device_class_matrix(label, dev, room=k)
+                    fp0 = self._fingerprint(lst, n0)        # one identity pass over the stored list per class and call
+                    trusted = self._fps.get(label) == (n0, fp0)
+                    dm = self.device_class_matrix(label, dev, room=k, fp=fp0)
                     cached = self._sums.get(label)
                     total = (cached[0] if cached is not None and cached[1] == n0 and trusted
                              else dm[0][:n0].double().sum(0).cpu())
@@ -205,7 +212,7 @@ class PrototypeMemory:
                         self._sums[label] = (total + fresh.double().sum(0), n0 + k)
                         self._stamp(label)
                         dm[1], dm[2] = n0 + k, self._fps[label][1]
-                        self._update_prototype(label)
+                        self._update_prototype(label, trusted=True)
                     else:
                         jobs.append((label, lst, new, dm, None, total, n0, k))
                     continue
@@ -298,7 +305,7 @@ class PrototypeMemory:
             self._sums[label] = (sums[i].clone(), n)
             self._stamp(label)
             dm[1], dm[2] = n, self._fps[label][1]
-            self._update_prototype(label)
+            self._update_prototype(label, trusted=True)
 
     def _add_one_no_counters(self, example: Example, label: str):
         """add_example minus the rebuild counters (used by add_examples_batch's host fallback)."""
@@ -316,12 +323,13 @@ class PrototypeMemory:
             self._prune_examples(label)
         self._update_prototype(label)
 
-    def _update_prototype(self, label: str):
+    def _update_prototype(self, label: str, trusted: bool = False):
+        """trusted: the caller stamped the list a moment ago (same critical section): skip the identity pass."""
         examples = self.examples[label]
         if not examples:
             return
         cached = self._sums.get(label)
-        if cached is None or cached[1] != len(examples) or not self._mirror_valid(label, len(examples)):
+        if cached is None or cached[1] != len(examples) or not (trusted or self._mirror_valid(label, len(examples))):
             # the list was assigned / edited by the caller: recompute from the list, as the reference always does
             mat = torch.stack([ex.embedding.detach().to(torch.float32) for ex in examples])
             cached = (mat.double().sum(0), len(examples))

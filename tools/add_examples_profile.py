@@ -1,6 +1,6 @@
 """Scratch: cProfile of the continuous-learning loop (host side)."""
 import sys, os, cProfile, pstats, io
-sys.argv = [sys.argv[0], "3000"]
+sys.argv = [sys.argv[0], "8000"]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pr = cProfile.Profile()
 pr.enable()
