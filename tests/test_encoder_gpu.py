@@ -60,6 +60,29 @@ def test_small_batch_one_launch_path_matches_transformers(hidden, layers, heads,
     assert (got - big).abs().max().item() < 2e-5
 
 
+def test_small_batch_path_without_types_and_mask_and_switch(cuda_dev):
+    """ids only (type ids = zeros, mask = ones) through the one-launch path; ac_set_persistent_kernels switches it off / on and
+    reports the previous mask."""
+    from adaptive_classifier import _native as nv
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_bert(768, 2, 12, 3072, vocab=3000, seed=2)
+    ids, types, mask = bert_oracle.synthetic_batch(2, 13, vocab=3000, seed=9, ragged=False)
+    want = bert_oracle.encode_cls(model, ids, torch.zeros_like(ids), torch.ones_like(ids))
+    enc = HipBertEncoder(model, device=cuda_dev)
+    got = enc.encode_cls(ids).cpu()
+    assert (got - want).abs().max().item() < 1e-4
+    prev = nv.lib().ac_set_persistent_kernels(-1)
+    assert prev & 2
+    try:
+        assert nv.lib().ac_set_persistent_kernels(prev & ~2) == prev
+        layered = enc.encode_cls(ids).cpu()
+        assert nv.lib().ac_set_persistent_kernels(-1) == prev & ~2
+    finally:
+        nv.lib().ac_set_persistent_kernels(prev)
+    assert (got - layered).abs().max().item() < 2e-5 and (layered - want).abs().max().item() < 1e-4
+
+
 def test_encoder_no_mask_and_large_batch(cuda_dev):
     from adaptive_classifier.encoder import HipBertEncoder
     from oracle import bert_oracle
