@@ -434,19 +434,35 @@ template <typename KeyFn, typename ActiveFn>
 __device__ __forceinline__ uint32_t block_radix_select(int n, int want, KeyFn key_of, ActiveFn active,
                                                        int* hist, int* bcast, int* rank_in_ties, int* n_ties) {
     const int tid = threadIdx.x;
+    __shared__ int wave_tot[kMergeThreads / 64];
     uint32_t prefix = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
         hist[tid] = 0;                       // kMergeThreads == 256 bins
         __syncthreads();
         const uint32_t himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+        // distances of one query's candidates share their leading bits, so in the first rounds nearly every key lands in
+        // the same bin: run-length aggregation per thread (one LDS atomic per run instead of one per key)
+        int run_bin = -1, run_cnt = 0;
         for (int t = tid; t < n; t += kMergeThreads) {
             if (!active(t)) continue;
             const uint32_t key = key_of(t);
-            if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255u], 1);
+            if ((key & himask) != (prefix & himask)) continue;
+            const int bin = (int)((key >> shift) & 255u);
+            if (bin == run_bin) { ++run_cnt; continue; }
+            if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
+            run_bin = bin; run_cnt = 1;
         }
+        if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
         __syncthreads();
-        int c = 0;                            // exclusive prefix of bin `tid`
-        for (int bb = 0; bb < tid; ++bb) c += hist[bb];
+        // exclusive prefix of bin `tid`: wave scan + the totals of the waves below (kMergeThreads == 256 = 4 waves)
+        const int mine_cnt = hist[tid];
+        int c = mine_cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(c, o); if ((tid & 63) >= o) c += v; }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = c;
+        __syncthreads();
+        for (int w = 0; w < (tid >> 6); ++w) c += wave_tot[w];
+        c -= mine_cnt;
         const int mine = hist[tid];
         if (c < want && want <= c + mine) { bcast[0] = tid; bcast[1] = want - c; bcast[2] = mine; }
         __syncthreads();
