@@ -504,7 +504,8 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
     const float* pd = prm.part_d + (size_t)q * n;
     const int32_t* pi = prm.part_i + (size_t)q * n;
     int nreal_local = 0;
-    for (int t = tid; t < n; t += kMergeThreads) {
+#pragma unroll 8
+    for (int t = tid; t < n; t += kMergeThreads) {          // (unrolled: the loads of several candidates in flight)
         const bool real = t < nfill && pi[t] >= 0;
         keys[t] = real ? fkey(pd[t]) : 0xffffffffu;
         nreal_local += real ? 1 : 0;
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
         const int32_t id = (int32_t)(uint32_t)(sel[s] & 0xffffffffull);
         const f32x4* prow = reinterpret_cast<const f32x4*>(prm.P + (size_t)id * prm.ldP);
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 4
         for (int c4 = lane; c4 < nc4; c4 += 64) {
             const f32x4 p = prow[c4];
             const f32x4 qq = *reinterpret_cast<const f32x4*>(qrow + 4 * c4);
@@ -601,11 +603,19 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
     __syncthreads();
 
     // ---- certificate ----
+    // largest row norm seen by the sweep: the per-block maxima reduced by the whole workgroup (a one-thread loop over up to
+    // 512 global loads was most of this kernel's time for a single query)
+    float mx_all = 0.f;
+    for (int b = tid; b < prm.nblk; b += kMergeThreads) mx_all = fmaxf(mx_all, prm.part_maxnorm[b]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx_all = fmaxf(mx_all, __shfl_xor(mx_all, o));
+    if (lane == 0) hist[wave] = (int)__float_as_uint(mx_all);           // (norms are non-negative: their bits order like the values)
+    __syncthreads();
     if (tid == 0) {
         int ok = 1;
         if (prm.N > (int64_t)kp) {
             float mx = 0.f;
-            for (int b = 0; b < prm.nblk; ++b) mx = fmaxf(mx, prm.part_maxnorm[b]);
+            for (int w = 0; w < kMergeThreads / 64; ++w) mx = fmaxf(mx, __uint_as_float((uint32_t)hist[w]));
             const double qn2 = dmisc[0];
             const double pn = sqrt((double)mx * 1.001), qn = sqrt(qn2);
             // fp32 fma-chain roundoff of |p|^2 - 2 q.p: every term passes through at most
