@@ -1,7 +1,7 @@
 // Small-batch BERT forward in ONE persistent launch (single-query predict(): classifier.py:1249-1282 with one short text).
 // With <= 32 token rows every kernel of the layer-by-layer path is a few microseconds of work behind ~10 us of launch
-// and dependency latency (86 launches, 1.0 ms); here the 12 layers run as phases of one cooperative kernel separated by
-// fence-free grid barriers (1.6 us each), activations exchanged with sc1 (agent-coherent) stores / loads:
+// and dependency latency (86 launches, 1.0 ms); here the 12 layers run as phases of one kernel of 192 co-resident
+// workgroups separated by fence-free grid barriers (1.7 us each), activations exchanged with sc1 (agent-coherent) stores / loads:
 //
 //   P0  embeddings: row t = word[id] + type[tt] + pos[p]                      (pre-LayerNorm) -> y0           | barrier
 //   per layer:
@@ -12,12 +12,13 @@
 //   PE  y0 = ffn W2^T + b + x1                                                                                  | barrier
 //   end x = LN(y0)[CLS rows], L2-normalised                                                       -> out
 //
-// GEMM phases: strict fp32 on v_mfma_f32_16x16x4_f32.  A workgroup owns one or two groups of 16 output columns; its
+// GEMM phases: strict fp32 on v_mfma_f32_16x16x4_f32.  A workgroup owns one group of 16 output columns (FFN2: one group
+// and a quarter / half of K, the parts added up by the consumers while they load them); its
 // eight waves split K; lane (m, kk) = (lane & 15, lane >> 4) holds float4 A[m][k0 + 4 kk ..] and float4 W[n0 + m][k0 + 4 kk ..]
 // -- four MFMA k-steps per load pair, 64-byte runs per row for both operands; the eight partial 32 x 16 tiles meet in
 // LDS, where bias / GELU / residual are applied.  The LayerNorm in front of PA / PD is computed by every consumer from
-// the fragments it already holds (two-pass statistics as ln_kernel); rows 0 .. T-1 of the normalised activations are
-// written out by workgroups 0 .. T-1 for the residual connections.
+// the fragments it already holds (two-pass statistics as ln_kernel); the rows of the normalised activations are written
+// out by the phase's workgroups (row r by workgroup r mod nactive) for the residual connections.
 #include "common.h"
 #include "grid_sync.h"
 

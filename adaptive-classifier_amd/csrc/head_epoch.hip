@@ -15,9 +15,9 @@
 //     P3  every workgroup: logits, loss, dz (B x C, redundantly), d2 = (dz W3) gated, in LDS
 //     P4  gradients of everything it owns (registers), EWC term, partial sums of |g|^2              | B3
 //     P5  clip coefficient from the G partials (fixed order), AdamW on the owned elements in LDS, W3 / b3 to global
-//   Exchanged data uses agent-scope relaxed atomics (sc1: coherent across the 8 XCD L2s), so the barriers need no
-//   L2 write-back / invalidate: 2.5 us per barrier instead of 7.8 us with release/acquire fences
-//   (tools/gridbar_probe.hip).  X, labels, Fisher and the EWC anchor are read-only for the launch: plain loads.
+//   Exchanged data travels as sc1 stores / loads (agent scope: coherent across the 8 XCD L2s), so the barriers need no
+//   L2 write-back / invalidate: 1.8 us per barrier (eight counters polled by eight lanes) instead of 7.8 us with
+//   release/acquire fences (tools/gridbar_probe.hip, grid_sync.h).  X, labels, Fisher and the EWC anchor are read-only for the launch: plain loads.
 //
 // Same arithmetic contract as the step-by-step path in head.hip (fp32, formulas of ewc_adamw_kernel and
 // head_top_kernel); summation orders differ (fma chains over the batch / wave-strided dot products instead of MFMA
