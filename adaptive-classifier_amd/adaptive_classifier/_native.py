@@ -23,6 +23,9 @@ class NativeError(RuntimeError):
     pass
 
 
+AC_BERT_LAYERED = 1     # include/acamd.h: ac_bert_encode_cls_opts never takes the one-launch path
+
+
 def build(force=False):
     """Compile csrc/*.hip for gfx950 into libacamd.so (hipcc cross-compiles without a GPU)."""
     if force:
@@ -151,6 +154,11 @@ _SIGNATURES = {
     "ac_bert_encode_cls_packed": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p, c_void_p,
                                           c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
                                           c_void_p]),
+    "ac_bert_encode_cls_opts": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p,
+                                        c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t, c_int,
+                                        ctypes.POINTER(c_int), c_void_p]),
+    "ac_bert_one_launch_status": (c_int, [ctypes.POINTER(ac_bert_config), c_int, c_int, c_void_p, c_size_t,
+                                          ctypes.POINTER(c_int), c_void_p]),
     "ac_bert_encode_cls": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
                                    c_void_p]),

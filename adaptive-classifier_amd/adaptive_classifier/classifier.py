@@ -92,10 +92,16 @@ class AdaptiveClassifier:
         return self.tokenizer(texts, max_length=self.config.max_length, truncation=True, padding=True,
                               return_tensors="pt")
 
-    def _embed_device(self, texts: List[str]) -> torch.Tensor:
-        """[b, D] unit-norm CLS embeddings on the device (classifier.py:1259-1275 without the D2H)."""
+    def _embed_device(self, texts: List[str], verify_small: bool = True, force_layered: bool = False) -> torch.Tensor:
+        """[b, D] unit-norm CLS embeddings on the device (classifier.py:1259-1275 without the D2H).
+        verify_small / force_layered: see HipBertEncoder.encode_cls -- by default a one-launch forward whose grid barrier
+        gave up (NaN rows) is detected and repeated here, for every caller."""
         inputs = self._tokenize(texts)
-        return self.model.encode_cls(inputs["input_ids"], inputs.get("token_type_ids"), inputs.get("attention_mask"))
+        try:
+            return self.model.encode_cls(inputs["input_ids"], inputs.get("token_type_ids"), inputs.get("attention_mask"),
+                                         verify_small=verify_small, force_layered=force_layered)
+        except TypeError:            # an encoder object without the options (user-supplied)
+            return self.model.encode_cls(inputs["input_ids"], inputs.get("token_type_ids"), inputs.get("attention_mask"))
 
     def _get_embeddings(self, texts: List[str]) -> List[torch.Tensor]:
         """Reference signature: list of CPU [D] tensors (classifier.py:1282)."""
@@ -220,26 +226,23 @@ class AdaptiveClassifier:
             Xe = X.index_select(0, order)
             ye = None if y is None else y.index_select(0, order)
             te = None if targets is None else targets.index_select(0, order)
-            def run_epoch():
+            def run_epoch(stepwise=False):
                 return trainer.fused_epoch(Xe, ye, None, nb0, AdaptiveHead.DROPOUT_P, base_seed + steps,
                                            fisher=None if ewc is None else ewc.fisher_flat,
                                            old_params=None if ewc is None else ewc.old_flat,
                                            lambda_B=0.0 if ewc is None else lambda_B, loss_kind=loss_kind,
-                                           targets_all=te)
+                                           targets_all=te, stepwise=stepwise)
             done = run_epoch()
             avg_loss = float(trainer.loss_accum.item()) / steps_per_epoch    # the only host sync of the epoch
             if avg_loss != avg_loss and (nv.lib().ac_set_persistent_kernels(-1) & 1):
                 # a NaN epoch loss with the persistent kernel on: either the run diverged or a grid barrier gave up (device
-                # shared with another process).  Put the parameters back and repeat the epoch launch by launch, once.
+                # shared with another process).  Put parameters and moments back and repeat the epoch launch by launch, once
+                # (per-call flag: no process-wide switch is touched).
                 logger.warning("training epoch returned NaN through the persistent kernel; repeating it with the step-by-step launches")
                 trainer.restore_epoch()
                 trainer.loss_accum.zero_()
-                prev = nv.lib().ac_set_persistent_kernels(nv.lib().ac_set_persistent_kernels(-1) & ~1)
-                try:
-                    done = run_epoch()
-                    avg_loss = float(trainer.loss_accum.item()) / steps_per_epoch
-                finally:
-                    nv.lib().ac_set_persistent_kernels(prev)
+                done = run_epoch(stepwise=True)
+                avg_loss = float(trainer.loss_accum.item()) / steps_per_epoch
             steps += done
             if sched is not None:
                 sched.step(avg_loss)
@@ -446,21 +449,19 @@ class AdaptiveClassifier:
         history-keyed weights (0.3/0.7 vs 0.7/0.3), stable sort, normalise, top-k.
         (Replaying this ~90-kernel single-query chain as one captured HIP graph was measured and dropped: 1.013 vs
         1.014 ms -- the chain is paced by the GPU's dependent-dispatch interval, not by host enqueue)"""
-        def run():
-            emb = self._embed_device([text])
+        def run(force_layered=False):
+            # the result comes to the host anyway: skip the encoder's own verdict read-back (a stream sync in the middle of
+            # the chain) and look at the scores instead
+            emb = self._embed_device([text], verify_small=False, force_layered=force_layered)
             max_classes = len(self.id_to_label) if self.id_to_label else k
             S, I, P = self._device_stage(emb, max_classes)
             return self._finish(S, I, P, k, regular=True, b=1)[0]
         res = run()
-        if any(s != s for _, s in res) and (nv.lib().ac_set_persistent_kernels(-1) & 2):
-            # NaN scores with the one-launch encoder on: one of its grid barriers gave up (device shared with another compute
+        if any(s != s for _, s in res) and getattr(self.model, "last_one_launch", False):
+            # NaN scores after the one-launch encoder: one of its grid barriers gave up (a device shared with another compute
             # process poisons the embedding with NaNs rather than hanging).  Repeat through the layer-by-layer kernels.
             logger.warning("single-query encoder returned NaN through the persistent kernel; repeating layer by layer")
-            prev = nv.lib().ac_set_persistent_kernels(nv.lib().ac_set_persistent_kernels(-1) & ~2)
-            try:
-                res = run()
-            finally:
-                nv.lib().ac_set_persistent_kernels(prev)
+            res = run(force_layered=True)
         return res
 
     def predict_batch(self, texts: List[str], k: int = 5, batch_size: int = 32) -> List[List[Tuple[str, float]]]:

@@ -40,6 +40,7 @@ class HipBertEncoder:
         nv.require_gpu()
         self.unpad = bool(unpad)
         self.last_tokens = 0                  # token rows the last encode_cls call actually ran (roofline accounting)
+        self.last_one_launch = False          # the last native call ran as the one persistent launch (bert_small.hip)
         cfg = hf_bert.config
         mtype = getattr(cfg, "model_type", "bert")
         if mtype not in ("bert", "distilbert"):
@@ -139,8 +140,15 @@ class HipBertEncoder:
         nv.check(nv.lib().ac_bert_workspace(ctypes.byref(self.ccfg), b, S, ctypes.byref(need)), "ac_bert_workspace")
         return need.value
 
-    def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None):
-        """int64 [b, S] ids (+ optional type ids / mask) -> unit-norm CLS embeddings [b, H] on device."""
+    def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None, verify_small=True,
+                   force_layered=False):
+        """int64 [b, S] ids (+ optional type ids / mask) -> unit-norm CLS embeddings [b, H] on device.
+
+        <= 32 token rows run as ONE persistent launch (bert_small.hip), launched without the cooperative residency check;
+        on a device shared with another compute process one of its grid barriers can give up, and the rows are then NaN.
+        verify_small=True (default) reads that verdict after such a launch (a 4-byte D2H, i.e. a stream sync) and repeats
+        the call layer by layer -- every caller gets finite embeddings.  Latency-critical callers that look at their final
+        result anyway pass verify_small=False and, on NaN, call again with force_layered=True (classifier._predict_regular)."""
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         b, S = ids.shape
         if not self._has_types:
@@ -176,11 +184,26 @@ class HipBertEncoder:
                             nv.stream_ptr(self.device)), "ac_bert_encode_cls_packed")
                         self.last_tokens += total
                         continue
-                nv.check(nv.lib().ac_bert_encode_cls(
-                    ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
-                    nv.ptr(None if tt is None else tt[r0:r1]), nv.ptr(None if mk is None else mk[r0:r1]), nb, S,
-                    nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
-                    "ac_bert_encode_cls")
+                used = ctypes.c_int(0)
+
+                def call(opts):
+                    nv.check(nv.lib().ac_bert_encode_cls_opts(
+                        ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
+                        nv.ptr(None if tt is None else tt[r0:r1]), nv.ptr(None if mk is None else mk[r0:r1]), nb, S,
+                        nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(), opts, ctypes.byref(used),
+                        nv.stream_ptr(self.device)), "ac_bert_encode_cls_opts")
+                call(nv.AC_BERT_LAYERED if force_layered else 0)
+                self.last_one_launch = bool(used.value)
+                if used.value and verify_small:
+                    aborted = ctypes.c_int(0)
+                    nv.check(nv.lib().ac_bert_one_launch_status(ctypes.byref(self.ccfg), nb, S, nv.ptr(self._ws),
+                                                                self._ws.numel(), ctypes.byref(aborted),
+                                                                nv.stream_ptr(self.device)), "ac_bert_one_launch_status")
+                    if aborted.value:
+                        import logging
+                        logging.getLogger(__name__).warning(
+                            "one-launch encoder: a grid barrier gave up (device shared?); repeating layer by layer")
+                        call(nv.AC_BERT_LAYERED)
                 self.last_tokens += nb * S
         return out
 
@@ -328,8 +351,9 @@ class HipModernBertEncoder:
                  "ac_modernbert_workspace")
         return need.value
 
-    def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None):
-        """int64 [b, S] ids (+ optional mask; token types do not exist in ModernBERT) -> unit-norm CLS [b, H]."""
+    def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None, verify_small=True, force_layered=False):
+        """int64 [b, S] ids (+ optional mask; token types do not exist in ModernBERT) -> unit-norm CLS [b, H].
+        (verify_small / force_layered: interface parity with HipBertEncoder; this encoder has no one-launch path.)"""
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         b, S = ids.shape
         mk = None if attention_mask is None else attention_mask.to(device=self.device, dtype=torch.int64).contiguous()

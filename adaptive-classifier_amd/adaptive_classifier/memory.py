@@ -54,6 +54,8 @@ class PrototypeMemory:
         self._sums = {}                      # label -> (fp64 running sum of the stored embeddings, count)
         self._mats = {}                      # label -> [host matrix of the stored embeddings, count]
         self._fps = {}                       # label -> (count, identity fingerprint) the two caches above describe
+        self._fp_refs = {}                   # label -> the fingerprinted embedding tensors (strong references: ids stay unique)
+        self._dm_refs = {}
         self._dmats = {}                     # label -> [DEVICE matrix of the stored embeddings, count, fingerprint]: input of the
                                              # device prune and of the training-set assembly (no per-call re-upload)
         self._dirty = set()                  # labels whose index row is out of date
@@ -77,6 +79,9 @@ class PrototypeMemory:
     def _stamp(self, label):
         exs = self.examples[label]
         self._fps[label] = (len(exs), self._fingerprint(exs, len(exs)))
+        # the fingerprint is made of object ids: hold the fingerprinted tensors so that CPython cannot hand one of their ids
+        # to a replacement embedding while the stamp is still trusted (A -> B -> C with C at A's address)
+        self._fp_refs[label] = tuple(map(_EMBEDDING_OF, exs))
 
     def _mirror_valid(self, label, n):
         """True iff the caches of `label` describe exactly examples[label][:n]."""
@@ -90,6 +95,8 @@ class PrototypeMemory:
         exs = self.examples[label]
         n = len(exs)
         dev = torch.device(dev)
+        if dev.type == "cuda" and dev.index is None:      # "cuda" names the current device; tensors carry "cuda:<index>"
+            dev = torch.device("cuda", torch.cuda.current_device())
         ent = self._dmats.get(label)
         if fp is None:                      # (callers that just computed the list's fingerprint pass it in)
             fp = self._fingerprint(exs, n)
@@ -98,6 +105,7 @@ class PrototypeMemory:
             if n:
                 d[:n] = torch.stack([e.embedding.detach().to(torch.float32) for e in exs]).to(dev)
             ent = [d, n, fp]
+            self._dm_refs[label] = tuple(map(_EMBEDDING_OF, exs))     # (same reason as _fp_refs)
         elif ent[0].shape[0] < n + room:
             d = torch.empty((max(n + room, 2 * ent[0].shape[0]), self.embedding_dim), dtype=torch.float32, device=dev)
             d[:n] = ent[0][:n]
@@ -212,6 +220,7 @@ class PrototypeMemory:
                         self._sums[label] = (total + fresh.double().sum(0), n0 + k)
                         self._stamp(label)
                         dm[1], dm[2] = n0 + k, self._fps[label][1]
+                        self._dm_refs[label] = self._fp_refs[label]
                         self._update_prototype(label, trusted=True)
                     else:
                         jobs.append((label, lst, new, dm, None, total, n0, k))
@@ -305,6 +314,7 @@ class PrototypeMemory:
             self._sums[label] = (sums[i].clone(), n)
             self._stamp(label)
             dm[1], dm[2] = n, self._fps[label][1]
+            self._dm_refs[label] = self._fp_refs[label]
             self._update_prototype(label, trusted=True)
 
     def _add_one_no_counters(self, example: Example, label: str):
@@ -458,12 +468,8 @@ class PrototypeMemory:
                 self._rebuild_index()
             self._flush_dirty()
             sharded = getattr(self, "_sharded", None)
-            if sharded is not None and sharded.world > 1:
-                b = queries.shape[0]
-                q_all = sharded.gather_queries(queries)
-                D, I = sharded.search(q_all, k)
-                r = sharded.rank
-                D, I = D[r * b:(r + 1) * b].contiguous(), I[r * b:(r + 1) * b].contiguous()
+            if sharded is not None and (sharded.world > 1 or sharded.force_collectives):
+                D, I = sharded.search_block(queries, k)       # this rank's queries against every rank's row shard
                 return proto_scores(D, I), I, D
             k = min(k, max(self.index.ntotal, 1))
             D, I = self.index.search_device(queries, k)
@@ -509,6 +515,8 @@ class PrototypeMemory:
             self._mats.clear()
             self._dmats.clear()
             self._fps.clear()
+            self._fp_refs.clear()
+            self._dm_refs.clear()
             self._dirty.clear()
             self.index = self._new_index()
             self.label_to_index.clear()
@@ -523,4 +531,6 @@ class PrototypeMemory:
         self._mats.pop(label, None)
         self._dmats.pop(label, None)
         self._fps.pop(label, None)
+        self._fp_refs.pop(label, None)
+        self._dm_refs.pop(label, None)
         self._dirty.discard(label)

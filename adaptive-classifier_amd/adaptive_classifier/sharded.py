@@ -4,13 +4,18 @@
               row_offset); the head and encoder weights are replicated; query batches are data parallel.
   exchange    1. all_gather the ranks' query blocks  [b/G, D] -> [b, D]        (RCCL over xGMI)
               2. local `ac_knn_l2_topk_x` of all b queries against the rank's shard
-              3. all_gather the per-shard (EXACT fp64 dist, id int64) [b, k] lists
-              4. `ac_topk_merge_f64` -> global top-k by (exact distance, id) on every rank, distances rounded to fp32
+              3. all_to_all of the per-shard (EXACT fp64 dist, id int64) lists: rank j receives, from every shard, the
+                 [b/G, k] candidates of ITS OWN query block (SURVEY 8e "alternative": 1/G of the bytes an all_gather of
+                 all [b, k] lists moves, and every rank merges b/G queries instead of all b)
+              4. `ac_topk_merge_f64` -> global top-k by (exact distance, id) of the rank's own queries, rounded to fp32
               (fp64 on the wire: two candidates on different shards whose exact distances differ but round to the same
               fp32 value must be ordered by distance, not by id, or the sharded result differs from the unsharded one --
               measured: ~40 of 131k neighbour pairs at 10M x 768, 4096 queries)
-The messages are tiny (cfg2: 2.1 MB per rank and step), i.e. latency bound; there is no other
-collective on the data path.  One process per GPU, torch.distributed backend "nccl" (= RCCL).
+              `search()` (every rank wants the result of ALL queries) keeps step 3 as an all_gather.
+The messages are small (cfg2 at G = 8: 2.1 MB of queries in, 0.26 MB of candidates per peer), i.e. latency bound; there
+is no other collective on the data path.  One process per GPU, torch.distributed backend "nccl" (= RCCL).
+No multi-GPU scaling curve has been measured by the builder (one GPU per gpurun box); the RCCL calls themselves are
+exercised on a world-size-1 nccl group (tests/test_sharded_gpu.py::test_rccl_branch_world1).
 
 The local search and the merge are injected so that the orchestration (offsets, gather layout,
 merge semantics) can be exercised with world_size-2 `gloo` groups on CPU in tests, where the
@@ -27,10 +32,23 @@ def shard_bounds(N, world, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def _pack(D, I):
+    """(fp64 distances [.., k], int64 ids [.., k]) -> one int64 tensor [.., 2k] (the exchanges are latency bound)"""
+    return torch.cat([D.contiguous().view(torch.int64), I], dim=-1)
+
+
+def _unpack(both):
+    k = both.shape[-1] // 2
+    return both[..., :k].contiguous().view(torch.float64), both[..., k:].contiguous()
+
+
 class ShardedSearch:
-    def __init__(self, local_rows, n_local, dim, row_offset, group=None, local_search=None, merge=None):
+    def __init__(self, local_rows, n_local, dim, row_offset, group=None, local_search=None, merge=None,
+                 force_collectives=False):
+        """force_collectives: run the collectives even on a one-rank group (tests: executes the RCCL calls on one GPU)."""
         self.rows, self.n_local, self.dim, self.row_offset = local_rows, n_local, dim, row_offset
         self.group = group
+        self.force_collectives = bool(force_collectives)
         self._prepared = None          # bf16 planes + norms of the local shard (batched searches), built on first use
         if local_search is None or merge is None:
             from . import index as ix
@@ -56,11 +74,18 @@ class ShardedSearch:
     def world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    @property
+    def _collective(self):
+        return self.world > 1 or (self.force_collectives and dist.is_initialized())
+
+    def _staged(self, t):
+        """device tensors under a non-RCCL backend (gloo: CPU tests, two processes on one GPU) travel through the host"""
+        return t.is_cuda and dist.get_backend(self.group) != "nccl"
+
     def _all_gather(self, t):
-        """all_gather along a new leading dim -> [world, ...].  RCCL gathers device tensors directly; the
-        gloo path (CPU tests, single-GPU dry runs) stages through the host."""
+        """all_gather along a new leading dim -> [world, ...].  RCCL gathers device tensors directly."""
         t = t.contiguous()
-        if t.is_cuda and dist.get_backend(self.group) != "nccl":
+        if self._staged(t):
             parts = [torch.empty_like(t, device="cpu") for _ in range(self.world)]
             dist.all_gather(parts, t.cpu(), group=self.group)
             return torch.stack(parts).to(t.device)
@@ -69,17 +94,44 @@ class ShardedSearch:
             dist.all_gather(list(out.unbind(0)), t, group=self.group)
         return out
 
+    def _all_to_all(self, t):
+        """t [world, m, ...]: block j goes to rank j; returns [world, m, ...] with block i = what rank i sent to this rank."""
+        t = t.contiguous()
+        if self._staged(t):
+            src = t.cpu()
+            out = torch.empty_like(src)
+            dist.all_to_all_single(out, src, group=self.group)
+            return out.to(t.device)
+        out = torch.empty_like(t)
+        dist.all_to_all_single(out, t, group=self.group)
+        return out
+
     def gather_queries(self, q_local):
         """Data-parallel query blocks -> the full [b, D] block on every rank (equal block sizes)."""
-        if self.world == 1:
+        if not self._collective:
             return q_local
         g = self._all_gather(q_local)
         return g.reshape(-1, q_local.shape[-1])
 
     def search(self, queries, k):
-        """queries [b, D] (identical on all ranks) -> global (dist fp32 [b,k], ids [b,k]) on every rank.
+        """queries [b, D] (identical on all ranks) -> global (dist fp32 [b,k], ids [b,k]) on EVERY rank.
         The local search returns EXACT fp64 distances; they are what travels and what the merge orders by."""
         D_loc, I_loc = self._search(self.rows, self.n_local, self.dim, queries, k, self.row_offset)
-        if self.world == 1:
+        if not self._collective:
             return D_loc.to(torch.float32), I_loc
-        return self._merge(self._all_gather(D_loc), self._all_gather(I_loc))
+        both = self._all_gather(_pack(D_loc, I_loc))            # ONE message per peer: fp64 bits and ids side by side
+        return self._merge(*_unpack(both))
+
+    def search_block(self, q_local, k):
+        """The data-parallel step: this rank's query block [b/G, D] (equal sizes on all ranks) -> the global
+        (dist fp32 [b/G, k], ids [b/G, k]) of THOSE queries.  all_gather(queries) -> local search of all b queries ->
+        all_to_all of the candidate lists -> this rank merges only its own block."""
+        if not self._collective:
+            D_loc, I_loc = self._search(self.rows, self.n_local, self.dim, q_local, k, self.row_offset)
+            return D_loc.to(torch.float32), I_loc
+        G, m = self.world, q_local.shape[0]
+        q_all = self.gather_queries(q_local)
+        D_loc, I_loc = self._search(self.rows, self.n_local, self.dim, q_all, k, self.row_offset)
+        both = _pack(D_loc, I_loc)                                 # [b, 2k] int64: one message per peer
+        both = self._all_to_all(both.reshape(G, m, both.shape[1]))   # -> [shard, own query, 2k]
+        return self._merge(*_unpack(both))

@@ -14,6 +14,7 @@ from . import _native as nv
 
 REDUCE_SCRATCH_BYTES = 8192
 LOSS_CE, LOSS_BCE_SIGMOID, LOSS_CE_SIGMOID = 0, 1, 2      # AC_LOSS_* of include/acamd.h
+LOSS_STEPWISE = 0x100                                     # AC_LOSS_STEPWISE: per-call opt-out of the persistent epoch kernel
 
 
 class HeadTrainer:
@@ -123,26 +124,27 @@ class HeadTrainer:
         return self.out3
 
     def fused_epoch(self, X_all, y_all, order, batch, dropout_p=0.1, seed0=0, fisher=None, old_params=None,
-                    lambda_B=0.0, loss_kind=LOSS_CE, targets_all=None):
+                    lambda_B=0.0, loss_kind=LOSS_CE, targets_all=None, stepwise=False):
         """One call = one epoch of fused steps over consecutive `batch`-row slices of `order`
         (`ac_head_train_epoch`): step i uses dropout seed seed0 + i; EWC weight lambda_B / rows_i.
         order=None: X_all / y_all / targets_all are already in epoch order (batches = consecutive row slices, no
-        per-step gather).  Returns the number of steps taken."""
+        per-step gather).  stepwise=True: this call uses the step-by-step launches (AC_LOSS_STEPWISE), whatever the
+        process-wide persistent-kernel switch says.  Returns the number of steps taken."""
         n_total = int(order.numel()) if order is not None else int(X_all.shape[0])
         ws = self._workspace(min(batch, max(n_total, 1)))
         done = ctypes.c_int(0)
         # the persistent epoch kernel publishes the output layer step by step; should one of its grid barriers give up (a GPU
         # shared with another compute process), the epoch is void and `restore_epoch()` puts the parameters back
         if self._snap is None:
-            self._snap = torch.empty_like(self.flat)
-        self._snap.copy_(self.flat)
+            self._snap = torch.empty((3,) + tuple(self.flat.shape), dtype=self.flat.dtype, device=self.flat.device)
+        self._snap[0].copy_(self.flat); self._snap[1].copy_(self.m); self._snap[2].copy_(self.v)
         self._snap_t = self.t
         with torch.cuda.device(self.device):
             nv.check(nv.lib().ac_head_train_epoch(
                 ctypes.byref(self.dims), nv.ptr(self.flat), nv.ptr(self.m), nv.ptr(self.v), nv.ptr(self.grads),
                 nv.ptr(X_all), X_all.stride(0), nv.ptr(y_all), nv.ptr(targets_all),
-                0 if targets_all is None else targets_all.stride(0), loss_kind, nv.ptr(order), n_total, batch,
-                dropout_p, seed0, nv.ptr(fisher), nv.ptr(old_params), lambda_B, self.max_grad_norm, self.lr,
+                0 if targets_all is None else targets_all.stride(0), loss_kind | (LOSS_STEPWISE if stepwise else 0),
+                nv.ptr(order), n_total, batch, dropout_p, seed0, nv.ptr(fisher), nv.ptr(old_params), lambda_B, self.max_grad_norm, self.lr,
                 self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t + 1, nv.ptr(self.out3),
                 nv.ptr(self.loss_accum), nv.ptr(ws), ws.numel(), ctypes.byref(done),
                 nv.stream_ptr(self.device)), "ac_head_train_epoch")
@@ -150,6 +152,8 @@ class HeadTrainer:
         return done.value
 
     def restore_epoch(self):
-        """Undo the last fused_epoch (parameters and step counter; the moments are only written when an epoch completes)."""
-        self.flat.copy_(self._snap)
+        """Undo the last fused_epoch: parameters, both Adam moments and the step counter.  (A persistent epoch writes the
+        moments back when it completes -- also when its loss is a genuine NaN -- and a barrier that gives up at the last
+        step leaves them half written, so they are part of the snapshot.)"""
+        self.flat.copy_(self._snap[0]); self.m.copy_(self._snap[1]); self.v.copy_(self._snap[2])
         self.t = self._snap_t

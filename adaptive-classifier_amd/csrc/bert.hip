@@ -610,22 +610,41 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
 
 }  // namespace
 
-extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids,
-                                  const int64_t* d_type_ids, const int64_t* d_mask, int b, int S,
-                                  float* d_out, int64_t ldo, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+extern "C" int ac_bert_encode_cls_opts(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids,
+                                       const int64_t* d_type_ids, const int64_t* d_mask, int b, int S,
+                                       float* d_out, int64_t ldo, void* d_ws, size_t ws_bytes, int opts, int* used_one_launch,
+                                       ac_stream_t stream_) {
+    if (used_one_launch) *used_one_launch = 0;
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (b == 0) return AC_OK;
     AC_REQUIRE(w && d_ids && d_out && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden, AC_EINVAL,
                "bert_encode_cls: bad arguments (b=%d S=%d max_pos=%d)", b, S, cfg->max_pos);
-    if (b * S <= 32) {          // a handful of token rows (single-query predict): every layer in ONE persistent launch
+    if (b * S <= 32 && !(opts & AC_BERT_LAYERED)) {   // a handful of token rows (single-query predict): every layer in ONE persistent launch
         const BertWs ws = bert_ws(*cfg, b, S);
         AC_REQUIRE(d_ws && ws_bytes >= ws.total, AC_EWORKSPACE, "bert_encode_cls: workspace %zu < %zu", ws_bytes, ws.total);
         rc = ac::bert_small_encode(*cfg, *w, d_ids, d_type_ids, d_mask, b, S, d_out, ldo, (char*)d_ws + ws.small, (hipStream_t)stream_);
+        if (rc == AC_OK && used_one_launch) *used_one_launch = 1;
         if (rc != 1) return rc;
     }
     return bert_encode_impl(cfg, w, d_ids, d_type_ids, d_mask, b, S, nullptr, nullptr, b * S, S, d_out, ldo, d_ws, ws_bytes,
                             (hipStream_t)stream_);
+}
+
+extern "C" int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids,
+                                  const int64_t* d_type_ids, const int64_t* d_mask, int b, int S,
+                                  float* d_out, int64_t ldo, void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    return ac_bert_encode_cls_opts(cfg, w, d_ids, d_type_ids, d_mask, b, S, d_out, ldo, d_ws, ws_bytes, 0, nullptr, stream_);
+}
+
+extern "C" int ac_bert_one_launch_status(const ac_bert_config* cfg, int b, int S, const void* d_ws, size_t ws_bytes,
+                                         int* aborted, ac_stream_t stream_) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    AC_REQUIRE(aborted && d_ws && b > 0 && S >= 1 && b * S <= 32, AC_EINVAL, "bert_one_launch_status: bad arguments");
+    const BertWs ws = bert_ws(*cfg, b, S);
+    AC_REQUIRE(ws_bytes >= ws.total, AC_EWORKSPACE, "bert_one_launch_status: workspace %zu < %zu", ws_bytes, ws.total);
+    return ac::bert_small_aborted(cfg->hidden, cfg->intermediate, (const char*)d_ws + ws.small, (hipStream_t)stream_, aborted);
 }
 
 extern "C" int ac_bert_pack(const int64_t* d_mask, int b, int S, int32_t* d_cu, int32_t* d_tok_src, int32_t* d_info,

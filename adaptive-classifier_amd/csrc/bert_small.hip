@@ -529,4 +529,15 @@ int bert_small_encode(const ac_bert_config& c, const ac_bert_weights& w, const i
     return AC_OK;
 }
 
+// abort flag of the last bert_small_encode launch in this workspace (1 = a grid barrier gave up and the output rows are NaN).
+// Synchronises the stream (4-byte D2H).
+int bert_small_aborted(int H, int I, const void* ws, hipStream_t stream, int* aborted) {
+    const GridCtl* ctl = (const GridCtl*)((const char*)ws + align_up(small_act_floats(H, I) * sizeof(float), 256));
+    unsigned v = 0;
+    AC_HIP_CHECK(hipMemcpyAsync(&v, &ctl->abort_, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    AC_HIP_CHECK(hipStreamSynchronize(stream));
+    *aborted = v != 0;
+    return AC_OK;
+}
+
 }  // namespace ac

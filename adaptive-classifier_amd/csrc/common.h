@@ -141,5 +141,6 @@ int head_epoch_persistent(const ac_head_dims& d, float* P, float* M, float* V, f
 size_t bert_small_ws_bytes(int H, int I);
 int bert_small_encode(const ac_bert_config& c, const ac_bert_weights& w, const int64_t* ids, const int64_t* type_ids,
                       const int64_t* mask, int b, int S, float* out, int64_t ldo, void* ws, hipStream_t stream);
+int bert_small_aborted(int H, int I, const void* ws, hipStream_t stream, int* aborted);
 
 }  // namespace ac

@@ -662,11 +662,13 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         else if (tm == 2) hipLaunchKernelGGL((gemm_tile_nt<E, 2>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);     \
         else hipLaunchKernelGGL((gemm_tile_nt<E, 1>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);                  \
     } while (0)
-        // EXPERIMENT, opt-in (ac_gemm_set_variant(2)): the persistent stream-K ring kernel of gemm_ring.hip.  Measured and
-        // rejected as default: +6 % at 8192^3 and +12 % on an isolated FFN1, but slower inside the encoder
-        // pass (-3 % end to end) and on every shape whose tiles are cut between workgroups.
-        if (planes && Ap && ac::gemm_variant() >= 2 && ac::ring_takes(M, N, K, cls, Cp != nullptr, ac::gemm_variant() == 2))
-            return ac::launch_gemm_ring(Ap, a_rows, Bp, b_rows, C, ldc, Cp, M, N, K, cls, epi, stream);
+        // ring-staged kernel (gemm_pipe.hip): ac_gemm_set_variant(cfg >= 1000) forces one configuration (A/B harness);
+        // variant 0 = the measured per-shape choice of pipe_choose(), variant 1 = never
+        if (planes && Ap && ac::pipe_takes(M, N, K, cls, Cp != nullptr)) {
+            const int v = ac::gemm_variant();
+            const int cfg = v >= 1000 ? v : (v == 0 ? ac::pipe_choose(M, N, K, cls, Cp != nullptr) : 0);
+            if (cfg) return ac::launch_gemm_pipe(cfg, Ap, a_rows, Bp, b_rows, C, ldc, Cp, M, N, K, cls, epi, stream);
+        }
         // 8-wave 256 x 128 tile when both operands are pre-split and the grid has >= 1.5 rounds of such tiles
         const int64_t b256 = (int64_t)((M + 255) / 256) * ntn;
         static const int tile256_env = getenv("AC_GEMM_TILE256") ? atoi(getenv("AC_GEMM_TILE256")) : -1;
@@ -835,7 +837,7 @@ extern "C" int ac_gemm_set_arith(int mode) {
 }
 extern "C" int ac_gemm_get_arith(void) { return ac::gemm_arith(); }
 extern "C" int ac_gemm_set_variant(int v) {
-    AC_REQUIRE(v == 0 || v == 2 || v == 3, AC_EINVAL, "gemm variant: unknown value %d", v);
+    AC_REQUIRE(v == 0 || v == 1 || v >= 1000, AC_EINVAL, "gemm variant: unknown value %d", v);
     ac::g_gemm_variant.store(v, std::memory_order_relaxed);
     return AC_OK;
 }

@@ -1,4 +1,4 @@
-// Shared pieces of the GEMM kernels (gemm.hip, gemm_ring.hip): the runtime epilogue description, the compile-time
+// Shared pieces of the GEMM kernels (gemm.hip, gemm_pipe.hip): the runtime epilogue description, the compile-time
 // epilogue classes and the C/D-layout tile stores (fp32 rows, or bf16x3 operand planes of the next GEMM).
 // Device code only; include inside an anonymous namespace user.
 #pragma once
@@ -184,9 +184,10 @@ __device__ __forceinline__ int xcd_tile_id(int wg, int nwg) {
 }  // namespace acg
 
 namespace ac {
-// gemm_ring.hip: persistent stream-K ring kernel for large-M GEMMs with both operands pre-split
-bool ring_takes(int M, int N, int K, int cls, bool c_planes, bool allow_cuts);
-int launch_gemm_ring(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, float* C, int64_t ldc,
+// gemm_pipe.hip: the planes GEMM with its operand stages in an LDS ring (counted vmcnt, raw barrier)
+bool pipe_takes(int M, int N, int K, int cls, bool c_planes);
+int pipe_choose(int M, int N, int K, int cls, bool c_planes);   // 0 = keep the two-buffer tile kernels of gemm.hip
+int launch_gemm_pipe(int cfg, const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, float* C, int64_t ldc,
                      uint16_t* Cp, int M, int N, int K, int cls, const acg::Epilogue& epi, hipStream_t stream);
-int gemm_variant();            // diagnostic switch (ac_gemm_set_variant): 0 = default dispatch, 2 = ring kernel where it applies
+int gemm_variant();            // diagnostic switch (ac_gemm_set_variant): 0 = default dispatch, 1 = two-buffer kernels only, >= 1000 = one ring configuration
 }  // namespace ac

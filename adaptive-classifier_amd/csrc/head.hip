@@ -597,6 +597,8 @@ extern "C" int ac_head_train_step(const ac_head_dims* dims, float* d_params, flo
     hipStream_t stream = (hipStream_t)stream_;
     AC_REQUIRE(d_params && d_m && d_v && d_grads && d_X && d_out && B > 0 && ldx >= dims->D && step >= 1,
                AC_EINVAL, "head_train_step: bad arguments");
+    const bool stepwise = (loss_kind & AC_LOSS_STEPWISE) != 0;       // per-call opt-out of the persistent kernel
+    loss_kind &= ~AC_LOSS_STEPWISE;
     AC_REQUIRE(loss_kind >= AC_LOSS_CE && loss_kind <= AC_LOSS_CE_SIGMOID, AC_EINVAL, "head_train_step: loss_kind=%d", loss_kind);
     AC_REQUIRE(loss_kind == AC_LOSS_BCE_SIGMOID ? (d_targets && ldt >= dims->C) : (d_y != nullptr), AC_EINVAL,
                "head_train_step: BCE needs float targets [rows, C]; CE needs int64 labels");
@@ -607,7 +609,7 @@ extern "C" int ac_head_train_step(const ac_head_dims* dims, float* d_params, flo
     const HeadWs w = head_ws(d, B);
     AC_REQUIRE(d_ws && ws_bytes >= w.total, AC_EWORKSPACE, "head_train_step: workspace %zu < %zu", ws_bytes, w.total);
     char* ws = (char*)d_ws;
-    {   // one step of the persistent epoch kernel when the shape fits (the same code path as ac_head_train_epoch)
+    if (!stepwise) {   // one step of the persistent epoch kernel when the shape fits (the same code path as ac_head_train_epoch)
         const int prc = ac::head_epoch_persistent(d, d_params, d_m, d_v, d_grads, d_X, ldx, d_y, d_targets, ldt, loss_kind, d_index, B, B,
                                                   dropout_p, dropout_seed, d_fisher, d_old, 0.f, d_fisher ? lambda_over_B : 0.f,
                                                   max_grad_norm, lr, beta1, beta2, eps, weight_decay, step, d_out, d_loss_accum,
@@ -710,14 +712,16 @@ extern "C" int ac_head_train_epoch(const ac_head_dims* dims, float* d_params, fl
     if (n_total > 0 && dims && d_params && d_m && d_v && d_grads && d_X && d_out && d_ws) {
         int rc = check_dims(dims);
         if (rc) return rc;
-        AC_REQUIRE(loss_kind >= AC_LOSS_CE && loss_kind <= AC_LOSS_CE_SIGMOID, AC_EINVAL, "head_train_epoch: loss_kind=%d", loss_kind);
-        AC_REQUIRE(loss_kind == AC_LOSS_BCE_SIGMOID ? (d_targets && ldt >= dims->C) : (d_y != nullptr), AC_EINVAL,
+        const int kind = loss_kind & ~AC_LOSS_STEPWISE;
+        AC_REQUIRE(kind >= AC_LOSS_CE && kind <= AC_LOSS_CE_SIGMOID, AC_EINVAL, "head_train_epoch: loss_kind=%d", loss_kind);
+        AC_REQUIRE(kind == AC_LOSS_BCE_SIGMOID ? (d_targets && ldt >= dims->C) : (d_y != nullptr), AC_EINVAL,
                    "head_train_epoch: BCE needs float targets [rows, C]; CE needs int64 labels");
         AC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f && ldx >= dims->D, AC_EINVAL, "head_train_epoch: bad dropout_p / ldx");
         AC_REQUIRE((d_fisher == nullptr) == (d_old == nullptr), AC_EINVAL, "head_train_epoch: fisher and old params must be given together");
         const HeadWs w = head_ws(*dims, (int)(n_total < batch ? n_total : batch));
         AC_REQUIRE(ws_bytes >= w.total, AC_EWORKSPACE, "head_train_epoch: workspace %zu < %zu", ws_bytes, w.total);
-        rc = ac::head_epoch_persistent(*dims, d_params, d_m, d_v, d_grads, d_X, ldx, d_y, d_targets, ldt, loss_kind, d_order, n_total,
+        rc = (loss_kind & AC_LOSS_STEPWISE) ? 1 :
+             ac::head_epoch_persistent(*dims, d_params, d_m, d_v, d_grads, d_X, ldx, d_y, d_targets, ldt, kind, d_order, n_total,
                                        batch, dropout_p, seed0, d_fisher, d_old, lambda_B, -1.f, max_grad_norm, lr, beta1, beta2, eps,
                                        weight_decay, step0, d_out, d_loss_accum, (char*)d_ws + w.epoch, (hipStream_t)stream);
         if (rc == AC_OK) { if (steps_done) *steps_done = (int)((n_total + batch - 1) / batch); return AC_OK; }

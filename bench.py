@@ -278,11 +278,11 @@ def sharded_cfg2(dev, rank, world, total_rows, batch=4096, k=32, reps=3):
     q_local = ix.synth_unit_rows(b, DIM, 2, row_offset=rank * b, device=dev)
     ss = ShardedSearch(rows, hi - lo, DIM, lo)
     for _ in range(1):
-        ss.search(ss.gather_queries(q_local), k)
+        ss.search_block(q_local, k)
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        Dg, Ig = ss.search(ss.gather_queries(q_local), k)
+        Dg, Ig = ss.search_block(q_local, k)
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -291,7 +291,7 @@ def sharded_cfg2(dev, rank, world, total_rows, batch=4096, k=32, reps=3):
     del rows
     torch.cuda.empty_cache()
     return {"workload": "BASELINE configs[2]: %d x %d row-sharded over %d GPUs, k=%d, batch %d (all-gather queries, local "
-                        "sweep, all-gather exact fp64 dist + ids, merge)" % (total_rows, DIM, world, k, b * world),
+                        "sweep, all-to-all of exact fp64 dist + ids, every rank merges its own query block)" % (total_rows, DIM, world, k, b * world),
             "ms_per_batch": dt / reps * 1e3, "queries_per_s": b * world * reps / dt, "rows_per_gpu": hi - lo}
 
 
@@ -620,7 +620,7 @@ def main():
                       "algorithmic_bytes_per_launch": rows_rank * DIM * 4, "avg_kernel_ms": slow,
                       "rank0_avg_kernel_ms": r["avg_kernel_ms"], "aggregation": "sum of shard bytes / max over ranks of the kernel time"}
     # N > 1: BASELINE configs[2] itself -- 10M x 768 row-sharded over the ranks, k = 32, 4096 queries per batch
-    # (4096 / N per rank, data parallel): all-gather(queries) -> local sweep -> all-gather(exact dist, ids) -> merge
+    # (4096 / N per rank, data parallel): all-gather(queries) -> local sweep -> all-to-all(exact dist, ids) -> merge of the rank's own block
     cfg2 = None
     if world > 1 and not args.no_sweep:
         cfg2 = sharded_cfg2(dev, rank, world, args.sweep_rows)

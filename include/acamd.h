@@ -202,9 +202,10 @@ int ac_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
 #define AC_GEMM_BF16X3 1
 int ac_gemm_set_arith(int mode);
 int ac_gemm_get_arith(void);
-/* Diagnostic / A-B switch for the large-M pre-split GEMM: 0 = default dispatch (the three-blocks-per-CU tile kernels),
- * 2 = the experimental persistent stream-K ring kernel (gemm_ring.hip; measured and rejected as default)
- * where it applies.  Env AC_GEMM_VARIANT sets the initial value. */
+/* Diagnostic / A-B switch for the large-M pre-split GEMM: 0 = default dispatch (per-shape choice between the two-buffer
+ * tile kernels of gemm.hip and the ring-staged kernels of gemm_pipe.hip), 1 = two-buffer tile kernels only,
+ * >= 1000 = one ring configuration tm * 1000 + wmw * 100 + ring depth * 10 + pipelining (tools/gemm_bench.hip).
+ * Env AC_GEMM_VARIANT sets the initial value. */
 int ac_gemm_set_variant(int variant);
 
 /* The persistent one-launch kernels of the latency-bound ends of the path are chosen automatically when the shape fits;
@@ -281,6 +282,10 @@ int ac_head_fwd_bwd_ce(const ac_head_dims* dims, const float* d_params,
 #define AC_LOSS_BCE_SIGMOID 1  /* nn.BCELoss on sigmoid(logits), float multi-hot targets (multilabel.py:361) */
 #define AC_LOSS_CE_SIGMOID  2  /* CrossEntropyLoss on sigmoid(logits): what the reference's new-class loop
                                   computes when the head is a MultiLabelAdaptiveHead (classifier.py:337-339) */
+/* OR-ed into loss_kind of ac_head_train_step / ac_head_train_epoch: this call takes the step-by-step launches even where the
+ * persistent epoch kernel (head_epoch.hip) would apply -- a per-call, thread-safe form of ac_set_persistent_kernels(~1),
+ * used to repeat an epoch whose persistent launch came back void (NaN loss: a grid barrier gave up on a shared device). */
+#define AC_LOSS_STEPWISE 0x100
 
 /* ac_head_fwd_bwd_ce generalised to the three losses (explicit dropout masks, parity path).
  * d_y int64 [B] for the CE kinds, d_targets float [B, ldt] for BCE. */
@@ -466,6 +471,24 @@ int ac_bert_encode_cls(const ac_bert_config* cfg, const ac_bert_weights* w,
                        const int64_t* d_mask, int b, int S,
                        float* d_out_unit_cls, int64_t ldo,
                        void* d_ws, size_t ws_bytes, ac_stream_t stream);
+
+/* ac_bert_encode_cls with per-call options and a report of the path taken.
+ *   opts & AC_BERT_LAYERED   never take the one-launch path of bert_small.hip (<= 32 token rows), whatever
+ *                            ac_set_persistent_kernels says: the layer-by-layer kernels run.
+ *   used_one_launch          (nullable, host) 1 if this call ran as the one persistent launch.
+ * The one-launch kernel is launched without the cooperative-launch residency check (it saves ~30 us per single query);
+ * if the device is shared with another compute process one of its grid barriers can give up after a bounded spin, in
+ * which case the output rows are NaN.  ac_bert_one_launch_status reads that verdict for the LAST one-launch call that
+ * used this workspace (same cfg, b, S): *aborted = 1 -> repeat the call with AC_BERT_LAYERED.  It synchronises the
+ * stream (a 4-byte D2H); callers that inspect their final result for NaN instead need not call it. */
+#define AC_BERT_LAYERED 1
+int ac_bert_encode_cls_opts(const ac_bert_config* cfg, const ac_bert_weights* w,
+                            const int64_t* d_ids, const int64_t* d_type_ids,
+                            const int64_t* d_mask, int b, int S,
+                            float* d_out_unit_cls, int64_t ldo,
+                            void* d_ws, size_t ws_bytes, int opts, int* used_one_launch, ac_stream_t stream);
+int ac_bert_one_launch_status(const ac_bert_config* cfg, int b, int S, const void* d_ws, size_t ws_bytes,
+                              int* aborted, ac_stream_t stream);
 
 /*
  * Padding-free ("packed") form of the same forward.  The reference pads every text to the longest of the batch and

@@ -9,7 +9,9 @@ import torch
 import torch.nn.functional as F
 
 
-def make_bert(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, max_pos=512, seed=0):
+def make_bert(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, max_pos=512, seed=0, qk_scale=1.0,
+              ln_outlier=1.0):
+    """qk_scale / ln_outlier: see sharpen_attention (1.0 = transformers' own init: std 0.02, near-uniform softmax)."""
     from transformers import BertConfig, BertModel
     cfg = BertConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
                      intermediate_size=intermediate, max_position_embeddings=max_pos)
@@ -18,9 +20,46 @@ def make_bert(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, m
     except Exception:
         pass
     torch.manual_seed(seed)
-    model = BertModel(cfg, add_pooling_layer=False)
-    # BERT's init std (0.02) makes LayerNorm inputs tiny and hides errors; widen a little
-    return model.eval()
+    model = BertModel(cfg, add_pooling_layer=False).eval()
+    if qk_scale != 1.0 or ln_outlier != 1.0:
+        sharpen_attention(model, qk_scale, ln_outlier, seed=seed + 17)
+    return model
+
+
+@torch.no_grad()
+def sharpen_attention(model, qk_scale=6.0, ln_outlier=1.0, seed=17):
+    """Random init at std 0.02 gives attention logits of ~0.3, i.e. a softmax within a few percent of uniform: the online
+    max / rescale path of an attention kernel and its key masks are then hardly exercised.  Scale the query and key
+    projections (weights and freshly drawn biases) by qk_scale so the distributions are peaked, as in trained
+    checkpoints; ln_outlier > 1 additionally gives a few LayerNorm channels a large gain and offset (trained BERTs
+    carry such outlier channels).  Works on BertModel and DistilBertModel (module names query/key, q_lin/k_lin)."""
+    g = torch.Generator().manual_seed(seed)
+    for name, mod in model.named_modules():
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf in ("query", "key", "q_lin", "k_lin") and isinstance(mod, torch.nn.Linear):
+            mod.weight.mul_(qk_scale)
+            mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.02 * qk_scale)
+        elif isinstance(mod, torch.nn.LayerNorm) and ln_outlier != 1.0:
+            idx = torch.randperm(mod.weight.numel(), generator=g)[:4]
+            mod.weight[idx] *= ln_outlier
+            mod.bias[idx] += 0.5 * ln_outlier * torch.randn(4, generator=g)
+    return model
+
+
+@torch.no_grad()
+def attention_peak_stats(model, ids, mask, types=None):
+    """(mean, min over layers of the mean) of max_k softmax probability over the valid queries -- how far the attention
+    of this model on this batch is from uniform (uniform = 1 / valid keys)."""
+    kw = dict(input_ids=ids, attention_mask=mask, output_attentions=True)
+    if types is not None:
+        kw["token_type_ids"] = types
+    att = model(**kw).attentions                      # per layer [b, heads, S, S]
+    valid = mask.bool()[:, None, :, None]
+    per_layer = []
+    for a in att:
+        mx = a.max(dim=-1, keepdim=True).values       # [b, h, S, 1]
+        per_layer.append(float(mx[valid.expand_as(mx)].mean()))
+    return sum(per_layer) / len(per_layer), min(per_layer)
 
 
 def synthetic_batch(b, S, vocab=30522, seed=1234, ragged=True):

@@ -5,6 +5,31 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# Attention regimes of the random-init oracle models (oracle/bert_oracle.sharpen_attention):
+#   flat   -- transformers' own init (std 0.02): logits ~0.3, softmax within a few percent of uniform;
+#   peaked -- query / key projections scaled so the mean max attention probability is >= 0.5 (S <= 64) / >= 0.3 (S = 512),
+#             plus four LayerNorm outlier channels (gain x12), as trained checkpoints have.
+# The same 1e-4 bar holds in both; the peaked regime is the one that drives the online-softmax max / rescale path and would
+# expose a key-mask mistake.
+REGIMES = ["flat", "peaked"]
+
+
+def regime_kw(regime, hidden):
+    if regime == "flat":
+        return {}
+    return {"qk_scale": 8.0 if hidden < 256 else 5.0, "ln_outlier": 12.0}
+
+
+def check_peaked(regime, model, ids, mask, types=None, S=None):
+    """print the attention statistics; in the peaked regime they must be far from uniform"""
+    from oracle import bert_oracle
+    mean_max, min_layer = bert_oracle.attention_peak_stats(model, ids, mask, types)
+    S = S or ids.shape[1]
+    print(f"[attention stats] regime={regime} S={S}: mean max probability {mean_max:.3f} (lowest layer {min_layer:.3f}), "
+          f"uniform would be ~{1.0 / max(1.0, float(mask.sum(1).float().mean())):.3f}")
+    if regime == "peaked":
+        assert mean_max >= (0.3 if S >= 256 else 0.5), mean_max
+
 
 @pytest.mark.parametrize("hidden,layers,heads,inter,b,S,ragged", [
     (128, 2, 2, 512, 5, 16, True),        # bert-tiny architecture
@@ -16,13 +41,16 @@ pytestmark = pytest.mark.gpu
     (1024, 2, 16, 4096, 9, 30, True),     # bert-large width with T = 270 rows: pre-split operand planes, ragged tiles
     (1024, 24, 16, 4096, 16, 32, True),   # FULL-DEPTH bert-large = e5-large-v2 architecture (BASELINE configs[4]): 24 layers
 ])
-def test_encoder_cls_matches_transformers(hidden, layers, heads, inter, b, S, ragged, cuda_dev):
+@pytest.mark.parametrize("regime", REGIMES)
+def test_encoder_cls_matches_transformers(hidden, layers, heads, inter, b, S, ragged, regime, cuda_dev):
     from adaptive_classifier.encoder import HipBertEncoder
     from oracle import bert_oracle
     vocab = 2000
-    model = bert_oracle.make_bert(hidden, layers, heads, inter, vocab=vocab, seed=0)
+    model = bert_oracle.make_bert(hidden, layers, heads, inter, vocab=vocab, seed=0, **regime_kw(regime, hidden))
     ids, types, mask = bert_oracle.synthetic_batch(b, S, vocab=vocab, seed=1234, ragged=ragged)
     types[:, S // 2:] = 1
+    if layers <= 12:
+        check_peaked(regime, model, ids, mask, types)
     want = bert_oracle.encode_cls(model, ids, types, mask)
     enc = HipBertEncoder(model, device=cuda_dev)
     got = enc.encode_cls(ids, types, mask).cpu()
@@ -40,16 +68,19 @@ def test_encoder_cls_matches_transformers(hidden, layers, heads, inter, b, S, ra
     (384, 6, 6, 1536, 1, 20, False),      # MiniLM-L6 width (H = 384: three k-blocks per wave)
     (128, 2, 2, 512, 4, 8, True),         # bert-tiny
 ])
-def test_small_batch_one_launch_path_matches_transformers(hidden, layers, heads, inter, b, S, ragged, cuda_dev):
+@pytest.mark.parametrize("regime", REGIMES)
+def test_small_batch_one_launch_path_matches_transformers(hidden, layers, heads, inter, b, S, ragged, regime, cuda_dev):
     """b * S <= 32 token rows: ac_bert_encode_cls runs every layer inside ONE persistent launch (bert_small.hip, strict
     fp32 MFMA).  Same 1e-4 bar against transformers fp32, and against the layer-by-layer kernels on the same texts
     (the batch replicated until it exceeds 32 rows takes that path)."""
     from adaptive_classifier.encoder import HipBertEncoder
     from oracle import bert_oracle
     vocab = 2000
-    model = bert_oracle.make_bert(hidden, layers, heads, inter, vocab=vocab, seed=0)
+    model = bert_oracle.make_bert(hidden, layers, heads, inter, vocab=vocab, seed=0, **regime_kw(regime, hidden))
     ids, types, mask = bert_oracle.synthetic_batch(b, S, vocab=vocab, seed=4321, ragged=ragged)
     types[:, S // 2:] = 1
+    if S >= 16:
+        check_peaked(regime, model, ids, mask, types)
     want = bert_oracle.encode_cls(model, ids, types, mask)
     enc = HipBertEncoder(model, device=cuda_dev)
     got = enc.encode_cls(ids, types, mask).cpu()
@@ -94,7 +125,8 @@ def test_encoder_no_mask_and_large_batch(cuda_dev):
     assert (got - want).abs().max().item() < 1e-4
 
 
-def test_distilbert_encoder_matches_transformers(cuda_dev):
+@pytest.mark.parametrize("regime", REGIMES)
+def test_distilbert_encoder_matches_transformers(regime, cuda_dev):
     """N4 (part): DistilBERT = the BERT block without token-type embeddings; same kernels, mapped weights."""
     import torch.nn.functional as F
     from transformers import DistilBertConfig, DistilBertModel
@@ -107,7 +139,10 @@ def test_distilbert_encoder_matches_transformers(cuda_dev):
         pass
     torch.manual_seed(0)
     model = DistilBertModel(cfg).eval()
+    if regime == "peaked":
+        bert_oracle.sharpen_attention(model, **regime_kw(regime, 768))
     ids, types, mask = bert_oracle.synthetic_batch(6, 40, vocab=2000, seed=7, ragged=True)
+    check_peaked(regime, model, ids, mask)
     with torch.no_grad():
         want = F.normalize(model(input_ids=ids, attention_mask=mask).last_hidden_state[:, 0, :], p=2, dim=1)
     enc = HipBertEncoder(model, device=cuda_dev)
@@ -166,18 +201,21 @@ def test_large_batches_are_encoded_in_row_chunks(cuda_dev, monkeypatch):
     assert (whole - enc2.encode_cls(ids, None, mask).cpu()).abs().max().item() < 2e-6
 
 
-def test_padding_free_path_equals_padded_path(cuda_dev):
+@pytest.mark.parametrize("regime", REGIMES)
+def test_padding_free_path_equals_padded_path(regime, cuda_dev):
     """ac_bert_pack + ac_bert_encode_cls_packed (padding tokens left out of the forward) give the CLS vectors of the padded
     forward: same dot products in the same order, masked keys contribute exact zeros.  Masks that are not right-padded
     (left padding, holes, an empty row) keep the padded path."""
     from adaptive_classifier.encoder import HipBertEncoder
     from oracle import bert_oracle
-    model = bert_oracle.make_bert(768, 3, 12, 3072, vocab=3000, seed=2)
+    model = bert_oracle.make_bert(768, 3, 12, 3072, vocab=3000, seed=2, **regime_kw(regime, 768))
     packed = HipBertEncoder(model, device=cuda_dev, unpad=True)
     padded = HipBertEncoder(model, device=cuda_dev, unpad=False)
     for (b, S, seed) in [(37, 48, 3), (256, 32, 1234), (5, 130, 9), (1, 16, 4)]:
         ids, types, mask = bert_oracle.synthetic_batch(b, S, vocab=3000, seed=seed, ragged=True)
         types[:, S // 3:] = 1
+        if b == 37:
+            check_peaked(regime, model, ids, mask, types)
         a = packed.encode_cls(ids, types, mask)
         assert packed.last_tokens == int(mask.sum()) or b == 1
         c = padded.encode_cls(ids, types, mask)

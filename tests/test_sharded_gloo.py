@@ -39,7 +39,8 @@ def _worker(rank, world, port, N, D, nq, k, ret):
     ss = ShardedSearch(rows, hi - lo, D, lo, local_search=local_search, merge=merge)
     Q = ss.gather_queries(q_local)
     Dg, Ig = ss.search(Q, k)
-    ret[rank] = (Q.numpy(), Dg.numpy(), Ig.numpy())
+    Db, Ib = ss.search_block(q_local, k)                   # all_to_all: this rank merges only its own query block
+    ret[rank] = (Q.numpy(), Dg.numpy(), Ig.numpy(), Db.numpy(), Ib.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,10 +55,12 @@ def test_sharded_search_world2(N, k):
     P = synth.synth_unit_rows(N, D, 1)
     Q = synth.synth_unit_rows(nq, D, 2)
     oD, oI = knn_oracle.knn_l2_topk(P, Q, k)
+    b = nq // world
     for r in range(world):
-        Qr, Dg, Ig = ret[r]
+        Qr, Dg, Ig, Db, Ib = ret[r]
         assert np.array_equal(Qr, Q)                       # gathered query block is the global batch
         assert np.array_equal(Ig, oI) and np.array_equal(Dg, oD)
+        assert np.array_equal(Ib, oI[r * b:(r + 1) * b]) and np.array_equal(Db, oD[r * b:(r + 1) * b])
 
 
 def test_shard_bounds_cover_rows():

@@ -42,6 +42,8 @@ def _worker(rank, world, port, N, D, nq, k, ret):
     ss = ShardedSearch(rows, hi - lo, D, lo)                                      # default wiring = the HIP kernels
     Q = ss.gather_queries(q_local)
     Dg, Ig = ss.search(Q, k)
+    Db, Ib = ss.search_block(q_local, k)                                          # all_to_all, own block merged only
+    assert torch.equal(Db, Dg[rank * b:(rank + 1) * b]) and torch.equal(Ib, Ig[rank * b:(rank + 1) * b])
     # the same through the memory object the classifier uses (row -> class map replicated)
     mem = PrototypeMemory(D, device=str(dev))
     mem.load_rows(rows, torch.arange(N, dtype=torch.int32) % 4, ["c0", "c1", "c2", "c3"], sharded=ss)
@@ -71,6 +73,48 @@ def test_two_processes_one_gpu_real_kernels(N, D, nq, k, cuda_dev):
         assert np.array_equal(Ig, uI) and np.array_equal(Dg, uD)          # every rank holds the global top-k
         assert np.array_equal(Im, uI[r * b:(r + 1) * b]) and np.array_equal(Dm, uD[r * b:(r + 1) * b])
         assert np.array_equal(Sm, uS[r * b:(r + 1) * b])
+
+
+def _rccl_worker(rank, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "adaptive-classifier_amd")]
+    from adaptive_classifier import index as ix
+    from adaptive_classifier.memory import PrototypeMemory
+    from adaptive_classifier.sharded import ShardedSearch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    N, D, nq, k = 150_001, 768, 48, 16
+    rows = ix.synth_unit_rows(N, D, 1, device=dev)
+    q = ix.synth_unit_rows(nq, D, 2, device=dev)
+    uD, uI = ix.knn_l2_topk(rows, N, D, q, k)
+    ss = ShardedSearch(rows, N, D, 0, force_collectives=True)
+    assert dist.get_backend() == "nccl" and ss._collective and not ss._staged(q)
+    g = ss._all_gather(q)                                                          # all_gather_into_tensor on device
+    Q = ss.gather_queries(q)
+    Dg, Ig = ss.search(Q, k)                                                        # all_gather of the packed lists + merge
+    Db, Ib = ss.search_block(q, k)                                                  # all_to_all_single + merge
+    mem = PrototypeMemory(D, device=str(dev))
+    mem.load_rows(rows, torch.arange(N, dtype=torch.int32) % 4, ["c0", "c1", "c2", "c3"], sharded=ss)
+    S, Im, Dm = mem.search_batch(q, k)
+    torch.cuda.synchronize()
+    ret["ok"] = bool(g.shape == (1, nq, q.shape[1]) and torch.equal(g[0], q) and torch.equal(Q, q)
+                     and torch.equal(Ig, uI) and torch.equal(Dg, uD) and torch.equal(Ib, uI) and torch.equal(Db, uD)
+                     and torch.equal(Im, uI) and torch.equal(Dm, uD) and torch.equal(S, ix.proto_scores(uD, uI)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_branch_world1(cuda_dev):
+    """The RCCL code path of ShardedSearch (all_gather_into_tensor / all_to_all_single on DEVICE tensors) on a one-rank
+    `nccl` group with the world-1 short cuts bypassed (force_collectives): the collectives really execute on the GPU and the
+    result equals the unsharded search.  (Real multi-GPU exchanges are the driver's to run: one GPU per box here.)"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    assert ret.get("ok") is True
 
 
 @pytest.mark.parametrize("G", [2, 4, 8])

@@ -1,9 +1,9 @@
 // Standalone A/B harness for the planes GEMM variants (no torch: runs in seconds on the GPU box).
 //   hipcc -O2 --offload-arch=gfx950 tools/gemm_bench.hip -o tools/ab/gemm_bench \
-//         -Ladaptive-classifier_amd/adaptive_classifier -lacamd -Wl,-rpath,/root/repo/adaptive-classifier_amd/adaptive_classifier
-//   tools/ab/gemm_bench [variants, e.g. 0,1] [reps] [M,N,K,act,res,cplanes ...]
-// For every shape: time each variant (ac_gemm_set_variant) of ac_linear_bf16x3 with pre-split operands, and compare
-// every variant's output with variant 0's (max |diff|, count of differing elements).
+//         -Ladaptive-classifier_amd/adaptive_classifier -lacamd -Wl,-rpath,'$ORIGIN/../../adaptive-classifier_amd/adaptive_classifier'
+//   tools/ab/gemm_bench <variants, e.g. 1,2231,2261> <reps> <rounds> [M,N,K,act,res,cplanes ...]
+// For every shape: R interleaved rounds over all variants (ac_gemm_set_variant) of ac_linear_bf16x3 with pre-split
+// operands; prints median and min time per variant and compares every variant's output with the first variant's bit for bit.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../include/acamd.h"
@@ -29,24 +30,25 @@ __global__ void fill(float* x, size_t n, uint64_t seed, float scale) {
 struct Shape { int M, N, K, act, res, cplanes; };
 
 int main(int argc, char** argv) {
-    std::vector<int> variants = {0, 2};
-    int reps = 20;
-    std::vector<Shape> shapes = {{8192, 2304, 768, 0, 0, 0}, {8192, 768, 768, 0, 1, 0}, {8192, 3072, 768, 2, 0, 1},
-                                 {8192, 768, 3072, 0, 1, 0}, {8192, 8192, 8192, 0, 0, 0}};
+    std::vector<int> variants = {1};
+    int reps = 20, rounds = 3;
+    std::vector<Shape> shapes = {{5141, 2304, 768, 0, 0, 0}, {5141, 768, 768, 0, 1, 0}, {5141, 3072, 768, 2, 0, 1},
+                                 {5141, 768, 3072, 0, 1, 0}};
     if (argc > 1) { variants.clear(); char* s = strdup(argv[1]); for (char* t = strtok(s, ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t)); }
     if (argc > 2) reps = atoi(argv[2]);
-    if (argc > 3) {
+    if (argc > 3) rounds = atoi(argv[3]);
+    if (argc > 4) {
         shapes.clear();
-        for (int i = 3; i < argc; ++i) { Shape s{0, 0, 0, 0, 0, 0}; sscanf(argv[i], "%d,%d,%d,%d,%d,%d", &s.M, &s.N, &s.K, &s.act, &s.res, &s.cplanes); shapes.push_back(s); }
+        for (int i = 4; i < argc; ++i) { Shape s{0, 0, 0, 0, 0, 0}; sscanf(argv[i], "%d,%d,%d,%d,%d,%d", &s.M, &s.N, &s.K, &s.act, &s.res, &s.cplanes); shapes.push_back(s); }
     }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& sh : shapes) {
         const size_t MA = (size_t)sh.M * sh.K, MW = (size_t)sh.N * sh.K, MC = (size_t)sh.M * sh.N;
-        float *A, *W, *bias, *R, *C0, *C1; uint16_t *Ap, *Wp, *Cp0, *Cp1;
+        float *A, *W, *bias, *R, *C; uint16_t *Ap, *Wp, *Cp;
         CK(hipMalloc(&A, MA * 4)); CK(hipMalloc(&W, MW * 4)); CK(hipMalloc(&bias, sh.N * 4)); CK(hipMalloc(&R, MC * 4));
-        CK(hipMalloc(&C0, MC * 4)); CK(hipMalloc(&C1, MC * 4));
-        CK(hipMalloc(&Ap, MA * 6)); CK(hipMalloc(&Wp, MW * 6)); CK(hipMalloc(&Cp0, MC * 6)); CK(hipMalloc(&Cp1, MC * 6));
+        CK(hipMalloc(&C, MC * 4));
+        CK(hipMalloc(&Ap, MA * 6)); CK(hipMalloc(&Wp, MW * 6)); CK(hipMalloc(&Cp, MC * 6));
         hipLaunchKernelGGL(fill, dim3((MA + 255) / 256), dim3(256), 0, st, A, MA, 1, 1.0f);
         hipLaunchKernelGGL(fill, dim3((MW + 255) / 256), dim3(256), 0, st, W, MW, 2, 0.05f);
         hipLaunchKernelGGL(fill, dim3((sh.N + 255) / 256), dim3(256), 0, st, bias, (size_t)sh.N, 3, 0.1f);
@@ -57,35 +59,51 @@ int main(int argc, char** argv) {
         printf("M=%d N=%d K=%d act=%d res=%d cplanes=%d\n", sh.M, sh.N, sh.K, sh.act, sh.res, sh.cplanes);
         const size_t cbytes = sh.cplanes ? MC * 6 : MC * 4;
         std::vector<uint8_t> ref(cbytes), got(cbytes);
+        auto run = [&]() -> int { return ac_linear_bf16x3(A, sh.K, Ap, W, sh.K, Wp, bias, sh.res ? R : nullptr, sh.N, sh.cplanes ? nullptr : C, sh.N,
+                                                         sh.cplanes ? Cp : nullptr, sh.M, sh.N, sh.K, sh.act, st); };
+        std::vector<std::vector<double>> t(variants.size());
+        std::vector<int> ok(variants.size(), 1);
+        std::vector<size_t> ndiff(variants.size(), 0);
+        std::vector<double> maxd(variants.size(), 0.0);
+        // correctness pass (and warm-up)
         for (size_t vi = 0; vi < variants.size(); ++vi) {
-            const int v = variants[vi];
-            AC(ac_gemm_set_variant(v));
-            float* C = vi == 0 ? C0 : C1; uint16_t* Cp = vi == 0 ? Cp0 : Cp1;
+            AC(ac_gemm_set_variant(variants[vi]));
             CK(hipMemsetAsync(sh.cplanes ? (void*)Cp : (void*)C, 0xff, cbytes, st));
-            auto run = [&]() { AC(ac_linear_bf16x3(A, sh.K, Ap, W, sh.K, Wp, bias, sh.res ? R : nullptr, sh.N, sh.cplanes ? nullptr : C, sh.N,
-                                                   sh.cplanes ? Cp : nullptr, sh.M, sh.N, sh.K, sh.act, st)); };
-            for (int i = 0; i < 3; ++i) run();
+            if (run() != 0) { ok[vi] = 0; continue; }
+            run(); run();
             CK(hipStreamSynchronize(st));
-            CK(hipEventRecord(e0, st));
-            for (int i = 0; i < reps; ++i) run();
-            CK(hipEventRecord(e1, st));
-            CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            const double us = ms * 1e3 / reps, tf = 2.0 * sh.M * sh.N * (double)sh.K / (us * 1e-6) / 1e12;
             CK(hipMemcpy((vi == 0 ? ref : got).data(), sh.cplanes ? (void*)Cp : (void*)C, cbytes, hipMemcpyDeviceToHost));
-            printf("  variant %d: %9.1f us  %7.1f TF fp32-equiv (%.3f of 416.7)", v, us, tf, tf / 416.7);
             if (vi > 0) {
-                size_t ndiff = 0; double maxd = 0;
-                if (sh.cplanes) { for (size_t i = 0; i < cbytes; ++i) ndiff += ref[i] != got[i]; }
+                if (sh.cplanes) { for (size_t i = 0; i < cbytes; ++i) ndiff[vi] += ref[i] != got[i]; }
                 else {
                     const float* a = (const float*)ref.data(); const float* b = (const float*)got.data();
-                    for (size_t i = 0; i < MC; ++i) { if (a[i] != b[i]) { ++ndiff; double d = fabs((double)a[i] - b[i]); if (!(d <= maxd)) maxd = d; } }
+                    for (size_t i = 0; i < MC; ++i) { if (!(a[i] == b[i])) { ++ndiff[vi]; double d = fabs((double)a[i] - b[i]); if (!(d <= maxd[vi])) maxd[vi] = d; } }
                 }
-                printf("   vs variant %d: %zu differing, max |diff| %.3g", variants[0], ndiff, maxd);
             }
+        }
+        for (int r = 0; r < rounds; ++r)
+            for (size_t vi = 0; vi < variants.size(); ++vi) {
+                if (!ok[vi]) continue;
+                AC(ac_gemm_set_variant(variants[vi]));
+                run();
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < reps; ++i) run();
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                t[vi].push_back(ms * 1e3 / reps);
+            }
+        for (size_t vi = 0; vi < variants.size(); ++vi) {
+            if (!ok[vi]) { printf("  variant %5d: not built / not applicable (%s)\n", variants[vi], ac_last_error()); continue; }
+            std::sort(t[vi].begin(), t[vi].end());
+            const double med = t[vi][t[vi].size() / 2], mn = t[vi][0];
+            const double tf = 2.0 * sh.M * sh.N * (double)sh.K / (med * 1e-6) / 1e12;
+            printf("  variant %5d: med %8.1f us  min %8.1f us  %6.1f TF fp32-equiv (%.3f of 416.7)", variants[vi], med, mn, tf, tf / 416.7);
+            if (vi > 0) printf("   vs first: %zu differing, max |diff| %.3g", ndiff[vi], maxd[vi]);
             printf("\n");
         }
-        hipFree(A); hipFree(W); hipFree(bias); hipFree(R); hipFree(C0); hipFree(C1); hipFree(Ap); hipFree(Wp); hipFree(Cp0); hipFree(Cp1);
+        fflush(stdout);
+        hipFree(A); hipFree(W); hipFree(bias); hipFree(R); hipFree(C); hipFree(Ap); hipFree(Wp); hipFree(Cp);
     }
     AC(ac_gemm_set_variant(0));
     return 0;
