@@ -103,6 +103,8 @@ _SIGNATURES = {
     "ac_gemm_set_arith": (c_int, [c_int]),
     "ac_gemm_get_arith": (c_int, []),
     "ac_gemm_set_variant": (c_int, [c_int]),
+    "ac_gemm_debug_stamps": (c_int, [c_void_p, c_int64]),
+    "ac_gemm_set_pipe_table": (c_int, [ctypes.c_char_p]),
     "ac_set_persistent_kernels": (c_int, [c_int]),
     "ac_gemm_occupancy": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "ac_split_bf16x3": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),

@@ -207,6 +207,14 @@ int ac_gemm_get_arith(void);
  * >= 1000 = one ring configuration tm * 1000 + wmw * 100 + ring depth * 10 + pipelining (tools/gemm_bench.hip).
  * Env AC_GEMM_VARIANT sets the initial value. */
 int ac_gemm_set_variant(int variant);
+/* Diagnostic: while d_buf is non-null the ring-staged GEMM kernels (gemm_pipe.hip) write 4 shader-clock stamps per
+ * workgroup -- start, ring filled, k-loop done, stores drained -- to d_buf[4 * workgroup] (launches whose grid exceeds
+ * capacity_workgroups skip it).  Used by tools/gemm_bench.hip to see where a launch's time goes. */
+int ac_gemm_debug_stamps(unsigned long long* d_buf, int64_t capacity_workgroups);
+/* Tuning / A-B: "NxK=cfg;NxK=cfg;..." overrides the built-in per-shape choice between the two-buffer tile kernels (cfg 0) and
+ * one ring configuration (cfg as in ac_gemm_set_variant) for planes GEMMs with N output columns and inner dimension K;
+ * "" = two-buffer kernels everywhere; NULL restores the built-in table (tools/encode_ab.py). */
+int ac_gemm_set_pipe_table(const char* spec);
 
 /* The persistent one-launch kernels of the latency-bound ends of the path are chosen automatically when the shape fits;
  * this switch (A/B tests, diagnosis) turns them off or on process-wide.  mask bit 0: ac_head_train_step / _epoch through

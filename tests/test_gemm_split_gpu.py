@@ -209,16 +209,21 @@ def test_fused_geglu_epilogue(cuda_dev, arith):
                                 nv.ptr(U), N, None, M, N, K, 3, st) != 0
 
 
+# every ring configuration gemm_pipe.hip builds: tm * 1000 + wmw * 100 + ring depth * 10 + pipelining
+PIPE_CFGS = [2220, 2230, 2231, 2232, 2241, 2261, 2262, 1220, 1240, 1241, 1281, 1430, 1431, 1461, 2420, 2431, 2441, 2442]
+
+
 @pytest.mark.parametrize("M,N,K,act,res", [
-    (8192, 768, 768, 0, True),      # 192 tiles of 256 x 128 on 256 CUs: every tile is cut between 2-3 workgroups
-    (8192, 2304, 768, 0, False),    # 2.25 tiles per workgroup
-    (8200, 3072, 64, 2, False),     # ragged last row tile, 4 k-stages per tile
-    (4096, 1024, 1024, 0, True),    # 0.5 tile per workgroup
+    (5141, 768, 768, 0, True),      # the attention-output GEMM of the timed batch (ragged last row tile)
+    (1000, 2304, 64, 0, False),     # 4 k-stages: shorter than the deepest ring (over-issued tail stages)
+    (261, 200, 96, 2, False),       # ragged rows AND columns, 6 stages
+    (4096, 3072, 1024, 0, True),    # bert-large width
 ])
-def test_ring_kernel_with_stream_k_cuts_is_fp32_grade(M, N, K, act, res, cuda_dev, arith):
-    """gemm_ring.hip in its stream-K mode (opt-in, ac_gemm_set_variant(2)): tiles cut between workgroups, partial
-    accumulators handed over inside an XCD, owner adds them in a fixed order.  Same fp32-grade bounds as the tile
-    kernels, and deterministic (two runs bit-identical)."""
+def test_ring_staged_kernels_equal_the_two_buffer_kernels_bit_for_bit(M, N, K, act, res, cuda_dev, arith):
+    """gemm_pipe.hip (operand stages in an LDS ring, counted vmcnt, raw barriers, software-pipelined fragment reads): every
+    built configuration computes the SAME six products in the same order per output element as gemm_planes_nt, so the results
+    are bit-identical to the two-buffer kernels (variant 1) -- a stage read before its DMA landed, or overwritten before its
+    last read, would show up here as differing elements -- and fp32-grade against fp64."""
     from adaptive_classifier import _native as nv
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -227,15 +232,18 @@ def test_ring_kernel_with_stream_k_cuts_is_fp32_grade(M, N, K, act, res, cuda_de
     R = rng.standard_normal((M, N)).astype(np.float32) if res else None
     want = _ref(A, W, b, R, act)
     arith(BF16X3)
-    tile = _linear(nv, cuda_dev, A, W, b, R, act, "aw")
-    bound = K * 2.0 ** -24 * (np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T) + 1e-6
-    nv.check(nv.lib().ac_gemm_set_variant(2), "ac_gemm_set_variant")
+    lib = nv.lib()
     try:
-        got = _linear(nv, cuda_dev, A, W, b, R, act, "aw")
-        again = _linear(nv, cuda_dev, A, W, b, R, act, "aw")
+        nv.check(lib.ac_gemm_set_variant(1), "ac_gemm_set_variant")
+        base = _linear(nv, cuda_dev, A, W, b, R, act, "aw")
+        bound = K * 2.0 ** -24 * (np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T) + 1e-6
+        assert np.all(np.abs(base - want) <= bound)
+        for cfg in PIPE_CFGS:
+            nv.check(lib.ac_gemm_set_variant(cfg), "ac_gemm_set_variant")
+            for rep in range(2):                                # (twice: a race would not repeat itself)
+                got = _linear(nv, cuda_dev, A, W, b, R, act, "aw")
+                assert np.array_equal(got, base), (cfg, rep, int((got != base).sum()), float(np.abs(got - base).max()))
+        nv.check(lib.ac_gemm_set_variant(0), "ac_gemm_set_variant")      # the default dispatch (per-shape choice)
+        assert np.array_equal(_linear(nv, cuda_dev, A, W, b, R, act, "aw"), base)
     finally:
-        nv.lib().ac_gemm_set_variant(0)
-    es = np.abs(got - want)
-    assert np.all(es <= bound), (es.max(), bound.min())
-    assert es.max() <= 1.5 * np.abs(tile - want).max() + 1e-7
-    assert np.array_equal(got, again)                       # fixed summation order: deterministic
+        lib.ac_gemm_set_variant(0)

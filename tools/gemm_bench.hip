@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "../include/acamd.h"
@@ -93,6 +94,41 @@ int main(int argc, char** argv) {
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 t[vi].push_back(ms * 1e3 / reps);
             }
+        static const bool want_stamps = getenv("GEMM_BENCH_STAMPS") != nullptr;
+        std::vector<std::string> stamp_line(variants.size());
+        if (want_stamps) {
+            const int64_t cap = 1 << 16;
+            unsigned long long* d_st; CK(hipMalloc(&d_st, cap * 4 * sizeof(unsigned long long)));
+            std::vector<unsigned long long> h(cap * 4);
+            for (size_t vi = 0; vi < variants.size(); ++vi) {
+                if (!ok[vi] || variants[vi] < 1000) continue;
+                AC(ac_gemm_set_variant(variants[vi]));
+                run(); run();
+                CK(hipMemsetAsync(d_st, 0, cap * 4 * sizeof(unsigned long long), st));
+                AC(ac_gemm_debug_stamps(d_st, cap));
+                run();
+                CK(hipStreamSynchronize(st));
+                AC(ac_gemm_debug_stamps(nullptr, 0));
+                CK(hipMemcpy(h.data(), d_st, cap * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                std::vector<double> pro, loop, epi, t0s, t3s;
+                unsigned long long mn = ~0ull, mx = 0;
+                for (int64_t b = 0; b < cap; ++b) {
+                    const unsigned long long* q = &h[b * 4];
+                    if (!q[0] || !q[3]) continue;
+                    pro.push_back((double)(q[1] - q[0])); loop.push_back((double)(q[2] - q[1])); epi.push_back((double)(q[3] - q[2]));
+                    mn = std::min(mn, q[0]); mx = std::max(mx, q[3]);
+                }
+                if (pro.empty()) continue;
+                for (int64_t b = 0; b < cap; ++b) { const unsigned long long* q = &h[b * 4]; if (q[0] && q[3]) { t0s.push_back((double)(q[0] - mn)); t3s.push_back((double)(mx - q[3])); } }
+                auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+                auto p95 = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[(size_t)(v.size() * 0.95)]; };
+                char buf[512];
+                snprintf(buf, sizeof buf, "      stamps (shader cycles, %zu workgroups): span %.0f | median prologue %.0f  k-loop %.0f  epilogue %.0f | start p95 %.0f  early-finish p95 %.0f",
+                         pro.size(), (double)(mx - mn), med(pro), med(loop), med(epi), p95(t0s), p95(t3s));
+                stamp_line[vi] = buf;
+            }
+            hipFree(d_st);
+        }
         for (size_t vi = 0; vi < variants.size(); ++vi) {
             if (!ok[vi]) { printf("  variant %5d: not built / not applicable (%s)\n", variants[vi], ac_last_error()); continue; }
             std::sort(t[vi].begin(), t[vi].end());
@@ -101,6 +137,7 @@ int main(int argc, char** argv) {
             printf("  variant %5d: med %8.1f us  min %8.1f us  %6.1f TF fp32-equiv (%.3f of 416.7)", variants[vi], med, mn, tf, tf / 416.7);
             if (vi > 0) printf("   vs first: %zu differing, max |diff| %.3g", ndiff[vi], maxd[vi]);
             printf("\n");
+            if (!stamp_line[vi].empty()) printf("%s\n", stamp_line[vi].c_str());
         }
         fflush(stdout);
         hipFree(A); hipFree(W); hipFree(bias); hipFree(R); hipFree(C); hipFree(Ap); hipFree(Wp); hipFree(Cp);
