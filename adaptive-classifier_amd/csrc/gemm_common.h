@@ -65,15 +65,16 @@ __device__ __forceinline__ float fast_epilogue(float acc, float bias, float res)
 __device__ __forceinline__ int acc_row32(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // shared epilogue of the LDS-tiled kernels: the 32x32 C/D layout (lane owns column lane & 31, 16 rows)
-template <int EPI, int TM, int BM = 64 * TM>
-__device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][2], float* __restrict__ C, int64_t ldc, int M, int N,
+// (a wave owns TM x TN tiles of 32 x 32: rows m0 + wm * 32 TM ..., columns n0 + wn * 32 TN ...)
+template <int EPI, int TM, int BM = 64 * TM, int TN = 2>
+__device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* __restrict__ C, int64_t ldc, int M, int N,
                                            int m0, int n0, int wm, int wn, int lane, const Epilogue& epi) {
     // epilogue: lane owns column (lane & 31) of each 32x32 tile, 16 rows
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = n0 + wn * (32 * TN) + ni * 32 + (lane & 31);
             if (col >= N) continue;
             const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
             if (EPI == EPI_GENERIC) {
@@ -117,19 +118,20 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][2], float* __restri
 constexpr int kTrLd = 36;                                  // padded row of the 32x32 transpose scratch (floats)
 constexpr int kTrFloats = 32 * kTrLd;                      // per wave
 
-template <int EPI, int TM>
-__device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][2], uint16_t* __restrict__ Cp, int M, int N,
+template <int EPI, int TM, int TN = 2>
+__device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][TN], uint16_t* __restrict__ Cp, int M, int N,
                                                   int m0, int n0, int wm, int wn, int lane, const Epilogue& epi,
                                                   float* scratch /* this wave's kTrFloats floats of LDS */) {
     constexpr bool GLU = EPI == EPI_GEGLU32;
+    static_assert(!GLU || TN == 2, "the fused GeGLU epilogue pairs the two column tiles of a 64-column wave tile");
     const int NO = GLU ? N / 2 : N;                                  // result columns
     const int64_t plane = (int64_t)M * NO;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < (GLU ? 1 : 2); ++ni) {
-            const int c0 = GLU ? n0 / 2 + wn * 32 : n0 + wn * 64 + ni * 32;      // first result column of the tile
-            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);                  // GEMM column of acc[mi][ni]
+        for (int ni = 0; ni < (GLU ? 1 : TN); ++ni) {
+            const int c0 = GLU ? n0 / 2 + wn * 32 : n0 + wn * (32 * TN) + ni * 32;      // first result column of the tile
+            const int col = n0 + wn * (32 * TN) + ni * 32 + (lane & 31);                  // GEMM column of acc[mi][ni]
             const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
             const float bias = col < N ? epi.bias[col] : 0.f;
             const float bias_g = (GLU && col + 32 < N) ? epi.bias[col + 32] : 0.f;

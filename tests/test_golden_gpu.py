@@ -122,7 +122,7 @@ def _golden_classifier(cuda_dev):
     clf.adaptive_head = AdaptiveHead(D, 4, [768, 384]).to(cuda_dev)
     texts = [f"q{i}" for i in range(8)]
     table = {t: torch.from_numpy(q) for t, q in zip(texts, Q)}
-    clf._embed_device = lambda ts: torch.stack([table[t] for t in ts]).to(cuda_dev)
+    clf._embed_device = lambda ts, **kw: torch.stack([table[t] for t in ts]).to(cuda_dev)
     return clf, mem, texts, Q
 
 
@@ -174,7 +174,7 @@ def test_multilabel_inherited_predict_paths_blend_softmax_of_sigmoid(cuda_dev):
     clf.adaptive_head = head.to(cuda_dev).eval()
     clf.default_threshold, clf.min_predictions, clf.max_predictions, clf.label_thresholds = 0.5, 1, None, {}
     table = {t: torch.from_numpy(q) for t, q in zip(texts, Q)}
-    clf._embed_device = lambda ts: torch.stack([table[t] for t in ts]).to(cuda_dev)
+    clf._embed_device = lambda ts, **kw: torch.stack([table[t] for t in ts]).to(cuda_dev)
     for key, want in g["predict_batch"].items():
         for got, w in zip(clf.predict_batch(texts, k=int(key[1:])), want):
             _same_preds(got, w)
