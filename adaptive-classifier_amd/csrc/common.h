@@ -102,14 +102,15 @@ __device__ __forceinline__ int64_t plane_off(int64_t rows, int64_t row, int k) {
 }
 #endif
 
-// knn_batch.hip: bf16x2 operand planes + GEMM-form proposal sweep for batched kNN (used by knn_l2.hip)
-size_t knn_planes_bytes(int64_t rows, int D);      // bytes of the (h, m) planes of a [rows, D] operand (rows padded to 128, D to 16)
-int knn_split2(const float* X, int64_t ldx, int64_t rows, int D, float scale, uint16_t* planes, float* norms,
-               uint32_t* maxnorm_bits, hipStream_t stream);
-int knn_thresholds(const double* sampleD, int kp, const float* Q, int64_t ldQ, int D, int nq, int nq_pad,
-                   const uint32_t* maxnorm_bits, double gamma, float* thr, hipStream_t stream);
+// knn_batch.hip: fp16 operand plane + GEMM-form proposal sweep for batched kNN (used by knn_l2.hip)
+size_t knn_planes_bytes(int64_t rows, int D);      // bytes of the fp16 plane of a [rows, D] operand (rows padded to 256, D to 64)
+double knn_batch_gamma(int D);                     // |sweep value - exact| <= gamma (max|p| + |q|)^2
+int knn_prepare_store(const float* X, int64_t ldx, int64_t rows, int D, uint16_t* plane, float* norms, uint32_t* maxnorm_bits,
+                      hipStream_t stream);
+int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t ldQ, int D, int nq, const uint32_t* maxnorm_bits,
+                        double gamma, uint16_t* qplane, float* thr, float* qfac, hipStream_t stream);
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
-                     float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, hipStream_t stream);
+                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, hipStream_t stream);
 
 // arithmetic of the LDS-tiled GEMMs (ac_gemm_set_arith / env AC_GEMM_ARITH = f32 | bf16x3)
 int gemm_arith();

@@ -404,7 +404,7 @@ struct MergeParams {
     int G;
     int nblk;       // entries of part_maxnorm
     double gamma;   // |sweep value - exact| <= gamma (|p| + |q|)^2: n * 2^-24 for the fp32 fma chain (n roundings per term);
-                    // the bf16x2 GEMM-form sweep adds its split-truncation term (knn_batch.hip)
+                    // the fp16 GEMM-form sweep uses its own bound (knn_batch_gamma, knn_batch.hip)
     // candidate-buffer mode (knn_batch.hip): one list of up to cand_cap entries per query instead of G lists of kp;
     // cand_cnt[q] = entries offered (may exceed cand_cap: overflow -> exact fallback)
     const int32_t* cand_cnt;
@@ -1134,7 +1134,7 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// batched search with a prepared store (bf16x2 planes + row norms): sample -> thresholds -> GEMM-form filter ->
+// batched search with a prepared store (fp16 plane + row norms): sample -> thresholds -> GEMM-form filter ->
 // the same merge / fp64 re-rank / certificate / exact fallback as above (knn_batch.hip explains the scheme)
 // ---------------------------------------------------------------------------------------------------------
 namespace {
@@ -1146,7 +1146,7 @@ constexpr int64_t kBatchMinRows = 65536;
 struct BatchPlan {
     int kp, cap, Dp;
     int64_t stride, S, q_rows;
-    size_t off_sD32, off_sD64, off_sI, off_thr, off_cnt, off_qp, off_cd, off_ci, off_flags, off_fb_d, off_fb_i, off_fb_ctr,
+    size_t off_sD32, off_sD64, off_sI, off_thr, off_qfac, off_cnt, off_qp, off_cd, off_ci, off_flags, off_fb_d, off_fb_i, off_fb_ctr,
         off_sub, sub_bytes, total;
     int fb_S, fb_F;
     size_t merge_lds, fb_lds;
@@ -1169,7 +1169,7 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     while (cap < 2 * expect) cap <<= 1;
     if (cap > 16384) cap = 16384;
     bp->cap = cap;
-    bp->q_rows = ((int64_t)nq + 127) / 128 * 128;
+    bp->q_rows = ((int64_t)nq + 255) / 256 * 256;
     size_t sub = 0;
     int rc = ac_knn_l2_topk_workspace(bp->S, D, nq, bp->kp, &sub);
     if (rc != AC_OK) return rc;
@@ -1180,6 +1180,7 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     bp->off_sD64 = take((size_t)nq * bp->kp * 8);
     bp->off_sI = take((size_t)nq * bp->kp * 8);
     bp->off_thr = take((size_t)bp->q_rows * 4);
+    bp->off_qfac = take((size_t)bp->q_rows * 4);
     bp->off_cnt = take((size_t)bp->q_rows * 4);
     bp->off_qp = take(ac::knn_planes_bytes(nq, D));
     bp->off_cd = take((size_t)bp->q_rows * cap * 4);
@@ -1204,7 +1205,7 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
 extern "C" int ac_knn_store_bytes(int64_t N, int D, size_t* planes_bytes, size_t* norms_bytes) {
     AC_REQUIRE(planes_bytes && norms_bytes && N >= 0 && D >= 1, AC_EINVAL, "knn_store_bytes: bad arguments");
     *planes_bytes = ac::knn_planes_bytes(N, D);
-    *norms_bytes = (size_t)((N + 127) / 128 * 128 + 64) * sizeof(float);
+    *norms_bytes = (size_t)((N + 255) / 256 * 256 + 64) * sizeof(float);      // |p|^2 per row, +inf tile padding, the maximum at [round_up(N, 256)]
     return AC_OK;
 }
 
@@ -1214,9 +1215,9 @@ extern "C" int ac_knn_prepare_store(const float* d_P, int64_t N, int64_t ldP, in
     AC_REQUIRE(d_P && d_planes && d_norms && N >= 1 && D >= 1 && ldP >= D, AC_EINVAL, "knn_prepare_store: bad arguments");
     AC_REQUIRE((((uintptr_t)d_planes) & 15) == 0 && (((uintptr_t)d_norms) & 15) == 0, AC_EINVAL,
                "knn_prepare_store: planes / norms must be 16-byte aligned");
-    const int64_t np = (N + 127) / 128 * 128;
+    const int64_t np = (N + 255) / 256 * 256;
     AC_HIP_CHECK(hipMemsetAsync(d_norms + np, 0, 64 * sizeof(float), stream));          // [np] = max |p|^2 (float bits)
-    return ac::knn_split2(d_P, ldP, N, D, 1.0f, d_planes, d_norms, reinterpret_cast<uint32_t*>(d_norms + np), stream);
+    return ac::knn_prepare_store(d_P, ldP, N, D, d_planes, d_norms, reinterpret_cast<uint32_t*>(d_norms + np), stream);
 }
 
 extern "C" int ac_knn_l2_topk_batch_workspace(int64_t N, int D, int nq, int k, size_t* bytes) {
@@ -1240,29 +1241,25 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     AC_REQUIRE(ldQ >= D && ldP >= bp.Dp && (ldP % 4) == 0 && (((uintptr_t)d_P) & 15) == 0, AC_EINVAL, "knn batch: bad leading dimension / alignment");
     AC_REQUIRE(d_ws && ws_bytes >= bp.total, AC_EWORKSPACE, "knn batch: workspace %zu < required %zu", ws_bytes, bp.total);
     char* ws = (char*)d_ws;
-    const int64_t np = (N + 127) / 128 * 128;
+    const int64_t np = (N + 255) / 256 * 256;
     const uint32_t* d_maxnorm = reinterpret_cast<const uint32_t*>(d_norms + np);
-    // |v - exact| <= gamma (|p| + |q|)^2: 3 Kp + 16 accumulated terms at 2 ulp each (the MFMA's internal summation is
-    // not documented: twice the round-to-nearest bound), the dropped m.m / residual products (3.02 * 2^-16 |p_i||2 q_i| per
-    // term, sum <= 2 |p||q| <= (|p|+|q|)^2 / 2), the rounding of |p|^2 to fp32
-    const int Kp = (D + 15) / 16 * 16;
-    const double gamma = 1.01 * (2.0 * (3.0 * Kp + 16.0) * 5.9604644775390625e-08 + 0.5 * 3.02 * 1.52587890625e-05 + 5.9604644775390625e-08);
+    // |v - exact| <= gamma (max|p| + |q|)^2 for the one-product fp16 sweep (knn_batch.hip; derivation at the declaration of
+    // this entry point in include/acamd.h)
+    const double gamma = ac::knn_batch_gamma(D);
 
     // 1. exact top-k' over the strided sample (rows 0, stride, 2 stride, ...) through the ordinary path
     rc = ac_knn_l2_topk_x(d_P, bp.S, ldP * bp.stride, D, d_Q, nq, ldQ, bp.kp, 0, (float*)(ws + bp.off_sD32),
                           (double*)(ws + bp.off_sD64), (int64_t*)(ws + bp.off_sI), ws + bp.off_sub, bp.sub_bytes, nullptr, stream_);
     if (rc != AC_OK) return rc;
-    // 2. per-query filter thresholds; query planes (-2 q)
-    rc = ac::knn_thresholds((const double*)(ws + bp.off_sD64), bp.kp, d_Q, ldQ, D, nq, (int)bp.q_rows, d_maxnorm, gamma,
-                            (float*)(ws + bp.off_thr), stream);
-    if (rc != AC_OK) return rc;
-    rc = ac::knn_split2(d_Q, ldQ, nq, D, -2.0f, (uint16_t*)(ws + bp.off_qp), nullptr, nullptr, stream);
+    // 2. per query: filter threshold, epilogue factor -2 2^(e_p + e_q), fp16 plane of q 2^-e_q
+    rc = ac::knn_prepare_queries((const double*)(ws + bp.off_sD64), bp.kp, d_Q, ldQ, D, nq, d_maxnorm, gamma,
+                                 (uint16_t*)(ws + bp.off_qp), (float*)(ws + bp.off_thr), (float*)(ws + bp.off_qfac), stream);
     if (rc != AC_OK) return rc;
     AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4, stream));
     // 3. the GEMM-form sweep: candidates (row, v) with v below the query's threshold
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
     rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
-                              (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, stream);
+                              (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, stream);
     if (rc != AC_OK) return rc;
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_stop, stream));
     // 4. merge + exact re-rank + certificate, then the exact fallback for uncertified queries
