@@ -30,8 +30,8 @@ BATCH_MIN_QUERIES, BATCH_MIN_ROWS, BATCH_MAX_K, BATCH_MIN_PAIRS = 64, 65536, 100
 
 
 def prepare_store(P, N, D):
-    """(planes, norms) of the first N rows of the store P for the batched search (`ac_knn_prepare_store`): bf16 (h, m)
-    operand planes + |p|^2 per row.  Costs one pass over the rows and 4 B per element; redo after the rows change."""
+    """(plane, norms) of the first N rows of the store P for the batched search (`ac_knn_prepare_store`): one fp16
+    operand plane + |p|^2 per row.  Costs two passes over the rows and 2 B per element; redo after the rows change."""
     nv.require_gpu()
     pb, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
     nv.check(nv.lib().ac_knn_store_bytes(N, D, ctypes.byref(pb), ctypes.byref(nb)), "ac_knn_store_bytes")
@@ -55,7 +55,7 @@ def knn_l2_topk(P, N, D, Q, k, row_offset=0, out=None, workspace=None, stats=Non
     Returns (dist fp32 [nq,k], ids int64 [nq,k]) on the same device.  Asynchronous.
     exact_out: optional float64 [nq,k] cuda tensor that receives the exact fp64 distances (shard merges).
     prepared: optional (planes, norms) from `prepare_store`: many-query searches then run the GEMM-form proposal
-              sweep on the bf16 pipe (`ac_knn_l2_topk_batch`) -- same exact result, ~3x the throughput.
+              sweep on the fp16 matrix pipe (`ac_knn_l2_topk_batch`) -- same exact result, several times the throughput.
     """
     if prepared is not None and batch_applies(N, Q.shape[0], k):
         return _knn_l2_topk_batch(P, N, D, Q, k, prepared, row_offset, out, workspace, stats, exact_out)

@@ -32,6 +32,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 using namespace acg;
@@ -39,11 +40,7 @@ using namespace acg;
 constexpr int BBM = 256, BBN = 256;          // store rows x queries per workgroup tile
 constexpr int BGA = BBM / 32, BGW = BBN / 32, BRG = BGA + BGW;
 constexpr int BSBK = 32;                      // k per stage: two MFMA chunks of 16
-constexpr int BNS = 4;                        // ring depth
 constexpr int BSLOT = 2 * BRG * 64;           // uint4 per ring slot: [chunk][group][lane] = 32 KB
-constexpr int BPPW = 4;                       // DMA pieces per wave and stage (32 pieces of 1 KB, 8 waves)
-constexpr int kBatchThreads = 512;
-constexpr size_t kBatchLds = (size_t)BNS * BSLOT * 16;
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
@@ -140,11 +137,20 @@ struct BatchParams {
 template <int N> __device__ __forceinline__ void bwait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // C/D layout of v_mfma_f32_32x32x16_f16: lane owns column (lane & 31); acc_row32(r, lane) gives its 16 rows.
-__global__ __launch_bounds__(kBatchThreads, 2) void knn_batch_sweep(BatchParams prm) {
+//   NWV = 8: 4 x 2 waves of 64 x 128 (two per SIMD, <= 256 registers each) -- the shipped form.  Its fragment reads + DMA
+//            writes need ~87 % of the LDS bandwidth at full matrix rate: the LDS, not the matrix pipe, paces this loop
+//            (matrix pipe busy 49 % of the SIMD cycles, profiles/r03/knn_batch_sweep_pmc.json).
+//   NWV = 4: 2 x 2 waves of 128 x 128, ONE per SIMD with the 512-register budget (a third fewer fragment bytes per MFMA):
+//            builds, exact, 1.5x slower under hipcc's schedule -- kept as a template argument, not instantiated.
+template <int BNS, int NWV>                   // ring depth, waves
+__global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams prm) {
+    constexpr int WMW = NWV / 2, TM = BBM / (32 * WMW), TN = 4;    // wave grid WMW x 2, wave tile (32 TM) x 128
+    constexpr int GPW = BGA / NWV;                                  // store / query groups each wave stages
+    constexpr int PPW = 4 * GPW;                                    // DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];    // [BNS][2 chunks][BRG groups][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                        // 4 x 2 waves of 64 rows x 128 queries
+    const int wm = wave >> 1, wn = wave & 1;
     const int i32 = lane & 31, kg = lane >> 5;
     // ---- workgroup -> (query tile, row group) ----
     const int per_xcd = (int)(gridDim.x >> 3), xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -156,101 +162,146 @@ __global__ __launch_bounds__(kBatchThreads, 2) void knn_batch_sweep(BatchParams 
     const int64_t my_tiles = prm.ntiles > g ? (prm.ntiles - 1 - g) / G + 1 : 0;
     if (my_tiles == 0) return;
     const int nk = prm.Kp / BSBK;                                   // even (Kp % 64 == 0)
-    const int64_t units = my_tiles * nk;
 
-    // ---- DMA stream.  Wave w stages store group w and query group w, both chunks: pieces (chunk c, A) and (chunk c, W).
+    // ---- DMA stream.  Wave w stages store groups w + NWV t and query groups w + NWV t, both chunks.
     //      A piece = 32 rows x 2 k-slots: lane (i32, kg) copies the 16 B of row i32, k-slot 4 s + 2 c + kg.
     const int64_t a_step = 4 * prm.p_rows * 8, w_step = 4 * prm.q_rows * 8;
-    auto a_base = [&](int64_t it) -> const uint16_t* {
-        int64_t row = (it * G + g) * BBM + 32 * wave + i32;
-        if (row > prm.N - 1) row = prm.N - 1;
-        return prm.Pp + ((int64_t)kg * prm.p_rows + row) * 8;
-    };
-    const uint16_t* const pw0 = prm.Qp + ((int64_t)kg * prm.q_rows + ((int64_t)qt * BBN + 32 * wave + i32)) * 8;
-    const uint16_t* pa = a_base(0);
-    const uint16_t* pw = pw0;
     const int64_t a_c1 = 2 * prm.p_rows * 8, w_c1 = 2 * prm.q_rows * 8;   // chunk 1 = two k-slots further
+    const uint16_t* pa[GPW];
+    const uint16_t* pw[GPW];
+    auto a_base = [&](int64_t it) {
+#pragma unroll
+        for (int t = 0; t < GPW; ++t) {
+            int64_t row = (it * G + g) * BBM + 32 * (wave + NWV * t) + i32;
+            if (row > prm.N - 1) row = prm.N - 1;
+            pa[t] = prm.Pp + ((int64_t)kg * prm.p_rows + row) * 8;
+        }
+    };
+    auto w_base = [&]() {
+#pragma unroll
+        for (int t = 0; t < GPW; ++t)
+            pw[t] = prm.Qp + ((int64_t)kg * prm.q_rows + ((int64_t)qt * BBN + 32 * (wave + NWV * t) + i32)) * 8;
+    };
+    a_base(0); w_base();
     int64_t st_it = 0; int st_k = 0, st_slot = 0;                   // unit / ring slot the next issue() loads
-    auto issue = [&]() {                                            // always BPPW DMA instructions (exact vmcnt accounting)
+    auto issue = [&]() {                                            // always PPW DMA instructions (exact vmcnt accounting)
         uint4* dst = lds + st_slot * BSLOT;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)pa, (lds_void_t*)(dst + (0 * BRG + wave) * 64), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)pw, (lds_void_t*)(dst + (0 * BRG + BGA + wave) * 64), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + a_c1), (lds_void_t*)(dst + (1 * BRG + wave) * 64), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(pw + w_c1), (lds_void_t*)(dst + (1 * BRG + BGA + wave) * 64), 16, 0, 0);
+#pragma unroll
+        for (int t = 0; t < GPW; ++t) {
+            const int ga = wave + NWV * t;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)pa[t], (lds_void_t*)(dst + (0 * BRG + ga) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)pw[t], (lds_void_t*)(dst + (0 * BRG + BGA + ga) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(pa[t] + a_c1), (lds_void_t*)(dst + (1 * BRG + ga) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(pw[t] + w_c1), (lds_void_t*)(dst + (1 * BRG + BGA + ga) * 64), 16, 0, 0);
+        }
         st_slot = st_slot + 1 == BNS ? 0 : st_slot + 1;
         if (++st_k == nk) {
             st_k = 0;
             if (st_it + 1 < my_tiles) ++st_it;                      // past the end: the last tile again (never consumed)
-            pa = a_base(st_it); pw = pw0;
-        } else { pa += a_step; pw += w_step; }
+            a_base(st_it); w_base();
+        } else {
+#pragma unroll
+            for (int t = 0; t < GPW; ++t) { pa[t] += a_step; pw[t] += w_step; }
+        }
     };
 
-    // thresholds / epilogue factors of this lane's four query columns (constant over the workgroup's row tiles)
-    float thr[4], qf[4];
-    int qcol[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        qcol[ni] = qt * BBN + wn * 128 + ni * 32 + i32;
-        thr[ni] = prm.thr[qcol[ni]];
-        qf[ni] = prm.qfac[qcol[ni]];
-    }
+    // this lane's four query columns (their thresholds / epilogue factors are re-read per tile: registers are scarce)
+    const int qcol0 = qt * BBN + wn * 128 + i32;                    // column ni = qcol0 + 32 ni
 
-    f32x16 acc[2][4];
+    f32x16 acc[TM][TN];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     };
-    struct Frags { f16x8_t a[2][2], b[2][4]; };                    // [chunk][tile]
+    struct Frags { f16x8_t a[2][TM], b[2][TN]; };                  // [chunk][tile]
     auto read_frags = [&](Frags& F, int slot) {
         const uint4* base = lds + slot * BSLOT + lane;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) F.a[c][a] = __builtin_bit_cast(f16x8_t, base[(c * BRG + 2 * wm + a) * 64]);
+            for (int a = 0; a < TM; ++a) F.a[c][a] = __builtin_bit_cast(f16x8_t, base[(c * BRG + TM * wm + a) * 64]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) F.b[c][b] = __builtin_bit_cast(f16x8_t, base[(c * BRG + BGA + 4 * wn + b) * 64]);
+            for (int b = 0; b < TN; ++b) F.b[c][b] = __builtin_bit_cast(f16x8_t, base[(c * BRG + BGA + TN * wn + b) * 64]);
         }
     };
     auto mfmas = [&](const Frags& F) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[c][a], F.b[c][b], acc[a][b], 0, 0, 0);
     };
-    // tile done: v = |p|^2 + f_q acc; keep what beats the query's threshold
+    // tile done: v = |p|^2 + f_q acc; keep what beats the query's threshold.  Two passes, so that a wave waits for memory
+    // ONCE per tile: (1) a bit mask of the qualifying elements per query column and their count -- no memory operations;
+    // (2) one slot reservation (atomicAdd) per query column with candidates, issued back to back, then the stores.
     int64_t it = 0;
     auto filter = [&]() {
-        const int64_t row0 = (it * G + g) * BBM + wm * 64;
+        const int64_t row0 = (it * G + g) * BBM + wm * (32 * TM);
+        // rows (r & 3) + 8 (r >> 2) + 4 kg of a 32-row tile: four runs of 4 norms (the array is padded to whole tiles with
+        // +inf: rows past N never qualify)
+        auto load_pn = [&](int mi, float (&pn)[16]) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            float pn[16];
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {                        // rows (r & 3) + 8 (r >> 2) + 4 kg: four runs of 4
-                // (the norms array is padded to whole tiles with +inf: rows past N never qualify)
+            for (int r4 = 0; r4 < 4; ++r4) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(prm.pnorm + row0 + mi * 32 + 8 * r4 + 4 * kg);
                 pn[4 * r4] = t.x; pn[4 * r4 + 1] = t.y; pn[4 * r4 + 2] = t.z; pn[4 * r4 + 3] = t.w;
             }
+        };
+        float thr[4], qf[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { thr[ni] = prm.thr[qcol0 + 32 * ni]; qf[ni] = prm.qfac[qcol0 + 32 * ni]; }
+        unsigned mask[TM / 2][4];                                   // bit 16 (mi & 1) + r of query column ni, row tiles 2 h, 2 h + 1
+        unsigned any = 0;
+#pragma unroll
+        for (int h = 0; h < TM / 2; ++h) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) mask[h][ni] = 0u;
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                float pn[16];
+                load_pn(2 * h + m2, pn);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        mask[h][ni] |= (fmaf(acc[2 * h + m2][ni][r], qf[ni], pn[r]) < thr[ni] ? 1u : 0u) << (16 * m2 + r);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) any |= mask[h][ni];
+        }
+        if (__builtin_amdgcn_ballot_w64(any != 0) == 0) return;    // (whole wave: nothing kept)
+        int base[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            int c = 0;
+#pragma unroll
+            for (int h = 0; h < TM / 2; ++h) c += __builtin_popcount(mask[h][ni]);
+            base[ni] = c ? atomicAdd(&prm.cand_cnt[qcol0 + 32 * ni], c) : 0;
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            unsigned here = 0;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) here |= mask[mi / 2][ni] >> (16 * (mi & 1)) & 0xffffu;
+            if (here == 0) continue;
+            float pn[16];
+            load_pn(mi, pn);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float val = fmaf(acc[mi][ni][r], qf[ni], pn[r]);
-                    if (val < thr[ni]) {
-                        const int64_t row = row0 + mi * 32 + acc_row32(r, lane);
-                        const int slot = atomicAdd(&prm.cand_cnt[qcol[ni]], 1);
+                for (int r = 0; r < 16; ++r)
+                    if ((mask[mi / 2][ni] >> (16 * (mi & 1) + r)) & 1u) {
+                        const int slot = base[ni]++;
                         if (slot < prm.cap) {
-                            prm.cand_d[(size_t)qcol[ni] * prm.cap + slot] = val;
-                            prm.cand_i[(size_t)qcol[ni] * prm.cap + slot] = (int32_t)row;
+                            prm.cand_d[(size_t)(qcol0 + 32 * ni) * prm.cap + slot] = fmaf(acc[mi][ni][r], qf[ni], pn[r]);
+                            prm.cand_i[(size_t)(qcol0 + 32 * ni) * prm.cap + slot] = (int32_t)(row0 + mi * 32 + acc_row32(r, lane));
                         }
                     }
-                }
         }
     };
 
@@ -258,33 +309,46 @@ __global__ __launch_bounds__(kBatchThreads, 2) void knn_batch_sweep(BatchParams 
     zero_acc();
 #pragma unroll
     for (int s = 0; s < BNS - 1; ++s) issue();
-    bwait_vm<(BNS - 2) * BPPW>();
+    bwait_vm<(BNS - 2) * PPW>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     Frags F0, F1;
-    read_frags(F0, 0);
-    int slot = 1, kt = 0;                                           // ring slot of stage u + 1
-#define AC_KNN_STEP(FC, FN)                                                                                      \
+    int slot = 0;                                                   // ring slot of the next stage to read
+    // One step = one 32-k stage u: this wave's DMA pieces of stage u + 1 have landed -> barrier (everyone's have; the MFMAs
+    // of stage u - 1 are issued) -> DMA of stage u + BNS - 1 into the slot stage u - 1 used -> fragments of stage u + 1 ->
+    // the MFMAs of stage u with the fragment reads pinned between them.  The LAST stage of a row tile reads no
+    // fragments: the filter runs with only the accumulators live (a spill reload pending at the loop's back edge made hipcc
+    // wait vmcnt(0) -- the whole DMA ring -- inside the loop), and the next tile's first fragments are read after it.
+    constexpr int NREAD = 2 * (TM + TN), NMFMA = 2 * TM * TN, MPR = NMFMA / NREAD;
+#define AC_KNN_STEP(FC, FN, READ_NEXT)                                                                           \
     do {                                                                                                         \
-        bwait_vm<(BNS - 3) * BPPW>();                    /* this wave's pieces of stage u + 1 have landed */      \
+        bwait_vm<(BNS - 3) * PPW>();                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
-        __builtin_amdgcn_s_barrier();                    /* ... everyone's; the MFMAs of stage u - 1 are issued */ \
+        __builtin_amdgcn_s_barrier();                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
-        issue();                                         /* stage u + BNS - 1 -> the slot stage u - 1 used */     \
-        read_frags(FN, slot);                            /* fragments of stage u + 1 */                           \
-        slot = slot + 1 == BNS ? 0 : slot + 1;                                                                   \
-        mfmas(FC);                                       /* stage u */                                            \
-        _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {   /* 16 MFMAs, 12 fragment reads: one read after each MFMA */ \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
+        issue();                                                                                                 \
+        if (READ_NEXT) { read_frags(FN, slot); slot = slot + 1 == BNS ? 0 : slot + 1; }                          \
+        mfmas(FC);                                                                                               \
+        if (READ_NEXT) {                                                                                         \
+            _Pragma("unroll") for (int g_ = 0; g_ < NREAD; ++g_) {                                               \
+                __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);                                             \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+            }                                                                                                    \
         }                                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                       \
-        if (++kt == nk) { filter(); zero_acc(); kt = 0; ++it; }                                                  \
     } while (0)
-    for (int64_t u = 0; u < units; u += 2) {                        // (units is even: nk is)
-        AC_KNN_STEP(F0, F1);
-        AC_KNN_STEP(F1, F0);
+    for (; it < my_tiles; ++it) {
+        read_frags(F0, slot);                                       // stage 0 of this tile (landed: waited for one step ago)
+        slot = slot + 1 == BNS ? 0 : slot + 1;
+        for (int kt = 0; kt < nk - 2; kt += 2) {                    // (nk is even)
+            AC_KNN_STEP(F0, F1, true);
+            AC_KNN_STEP(F1, F0, true);
+        }
+        AC_KNN_STEP(F0, F1, true);
+        AC_KNN_STEP(F1, F0, false);
+        __builtin_amdgcn_sched_barrier(0);
+        filter();
+        zero_acc();
     }
 #undef AC_KNN_STEP
     bwait_vm<0>();                                                  // the over-issued tail stages must land before LDS is released
@@ -333,9 +397,14 @@ int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t l
 
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
                      const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, hipStream_t stream) {
+    // (measured and dropped, profiles/r03/knn_batch_probe*.txt: a ring of 5 slots -- no change, the DMA depth is not the limit;
+    //  2 x 2 waves of 128 x 128 with the 512-register budget, one wave per SIMD -- 120 vs 80 ms at 4096 x 10M: hipcc shuffles
+    //  ~200 accumulator registers per iteration and a lone wave per SIMD hides nothing)
+    constexpr int ns = 4, nwv = 8;
+    const size_t lds = (size_t)ns * BSLOT * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBatchLds));
+        AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     BatchParams p;
@@ -362,7 +431,8 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
         p.Qp = Qp + qoff * 8;                                       // plane[k/8][q_rows][8]: tile t0 starts at row t0 * 256 of every k-slot
         p.thr = thr + qoff; p.qfac = qfac + qoff;
         p.cand_d = cand_d + qoff * cap; p.cand_i = cand_i + qoff * cap; p.cand_cnt = cand_cnt + qoff;
-        hipLaunchKernelGGL(knn_batch_sweep, dim3((unsigned)nblk), dim3(kBatchThreads), kBatchLds, stream, p);
+        const dim3 grid((unsigned)nblk), block(64 * nwv);
+        hipLaunchKernelGGL((knn_batch_sweep<ns, nwv>), grid, block, lds, stream, p);
         AC_LAUNCH_CHECK();
     }
     return AC_OK;

@@ -202,7 +202,7 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
     if full:
         nqb = 4096
         Qb = ix.synth_unit_rows(nqb, DIM, 2, device=dev)
-        prep = ix.prepare_store(P, n_rows, DIM)        # bf16 (h, m) planes + row norms, once per store
+        prep = ix.prepare_store(P, n_rows, DIM)        # fp16 plane + row norms, once per store
         wsb = torch.empty(ix.knn_batch_workspace_bytes(n_rows, DIM, nqb, k), dtype=torch.uint8, device=dev)
         stb = torch.zeros(4, dtype=torch.int32, device=dev)
         outb = (torch.empty((nqb, k), dtype=torch.float32, device=dev), torch.empty((nqb, k), dtype=torch.int64, device=dev))
@@ -215,7 +215,7 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
         b1.record(); torch.cuda.synchronize()
         bms = b0.elapsed_time(b1) / 2
         batch = {"workload": "BASELINE configs[2] on ONE GPU: %d x %d store, k=%d, batch %d" % (n_rows, DIM, k, nqb),
-                 "path": "prepared store: bf16x2 GEMM-form proposals (3 MFMA products) + fp64 re-rank / certificate (ac_knn_l2_topk_batch)",
+                 "path": "prepared store: fp16 GEMM-form proposals (one MFMA product) + fp64 re-rank / certificate (ac_knn_l2_topk_batch)",
                  "ms_per_batch": bms, "queries_per_s": nqb / bms * 1e3, "TFLOPs_fp32_equiv": 2.0 * nqb * n_rows * DIM / bms / 1e9,
                  "exact_fallback_queries": int(stb[0].item()),
                  "ids_equal_fp32_sweep_subset": bool(torch.equal(outb[1][:16], out16_ids)) if out16_ids is not None else None}

@@ -101,12 +101,18 @@ int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
 /*
  * Batched search over a PREPARED store (many queries: predict_batch, BASELINE configs[2] / [4]).  Same result
  * contract as ac_knn_l2_topk_x -- the ids are the exact top-k, bit for bit -- but the proposal sweep runs as a
- * GEMM on the bf16 matrix pipe (three split products, 3/16 of the fp32-input MFMA time; knn_batch.hip) and only
- * the re-rank / certificate / fallback stay in fp64.
+ * GEMM on the matrix pipe over ONE fp16 plane per operand (one v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block;
+ * knn_batch.hip) and only the re-rank / certificate / fallback stay in fp64.
  *   ac_knn_store_bytes       sizes of the two auxiliary buffers of a store of N rows
- *   ac_knn_prepare_store     fills them from the fp32 rows: d_planes = bf16 (h, m) planes, k-slot-major;
- *                            d_norms = |p|^2 per row (+ the maximum at [round_up(N,128)]).  Redo after any row changes.
+ *   ac_knn_prepare_store     fills them from the fp32 rows: d_planes = fp16(p 2^-e_p), k-slot-major [K/8][rows][8] with
+ *                            rows padded to 256 and K to 64, 2^e_p > max |p|; d_norms = |p|^2 per row, +inf on the
+ *                            padding rows, the maximum at [round_up(N, 256)].  Redo after any row changes.
  *   ac_knn_l2_topk_batch     N >= 65536, k <= 100 (AC_EUNSUPPORTED otherwise: use ac_knn_l2_topk_x); d_stats as above
+ * Error bound of the proposal value v = |p|^2 - 2 p.q used by the filter and the certificate (unit = (max|p| + |q|)^2):
+ *   operands scaled into the unit ball (p^ = p 2^-e_p, q^ = q 2^-e_q, per-query e_q) and rounded to nearest fp16:
+ *   |x^ - h| <= 2^-11 |x^| + 2^-25, so |p^.q^ - h_p.h_q| <= 2^-10 (1 + 2^-10) |p^||q^| + 2^-25 sqrt(K) (|p^| + |q^|);
+ *   fp16 products are exact in the fp32 accumulator, whose K + 16 additions are charged 2 ulp each; times 2 2^(e_p+e_q),
+ *   plus the roundings of |p|^2 and of the final fma:  gamma = 1.01 (2^-11 + (K + 18 + sqrt K) 2^-24).
  */
 int ac_knn_store_bytes(int64_t N, int D, size_t* planes_bytes, size_t* norms_bytes);
 int ac_knn_prepare_store(const float* d_P, int64_t N, int64_t ldP, int D,

@@ -1,18 +1,22 @@
-"""Scratch probe for rocprofv3 --pmc: a few launches of the planes GEMM (both operands pre-split) on one shape."""
+"""Scratch probe for rocprofv3 --pmc: a few launches of the planes GEMM (both operands pre-split) on one shape
+(M,N,K[,act,res,cplanes]) through the default dispatch."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "adaptive-classifier_amd")]
 import torch
 from adaptive_classifier import _native as nv
 dev = torch.device("cuda:0"); lib = nv.lib()
-M, N, K = (int(x) for x in sys.argv[1].split(","))
+v = [int(x) for x in sys.argv[1].split(",")] + [0, 0, 0]
+M, N, K, act, res, cpl = v[:6]
 lib.ac_gemm_set_arith(1)
-A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) / K ** .5; b = torch.randn(N, device=dev)
+A = torch.rand(M, K, device=dev) * 2 - 1; W = (torch.rand(N, K, device=dev) * 2 - 1) * 0.05; b = torch.randn(N, device=dev)
+R = torch.randn(M, N, device=dev) if res else None
 C = torch.empty(M, N, device=dev)
+Cp = torch.empty(3 * M * N, dtype=torch.int16, device=dev) if cpl else None
 Wp = torch.empty(3 * N * K, dtype=torch.int16, device=dev); Ap = torch.empty(3 * M * K, dtype=torch.int16, device=dev)
 st = nv.stream_ptr(dev)
 lib.ac_split_bf16x3(nv.ptr(W), K, N, K, nv.ptr(Wp), st); lib.ac_split_bf16x3(nv.ptr(A), K, M, K, nv.ptr(Ap), st)
-for _ in range(4):
-    nv.check(lib.ac_linear_bf16x3(nv.ptr(A), K, nv.ptr(Ap), nv.ptr(W), K, nv.ptr(Wp), nv.ptr(b), None, N, nv.ptr(C), N, None,
-                                  M, N, K, 0, st), "lin")
+for _ in range(6):
+    nv.check(lib.ac_linear_bf16x3(nv.ptr(A), K, nv.ptr(Ap), nv.ptr(W), K, nv.ptr(Wp), nv.ptr(b), nv.ptr(R) if res else None, N,
+                                  None if cpl else nv.ptr(C), N, nv.ptr(Cp) if cpl else None, M, N, K, act, st), "lin")
 torch.cuda.synchronize()
