@@ -23,6 +23,12 @@ roofline the kNN distance sweep in its HBM-bound regime (the north star's roofli
          157.3 TFLOP/s peak) and reported as config.value_f32_mfma.
 cpu_baseline  the oracle port of the same predict() step (transformers BertModel fp32 on torch-CPU +
          C fp32 brute-force kNN + torch head) on the host cores, on a bounded sample, rank 0, N = 1 only.
+extras   (N = 1, outside the timed region of `value`; --no-extras skips them) the other BASELINE configs in reduced form,
+         so that one default run measures every config: `predict_from_text` (predict_batch on raw strings, tokenisation
+         included, device WordPiece vs host tokenizer), `latency_ms_b1` (one predict() of one 16-token text + its CPU port),
+         `cfg4` (configs[4] on one GPU: e5-large-v2 architecture, 2M x 1024 store, batch 1024, 5 steps, parity on 8 queries),
+         `add_examples` (configs[3] at 6000 examples, as-wired EWC mode).  `--config latency | cfg4 | add_examples` run
+         them at full size as their own JSON lines.
 """
 import argparse
 import json
@@ -295,7 +301,7 @@ def sharded_cfg2(dev, rank, world, total_rows, batch=4096, k=32, reps=3):
             "ms_per_batch": dt / reps * 1e3, "queries_per_s": b * world * reps / dt, "rows_per_gpu": hi - lo}
 
 
-def bench_cfg4(dev, args):
+def measure_cfg4(dev, args, steps=None, warmup=None, parity_queries=16):
     """BASELINE configs[4] end to end on ONE GPU: e5-large-v2 architecture (= BERT-large: 24 layers, 1024 hidden, 16 heads,
     4096 intermediate; random init, no weights offline), 2M x 1024 prototype store, 64 classes (row % 64), batch 1024,
     k = 32, S = 32.  Same step as the headline: encode -> kNN -> head -> blend -> Python result lists."""
@@ -321,12 +327,14 @@ def bench_cfg4(dev, args):
     lens = torch.randint(8, S + 1, (B,), generator=g); lens[0] = S
     mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64)
     ids = (ids * mask).to(dev); mask = mask.to(dev); types = torch.zeros_like(ids)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     step = lambda: clf.predict_embeddings(clf.model.encode_cls(ids, types, mask), k=K_)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         preds = step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         preds = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -337,28 +345,34 @@ def bench_cfg4(dev, args):
     parity = None
     if not args.no_parity:
         from oracle import c_oracle
-        sel = np.arange(0, B, 64)
+        sel = np.arange(0, B, max(1, B // parity_queries))
         chunks = ((s, rows[s:min(NP_, s + 500_000), :D].cpu().numpy()) for s in range(0, NP_, 500_000))
         oD, oI = c_oracle.knn_l2_topk_chunked(chunks, emb[:, :D].cpu().numpy()[sel], K_)
         want = torch.nn.functional.normalize(hf(input_ids=ids[:4].cpu(), token_type_ids=types[:4].cpu(),
                                                 attention_mask=mask[:4].cpu()).last_hidden_state[:, 0, :], dim=1)
         parity = {"checked_queries": int(len(sel)), "id_mismatches": int((I_.cpu().numpy()[sel] != oI).sum()),
                   "encoder_max_abs_diff_vs_transformers_fp32": float((emb[:4].cpu() - want.detach()).abs().max())}
-    print(json.dumps({
-        "metric": "predict() queries/sec + kNN GB/s vs HBM roofline, 768-d", "value": B * args.steps / dt, "unit": "queries/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+    lens_h = mask.sum(1).double().cpu()
+    enc_flops = enc.flops(B, S, tokens=float(lens_h.sum()), sum_len_sq=float((lens_h ** 2).sum())) if enc.last_tokens < B * S else enc.flops(B, S)
+    del rows, clf, enc
+    torch.cuda.empty_cache()
+    return {
+        "metric": "predict() queries/sec + kNN GB/s vs HBM roofline, 768-d", "value": B * steps / dt, "unit": "queries/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[4] on ONE GPU (the config names 4): e5-large-v2 architecture (BERT-large, random "
                                "init), 1024-d, 2M prototypes, 64 classes, batch=1024, k=32, S=32, end-to-end predict()",
                    "batch_per_gpu": B, "seq_len": S, "prototypes": NP_, "dim": D, "k": K_, "classes": C, "parallelism": "dp1"},
         "stages_ms": {"encode_ms": ev[0].elapsed_time(ev[1]), "knn_ms": ev[1].elapsed_time(ev[2])},
-        "roofline_encoder": {"bound": "mfma", "achieved": enc.flops(B, S) / ev[0].elapsed_time(ev[1]) / 1e9,
+        "roofline_encoder": {"bound": "mfma", "achieved": enc_flops / ev[0].elapsed_time(ev[1]) / 1e9,
                              "peak": BF16_MFMA_PEAK_TF / 6.0, "unit": "TFLOP/s",
-                             "frac": enc.flops(B, S) / ev[0].elapsed_time(ev[1]) / 1e9 / (BF16_MFMA_PEAK_TF / 6.0)},
-        "parity": parity}), flush=True)
+                             "frac": enc_flops / ev[0].elapsed_time(ev[1]) / 1e9 / (BF16_MFMA_PEAK_TF / 6.0),
+                             "note": "executed FLOPs (padding tokens left out, last layer on the CLS rows) against the fp32-equivalent "
+                                     "bf16x3 ceiling 2500 / 6"},
+        "parity": parity}
 
 
-def bench_add_examples(dev, args):
+def measure_add_examples(dev, args, n=None, modes=("as_wired", "intended"), with_cpu=None):
     """BASELINE configs[3]: the add_examples() continuous-learning loop on one GPU.  50 000 pre-computed unit-norm 768-d
     embeddings (class centroid + 0.5 noise, 4 classes) fed in chunks of 32 through add_embeddings (= add_examples after
     the encoder call), max_examples_per_class = 1000; every call updates the memory (device prune), retrains the head on
@@ -371,7 +385,8 @@ def bench_add_examples(dev, args):
     class _NoEncoder:                      # the loop is fed embeddings; the encoder is bypassed
         config = _Cfg(DIM, "precomputed-embeddings")
 
-    n, C = args.examples, 4
+    n, C = (args.examples if n is None else n), 4
+    with_cpu = (not getattr(args, "no_cpu_baseline", False)) if with_cpu is None else with_cpu
     cent = ix.synth_unit_rows(C + 1, DIM, 3, device=dev)[:, :DIM]
     noise = ix.synth_unit_rows(n + 64, DIM, 4, device=dev)[:, :DIM]
     cls = torch.arange(n + 64, device=dev) % C
@@ -384,7 +399,7 @@ def bench_add_examples(dev, args):
         wclf.add_embeddings([f"w{i}" for i in range(s, s + 32)], [E[i] for i in range(s, s + 32)], [f"c{i % C}" for i in range(s, s + 32)])
     wclf.add_embeddings([f"wn{i}" for i in range(8)], [E[n + i] for i in range(8)], ["znew"] * 8)
     del wclf
-    for mode in ("as_wired", "intended"):
+    for mode in modes:
         clf = AdaptiveClassifier("precomputed", device=str(dev), config={"ewc_mode": mode}, encoder=_NoEncoder(), tokenizer=None)
         T = {"memory": 0.0, "train": 0.0, "rebuild": 0.0}
 
@@ -420,7 +435,7 @@ def bench_add_examples(dev, args):
     # on the host cores, a bounded sample of the same steps; the loop's examples/s would be steps/s x (examples per step of
     # the GPU run) if nothing else cost anything
     cpu = None
-    if not getattr(args, "no_cpu_baseline", False):
+    if with_cpu:
         from oracle import c_oracle, head_oracle
         cores = c_oracle.usable_cores()
         torch.set_num_threads(cores)
@@ -438,7 +453,7 @@ def bench_add_examples(dev, args):
         cpu = {"value": nst / dtc * (n / max(1, headline["train_steps"])), "unit": "examples/s", "cores": int(torch.get_num_threads()), "kind": "port",
                "steps_per_s": nst / dtc, "sample": f"{nst} reference training steps (batch 32, torch CPU) in {dtc:.1f} s; value = steps/s x "
                f"examples per training step of the GPU run ({n}/{headline['train_steps']}), memory bookkeeping not charged"}
-    print(json.dumps({
+    return {
         "metric": "add_examples() examples/sec (continuous-learning loop)", "value": headline["examples_per_s"], "unit": "examples/s",
         "n_gpus": 1, "steps": headline["train_steps"], "warmup": 0, "ms_per_step": headline["seconds"] / max(1, headline["train_steps"]) * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -452,14 +467,15 @@ def bench_add_examples(dev, args):
                      "note": "the step is a chain of dependent phases (3 grid barriers + 3 dependent cross-CU reads per step, ~28 us); "
                              "its algorithmic traffic (36 B/param = 32 MB/step) would take 4 us at the HBM peak and never leaves LDS here"},
         "cpu_baseline": cpu,
-        "modes": out}), flush=True)
+        "modes": out}
 
 
-def bench_latency(dev, args, S=16, reps=200):
+def measure_latency(dev, args, S=16, reps=200, made=None, with_cpu=None, cpu_seconds=10.0):
     """Single predict() latency: one text of S tokens (ids given: tokenisation excluded like everywhere in this file) ->
     encoder (one persistent launch, bert_small.hip) -> kNN over the configs[1] store (100k x 768) -> head -> blend -> the
     reference's [(label, score)] list on the host.  cpu_baseline: the same single query through the CPU port."""
-    clf, hf = make_classifier(dev, 0, 1)
+    clf, hf = made if made is not None else make_classifier(dev, 0, 1)
+    with_cpu = (not args.no_cpu_baseline) if with_cpu is None else with_cpu
     g = torch.Generator().manual_seed(5)
     ids = torch.randint(1000, VOCAB, (1, S), generator=g); ids[:, 0] = 101
     ids_d = ids.to(dev)
@@ -482,7 +498,7 @@ def bench_latency(dev, args, S=16, reps=200):
     e1.record(); torch.cuda.synchronize()
     enc_ms = e0.elapsed_time(e1) / reps
     cpu = None
-    if not args.no_cpu_baseline:
+    if with_cpu:
         from oracle import c_oracle, head_oracle
         cores = c_oracle.usable_cores()
         torch.set_num_threads(cores); c_oracle.set_threads(cores)
@@ -499,11 +515,11 @@ def bench_latency(dev, args, S=16, reps=200):
         for _ in range(3):
             cpu_one()
         t0 = time.perf_counter(); n = 0
-        while time.perf_counter() - t0 < 10.0:
+        while time.perf_counter() - t0 < cpu_seconds:
             cpu_one(); n += 1
         cpu = {"value": (time.perf_counter() - t0) / n * 1e3, "unit": "ms", "cores": int(torch.get_num_threads()), "kind": "port",
                "sample": f"{n} single queries: transformers BertModel fp32 (torch CPU) + C fp32 brute-force kNN over {NPROTO}x{DIM} + torch head"}
-    print(json.dumps({
+    return {
         "metric": "single predict() latency (one text, %d tokens)" % S, "value": dt * 1e3, "unit": "ms", "n_gpus": 1, "steps": reps,
         "warmup": 10, "ms_per_step": dt * 1e3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
@@ -516,7 +532,65 @@ def bench_latency(dev, args, S=16, reps=200):
                      "note": "60 dependent phase boundaries of ~3.5 us inside the encoder launch + ~10 launches after it; the 340 MB of "
                              "fp32 encoder weights stream once (43 us at the HBM peak), the 307 MB store once (38 us)"},
         "cpu_baseline": cpu, "reference_published": {"pytorch_cpu_ms": 8.3, "onnx_cpu_ms": 2.1, "source": "reference README.md:256-261, hardware unspecified"},
-        "result": [[l, float(s_)] for l, s_ in res[0]]}), flush=True)
+        "result": [[l, float(s_)] for l, s_ in res[0]]}
+
+
+def synthetic_wordpiece(vocab_size=VOCAB, seed=7):
+    """A synthetic BERT-style WordPiece vocabulary of `vocab_size` entries (no pretrained vocabulary is available offline):
+    specials, every printable ASCII character and its ## form, then random lower-case words and ## suffixes.  Returns
+    (vocab dict, list of whole words it contains)."""
+    rng = np.random.default_rng(seed)
+    toks = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    chars = [chr(c) for c in range(33, 127) if not ("A" <= chr(c) <= "Z")]
+    toks += chars + ["##" + c for c in chars if c.isalnum()]
+    seen, words = set(toks), []
+    letters = list("abcdefghijklmnopqrstuvwxyz")
+    while len(toks) < vocab_size:
+        w = "".join(rng.choice(letters, int(rng.integers(2, 10))))
+        for piece in ((w, "##" + w[-3:]) if len(toks) % 3 else (w,)):
+            if piece not in seen and len(toks) < vocab_size:
+                seen.add(piece); toks.append(piece)
+                if not piece.startswith("##"):
+                    words.append(piece)
+    return {t: i for i, t in enumerate(toks)}, words
+
+
+def measure_predict_from_text(dev, clf, reps=5):
+    """predict_batch(raw strings) queries/s, tokenisation INCLUDED ("with and without host tokenisation"):
+    256 synthetic texts of 6..28 words (<= 32 tokens after truncation) through the classifier's own entry point, once with
+    the on-device WordPiece (ac_wordpiece_encode) and once with the wrapped transformers tokenizer on the host."""
+    from adaptive_classifier import AdaptiveClassifier
+    from transformers import BertTokenizer
+    vocab, words = synthetic_wordpiece()
+    tok = BertTokenizer(vocab=vocab, do_lower_case=True)
+    rng = np.random.default_rng(11)
+    punct = list(",.;:!?")
+    texts = []
+    for _ in range(BATCH):
+        ws = [str(rng.choice(words)) for _ in range(int(rng.integers(6, 29)))]
+        if rng.random() < 0.5:
+            ws[int(rng.integers(0, len(ws)))] += str(rng.choice(punct))
+        texts.append(" ".join(ws).capitalize())
+    out = {"texts": BATCH, "max_length": SEQ, "vocabulary": "synthetic WordPiece, %d entries (no pretrained vocabulary offline)" % len(vocab)}
+    for name, extra in (("device_tokenizer", {}), ("host_tokenizer", {"device_tokenizer": False})):
+        c = AdaptiveClassifier("bert-base-uncased(random-init)", device=str(dev), config={"max_length": SEQ, **extra},
+                               encoder=clf.model, tokenizer=tok)
+        c.label_to_id, c.id_to_label, c.training_history = clf.label_to_id, clf.id_to_label, clf.training_history
+        c.adaptive_head, c.memory = clf.adaptive_head, clf.memory
+        for _ in range(2):
+            preds = c.predict_batch(texts, k=KNN_K, batch_size=BATCH)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            preds = c.predict_batch(texts, k=KNN_K, batch_size=BATCH)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            enc_in = c.tokenizer(texts, max_length=SEQ, truncation=True, padding=True, return_tensors="pt")
+        torch.cuda.synchronize(); dtt = (time.perf_counter() - t0) / reps
+        assert len(preds) == BATCH
+        out[name] = {"queries_per_s": BATCH / dt, "ms_per_batch": dt * 1e3, "tokenizer_call_ms": dtt * 1e3,
+                     "tokens_padded": list(enc_in["input_ids"].shape), "tokenizer": type(c.tokenizer).__name__}
+    return out
 
 
 def main():
@@ -528,6 +602,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the on-box oracle checks (parity fields become null)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default run only: skip the other BASELINE configs carried as extra keys (latency_ms_b1, cfg4, add_examples, predict_from_text)")
     ap.add_argument("--config", default="predict", choices=["predict", "cfg4", "add_examples", "latency"],
                     help="predict = BASELINE configs[1] (the headline, default); cfg4 = configs[4] end to end on one GPU; "
                          "add_examples = configs[3] continuous-learning loop; latency = one predict() of one short text "
@@ -557,9 +633,10 @@ def main():
     if args.config != "predict":
         if world > 1:
             raise SystemExit("--config %s is a single-GPU measurement" % args.config)
-        if args.config == "latency":
-            return bench_latency(dev, args)
-        return bench_cfg4(dev, args) if args.config == "cfg4" else bench_add_examples(dev, args)
+        out = (measure_latency(dev, args) if args.config == "latency" else
+               measure_cfg4(dev, args) if args.config == "cfg4" else measure_add_examples(dev, args))
+        print(json.dumps(out), flush=True)
+        return
 
     clf, hf = make_classifier(dev, rank, world)
     ids, types, mask = synthetic_tokens(dev, rank)
@@ -682,6 +759,22 @@ def main():
             line["parity"] = step_parity(clf, hf, ids, types, mask)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hf, clf, clf.memory.index._store[:NPROTO])
+        if world == 1 and not args.no_extras:
+            # the other BASELINE configs, measured by the same run (outside the timed region of `value`), reduced so the whole
+            # command stays within ~90 s: `--config latency | cfg4 | add_examples` run them at full size on their own
+            torch.cuda.empty_cache()
+            line["predict_from_text"] = measure_predict_from_text(dev, clf)
+            lat = measure_latency(dev, args, reps=100, made=(clf, hf), with_cpu=not args.no_cpu_baseline, cpu_seconds=3.0)
+            line["latency_ms_b1"] = {k: lat[k] for k in ("value", "unit", "stages_ms", "cpu_baseline", "config", "reference_published")}
+            del clf
+            torch.cuda.empty_cache()
+            c4 = measure_cfg4(dev, args, steps=5, warmup=2, parity_queries=8)
+            line["cfg4"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "steps", "stages_ms", "roofline_encoder", "parity", "config")}
+            ae = measure_add_examples(dev, args, n=6000, modes=("as_wired",), with_cpu=False)
+            m = ae["modes"]["as_wired"]
+            line["add_examples"] = {"value": ae["value"], "unit": ae["unit"], "examples": m["examples"], "train_steps": m["train_steps"],
+                                    "steps_per_s": m["steps_per_s"], "host_seconds_by_phase": m["host_seconds_by_phase"],
+                                    "accuracy_5way": m["accuracy_5way"], "config": ae["config"]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
