@@ -24,9 +24,10 @@ def knn_workspace_bytes(N, D, nq, k):
 
 
 # Where the prepared-store GEMM-form path applies (library limits: N >= 65536, k <= 100) and pays: its fixed cost (sample
-# search, thresholds, query planes, a deeper merge: ~0.5 ms) beats the fp32 sweep from ~25 G query-row pairs on
-# (measured: 256 x 100k sweep 0.59 vs 0.82 ms; 256 x 10M 35 vs 13 ms; 1024 x 2M 56 vs 13 ms; 4096 x 10M 552 vs 180 ms)
-BATCH_MIN_QUERIES, BATCH_MIN_ROWS, BATCH_MAX_K, BATCH_MIN_PAIRS = 64, 65536, 100, 1.0e8
+# search, thresholds, query plane, a deeper merge: ~0.3 ms) beats the fp32 sweep from ~20 M query-row pairs on
+# (measured, round 3, fp32 sweep vs batched: 256 x 100k 0.56 vs 0.39 ms inside the predict step; 1024 x 2M x 1024 56 vs 6.5 ms;
+# 4096 x 10M 552 vs 78 ms)
+BATCH_MIN_QUERIES, BATCH_MIN_ROWS, BATCH_MAX_K, BATCH_MIN_PAIRS = 64, 65536, 100, 2.0e7
 
 
 def prepare_store(P, N, D):
