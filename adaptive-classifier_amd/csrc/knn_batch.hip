@@ -95,10 +95,10 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
         if (lane == 0) {
             if (row < rows) {
                 const double E = gamma * (pmax + qn) * (pmax + qn) + 1e-30;
-                const double tau = sampleD[(size_t)row * kp + kp - 1];
+                const double tau = sampleD ? sampleD[(size_t)row * kp + kp - 1] : (double)INFINITY;
                 float t = (float)(tau - a + E);
                 if ((double)t < tau - a + E) t = nextafterf(t, INFINITY);
-                thr[row] = isfinite(tau) ? t : INFINITY;                 // (sample smaller than k': keep everything)
+                thr[row] = isfinite(tau) ? t : INFINITY;                 // (no sample yet / sample smaller than k': keep everything)
                 qfac[row] = -ldexpf(2.0f, ep + e);
             } else { thr[row] = -INFINITY; qfac[row] = 0.f; }            // padding queries keep nothing
         }
@@ -119,13 +119,34 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
     }
 }
 
+// thr[q] from a new tau_q = tauD[q][kp - 1] (an exact distance that at least kp store rows do not exceed)
+__global__ __launch_bounds__(64) void knn_thr_kernel(const double* __restrict__ tauD, int kp, const float* __restrict__ Q, int64_t ldQ,
+                                                     int D, int nq, const uint32_t* __restrict__ maxnorm_bits, double gamma,
+                                                     float* __restrict__ thr) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= nq) return;
+    double a = 0.0;
+    for (int c = lane; c < D; c += 64) { const double x = Q[(size_t)q * ldQ + c]; a = fma(x, x, a); }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o);
+    if (lane == 0) {
+        const double pmax = sqrt((double)__uint_as_float(*maxnorm_bits) * 1.001), qn = sqrt(a);
+        const double E = gamma * (pmax + qn) * (pmax + qn) + 1e-30;
+        const double tau = tauD[(size_t)q * kp + kp - 1];
+        float t = (float)(tau - a + E);
+        if ((double)t < tau - a + E) t = nextafterf(t, INFINITY);
+        thr[q] = isfinite(tau) ? t : INFINITY;
+    }
+}
+
 struct BatchParams {
     const uint16_t* Pp; int64_t p_rows;      // store plane [Kp/8][p_rows][8] fp16
     const float* pnorm;                      // [p_rows]: |p|^2, +inf past N
     const uint16_t* Qp; int64_t q_rows;      // query plane, q_rows = round_up(nq, 256)
     const float* thr;                        // [q_rows]
     const float* qfac;                       // [q_rows]
-    int64_t N;
+    int64_t N;                               // LOGICAL rows swept: logical row i is store row i * row_stride
+    int64_t row_stride;                      // 1 = the whole store; > 1 = a strided sample (threshold stages)
     int Kp;
     int nqt;                                 // query tiles of 256 in this launch
     int b;                                   // query tiles per XCD (1, 2, 4)
@@ -174,7 +195,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
         for (int t = 0; t < GPW; ++t) {
             int64_t row = (it * G + g) * BBM + 32 * (wave + NWV * t) + i32;
             if (row > prm.N - 1) row = prm.N - 1;
-            pa[t] = prm.Pp + ((int64_t)kg * prm.p_rows + row) * 8;
+            pa[t] = prm.Pp + ((int64_t)kg * prm.p_rows + row * prm.row_stride) * 8;
         }
     };
     auto w_base = [&]() {
@@ -246,10 +267,18 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
         // rows (r & 3) + 8 (r >> 2) + 4 kg of a 32-row tile: four runs of 4 norms (the array is padded to whole tiles with
         // +inf: rows past N never qualify)
         auto load_pn = [&](int mi, float (&pn)[16]) {
+            if (prm.row_stride == 1) {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(prm.pnorm + row0 + mi * 32 + 8 * r4 + 4 * kg);
-                pn[4 * r4] = t.x; pn[4 * r4 + 1] = t.y; pn[4 * r4 + 2] = t.z; pn[4 * r4 + 3] = t.w;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(prm.pnorm + row0 + mi * 32 + 8 * r4 + 4 * kg);
+                    pn[4 * r4] = t.x; pn[4 * r4 + 1] = t.y; pn[4 * r4 + 2] = t.z; pn[4 * r4 + 3] = t.w;
+                }
+            } else {                                                // strided sample: one norm at a time, rows past the end never qualify
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t lr = row0 + mi * 32 + acc_row32(r, lane);
+                    pn[r] = lr < prm.N ? prm.pnorm[lr * prm.row_stride] : INFINITY;
+                }
             }
         };
         float thr[4], qf[4];
@@ -395,8 +424,17 @@ int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t l
     return AC_OK;
 }
 
+int knn_thresholds(const double* tauD, int kp, const float* Q, int64_t ldQ, int D, int nq, const uint32_t* maxnorm_bits, double gamma,
+                   float* thr, hipStream_t stream) {
+    hipLaunchKernelGGL(knn_thr_kernel, dim3(nq), dim3(64), 0, stream, tauD, kp, Q, ldQ, D, nq, maxnorm_bits, gamma, thr);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+// N = rows of the prepared store, row_stride >= 1: sweep the logical rows 0, row_stride, 2 row_stride, ... (ceil(N / row_stride) of them)
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
-                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, hipStream_t stream) {
+                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int64_t row_stride,
+                     hipStream_t stream) {
     // (measured and dropped, profiles/r03/knn_batch_probe*.txt: a ring of 5 slots -- no change, the DMA depth is not the limit;
     //  2 x 2 waves of 128 x 128 with the 512-register budget, one wave per SIMD -- 120 vs 80 ms at 4096 x 10M: hipcc shuffles
     //  ~200 accumulator registers per iteration and a lone wave per SIMD hides nothing)
@@ -410,8 +448,9 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
     BatchParams p;
     p.Pp = Pp; p.p_rows = (N + 255) / 256 * 256; p.pnorm = pnorm;
     p.q_rows = ((int64_t)nq + 255) / 256 * 256;
-    p.N = N; p.Kp = knn_kp(D);
-    p.ntiles = (N + BBM - 1) / BBM;
+    p.row_stride = row_stride < 1 ? 1 : row_stride;
+    p.N = (N + p.row_stride - 1) / p.row_stride; p.Kp = knn_kp(D);
+    p.ntiles = (p.N + BBM - 1) / BBM;
     p.cap = cap;
     // one persistent workgroup per CU (128 KB of LDS); the grid is a multiple of 8 so every XCD gets the same share
     int nblk = ac::dev_info().cus / 8 * 8;

@@ -1145,7 +1145,7 @@ constexpr int64_t kBatchMinRows = 65536;
 
 struct BatchPlan {
     int kp, cap, Dp;
-    int64_t stride, S, q_rows;
+    int64_t stride, stride_a, S, q_rows;
     size_t off_sD32, off_sD64, off_sI, off_thr, off_qfac, off_cnt, off_qp, off_cd, off_ci, off_flags, off_fb_d, off_fb_i, off_fb_ctr,
         off_sub, sub_bytes, total;
     int fb_S, fb_F;
@@ -1159,24 +1159,28 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
                D, nq, k, kBatchMaxK);
     bp->kp = k + kBatchPad;
     bp->Dp = (D + 3) / 4 * 4;
-    // sample stride: the exact search over the N / stride sample rows costs as much per row as the old fp32 sweep (10 ms at
-    // 4096 x 10M with stride 64, 13 % of the call now that the proposal sweep is 3x faster), while the expected candidates per
-    // query grow as k' * stride and must stay within half the candidate buffer (<= 16384 entries)
-    int64_t stride = N / 4096, smax = 8192 / bp->kp;
+    // Thresholds come from strided SAMPLES of the store swept by the same GEMM-form kernel (knn_batch.hip) and re-ranked exactly
+    // by the merge kernel: tau_q = the largest exact distance among the k' sample rows with the smallest sweep values -- k' rows
+    // of the store within tau_q, so the store's k'-th smallest distance is <= tau_q whatever the sweep's rounding did.
+    //   stage A: every `stride_a`-th row, nothing filtered (the sample must fit a candidate buffer: <= 4096 rows);
+    //   stage B (stores beyond ~0.5 M rows): every `stride`-th row filtered by stage A's tau (k' stride_a / stride expected);
+    //   main:    all rows filtered by the last tau: k' * stride candidates expected, at most half the candidate buffer.
+    // (Round 2 searched ONE sample of N / 64 rows exactly with the fp32 sweep: 10 ms at 4096 x 10M, 0.17 ms of the 0.39 ms a
+    //  256 x 100k call takes.)
+    int64_t smax = 8192 / bp->kp;
     if (smax > 128) smax = 128;
-    if (stride > smax) stride = smax;
-    if (stride < 1) stride = 1;
+    if (smax < 1) smax = 1;
+    int64_t stride_a = (N + 4095) / 4096, stride = stride_a;
+    if (stride > smax) stride = smax;                  // stage B's (or, for small stores, stage A's own) stride
+    bp->stride_a = stride_a;
     bp->stride = stride;
-    bp->S = (N + stride - 1) / stride;
+    bp->S = (N + stride_a - 1) / stride_a;               // rows of the unfiltered stage-A sample (<= 4096)
     const int64_t expect = (int64_t)bp->kp * stride;             // E[candidates per query] = N * k' / S
     int cap = 1024;
-    while (cap < 2 * expect) cap <<= 1;
-    if (cap > 16384) cap = 16384;
+    while ((cap < 2 * expect || cap < bp->S) && cap < 16384) cap <<= 1;
     bp->cap = cap;
     bp->q_rows = ((int64_t)nq + 255) / 256 * 256;
-    size_t sub = 0;
-    int rc = ac_knn_l2_topk_workspace(bp->S, D, nq, bp->kp, &sub);
-    if (rc != AC_OK) return rc;
+    const size_t sub = 256;                                // (the exact sample search of round 2 needed a workspace of its own)
     bp->sub_bytes = sub;
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += ac::align_up(n, 256); return o; };
@@ -1251,19 +1255,53 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     // this entry point in include/acamd.h)
     const double gamma = ac::knn_batch_gamma(D);
 
-    // 1. exact top-k' over the strided sample (rows 0, stride, 2 stride, ...) through the ordinary path
-    rc = ac_knn_l2_topk_x(d_P, bp.S, ldP * bp.stride, D, d_Q, nq, ldQ, bp.kp, 0, (float*)(ws + bp.off_sD32),
-                          (double*)(ws + bp.off_sD64), (int64_t*)(ws + bp.off_sI), ws + bp.off_sub, bp.sub_bytes, nullptr, stream_);
-    if (rc != AC_OK) return rc;
-    // 2. per query: filter threshold, epilogue factor -2 2^(e_p + e_q), fp16 plane of q 2^-e_q
-    rc = ac::knn_prepare_queries((const double*)(ws + bp.off_sD64), bp.kp, d_Q, ldQ, D, nq, d_maxnorm, gamma,
+    // 1. per query: epilogue factor -2 2^(e_p + e_q), fp16 plane of q 2^-e_q, threshold +inf (keep everything)
+    rc = ac::knn_prepare_queries(nullptr, bp.kp, d_Q, ldQ, D, nq, d_maxnorm, gamma,
                                  (uint16_t*)(ws + bp.off_qp), (float*)(ws + bp.off_thr), (float*)(ws + bp.off_qfac), stream);
     if (rc != AC_OK) return rc;
+    // 2. threshold stages: sweep a strided sample, re-rank its k' best exactly (knn_merge_rerank in candidate mode, asked for
+    //    k' results; its certificate is irrelevant here -- ANY k' rows bound the k'-th smallest distance from above)
+    MergeParams sp;
+    sp.P = d_P; sp.Q = d_Q; sp.ldQ = ldQ; sp.D = D; sp.Dp = bp.Dp;
+    sp.k = bp.kp; sp.kp = bp.kp; sp.G = 1; sp.nblk = 1; sp.gamma = gamma;
+    sp.cand_cnt = (const int32_t*)(ws + bp.off_cnt); sp.cand_cap = bp.cap; sp.row_offset = 0;
+    sp.part_d = (const float*)(ws + bp.off_cd); sp.part_i = (const int32_t*)(ws + bp.off_ci);
+    sp.part_maxnorm = reinterpret_cast<const float*>(d_maxnorm);
+    sp.outD = (float*)(ws + bp.off_sD32); sp.outD64 = (double*)(ws + bp.off_sD64); sp.outI = (int64_t*)(ws + bp.off_sI);
+    sp.flags = (int32_t*)(ws + bp.off_flags); sp.stats = nullptr;
+    sp.fb_S = bp.fb_S; sp.fb_F = 0; sp.fb_d = nullptr; sp.fb_i = nullptr; sp.fb_slotctr = (int32_t*)(ws + bp.off_fb_ctr) + 8;
+    (void)hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.merge_lds);
+    static const bool dbg = getenv("AC_KNN_BATCH_DEBUG") != nullptr;
+    const int64_t stage_stride[2] = {bp.stride_a, bp.stride};
+    const int nstages = bp.stride_a > bp.stride ? 2 : 1;
+    for (int st = 0; st < nstages; ++st) {
+        const int64_t sst = stage_stride[st];
+        AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4, stream));
+        rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
+                                  (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci),
+                                  (int32_t*)(ws + bp.off_cnt), bp.cap, sst, stream);
+        if (rc != AC_OK) return rc;
+        sp.N = (N + sst - 1) / sst; sp.ldP = ldP * sst;           // logical sample row i = store row i * sst
+        hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), bp.merge_lds, stream, sp);
+        AC_LAUNCH_CHECK();
+        rc = ac::knn_thresholds((const double*)(ws + bp.off_sD64), bp.kp, d_Q, ldQ, D, nq, d_maxnorm, gamma, (float*)(ws + bp.off_thr), stream);
+        if (rc != AC_OK) return rc;
+        if (dbg) {
+            AC_HIP_CHECK(hipStreamSynchronize(stream));
+            int32_t cnt[4]; float thr[4]; double tau[4];
+            AC_HIP_CHECK(hipMemcpy(cnt, ws + bp.off_cnt, sizeof(cnt), hipMemcpyDeviceToHost));
+            AC_HIP_CHECK(hipMemcpy(thr, ws + bp.off_thr, sizeof(thr), hipMemcpyDeviceToHost));
+            for (int i = 0; i < 4; ++i)
+                AC_HIP_CHECK(hipMemcpy(&tau[i], ws + bp.off_sD64 + ((size_t)(i < nq ? i : 0) * bp.kp + bp.kp - 1) * 8, 8, hipMemcpyDeviceToHost));
+            fprintf(stderr, "knn batch stage %d: stride %lld rows %lld cap %d kp %d | cand %d %d %d %d | tau %g %g %g %g | thr %g %g %g %g\n", st,
+                    (long long)sst, (long long)sp.N, bp.cap, bp.kp, cnt[0], cnt[1], cnt[2], cnt[3], tau[0], tau[1], tau[2], tau[3], thr[0], thr[1], thr[2], thr[3]);
+        }
+    }
     AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4, stream));
     // 3. the GEMM-form sweep: candidates (row, v) with v below the query's threshold
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
     rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
-                              (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, stream);
+                              (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, 1, stream);
     if (rc != AC_OK) return rc;
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_stop, stream));
     // 4. merge + exact re-rank + certificate, then the exact fallback for uncertified queries
