@@ -112,7 +112,7 @@ int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t l
 int knn_thresholds(const double* tauD, int kp, const float* Q, int64_t ldQ, int D, int nq, const uint32_t* maxnorm_bits, double gamma,
                    float* thr, hipStream_t stream);
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
-                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int64_t row_stride,
+                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int64_t row_stride, int best_only,
                      hipStream_t stream);
 
 // arithmetic of the LDS-tiled GEMMs (ac_gemm_set_arith / env AC_GEMM_ARITH = f32 | bf16x3)

@@ -147,6 +147,7 @@ struct BatchParams {
     const float* qfac;                       // [q_rows]
     int64_t N;                               // LOGICAL rows swept: logical row i is store row i * row_stride
     int64_t row_stride;                      // 1 = the whole store; > 1 = a strided sample (threshold stages)
+    int best_only;                           // unfiltered sample stage: every lane offers only the best of its 32 rows per query column
     int Kp;
     int nqt;                                 // query tiles of 256 in this launch
     int b;                                   // query tiles per XCD (1, 2, 4)
@@ -284,6 +285,33 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
         float thr[4], qf[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) { thr[ni] = prm.thr[qcol0 + 32 * ni]; qf[ni] = prm.qfac[qcol0 + 32 * ni]; }
+        if (prm.best_only) {
+            // The first threshold stage has no threshold yet.  Any k' rows bound the k'-th smallest distance from above, so
+            // instead of offering all of the sample (a million appends from the few workgroups a 4096-row sample occupies)
+            // every lane offers the best of the 32 * TM rows it holds per query column: 8 offers per (query, 256-row tile).
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                float best = INFINITY; int bidx = 0;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    float pn[16];
+                    load_pn(mi, pn);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float val = fmaf(acc[mi][ni][r], qf[ni], pn[r]);
+                        if (val < best) { best = val; bidx = 16 * mi + r; }
+                    }
+                }
+                if (best < thr[ni]) {
+                    const int slot = atomicAdd(&prm.cand_cnt[qcol0 + 32 * ni], 1);
+                    if (slot < prm.cap) {
+                        prm.cand_d[(size_t)(qcol0 + 32 * ni) * prm.cap + slot] = best;
+                        prm.cand_i[(size_t)(qcol0 + 32 * ni) * prm.cap + slot] = (int32_t)(row0 + (bidx >> 4) * 32 + acc_row32(bidx & 15, lane));
+                    }
+                }
+            }
+            return;
+        }
         unsigned mask[TM / 2][4];                                   // bit 16 (mi & 1) + r of query column ni, row tiles 2 h, 2 h + 1
         unsigned any = 0;
 #pragma unroll
@@ -433,7 +461,7 @@ int knn_thresholds(const double* tauD, int kp, const float* Q, int64_t ldQ, int 
 
 // N = rows of the prepared store, row_stride >= 1: sweep the logical rows 0, row_stride, 2 row_stride, ... (ceil(N / row_stride) of them)
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
-                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int64_t row_stride,
+                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int64_t row_stride, int best_only,
                      hipStream_t stream) {
     // (measured and dropped, profiles/r03/knn_batch_probe*.txt: a ring of 5 slots -- no change, the DMA depth is not the limit;
     //  2 x 2 waves of 128 x 128 with the 512-register budget, one wave per SIMD -- 120 vs 80 ms at 4096 x 10M: hipcc shuffles
@@ -449,6 +477,7 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
     p.Pp = Pp; p.p_rows = (N + 255) / 256 * 256; p.pnorm = pnorm;
     p.q_rows = ((int64_t)nq + 255) / 256 * 256;
     p.row_stride = row_stride < 1 ? 1 : row_stride;
+    p.best_only = best_only;
     p.N = (N + p.row_stride - 1) / p.row_stride; p.Kp = knn_kp(D);
     p.ntiles = (p.N + BBM - 1) / BBM;
     p.cap = cap;

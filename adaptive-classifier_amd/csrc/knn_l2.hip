@@ -1162,7 +1162,7 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     // Thresholds come from strided SAMPLES of the store swept by the same GEMM-form kernel (knn_batch.hip) and re-ranked exactly
     // by the merge kernel: tau_q = the largest exact distance among the k' sample rows with the smallest sweep values -- k' rows
     // of the store within tau_q, so the store's k'-th smallest distance is <= tau_q whatever the sweep's rounding did.
-    //   stage A: every `stride_a`-th row, nothing filtered (the sample must fit a candidate buffer: <= 4096 rows);
+    //   stage A: every `stride_a`-th row (max(4096, 128 k') rows), no threshold yet: every lane offers the best of its 32 rows per query;
     //   stage B (stores beyond ~0.5 M rows): every `stride`-th row filtered by stage A's tau (k' stride_a / stride expected);
     //   main:    all rows filtered by the last tau: k' * stride candidates expected, at most half the candidate buffer.
     // (Round 2 searched ONE sample of N / 64 rows exactly with the fp32 sweep: 10 ms at 4096 x 10M, 0.17 ms of the 0.39 ms a
@@ -1170,14 +1170,17 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     int64_t smax = 8192 / bp->kp;
     if (smax > 128) smax = 128;
     if (smax < 1) smax = 1;
-    int64_t stride_a = (N + 4095) / 4096, stride = stride_a;
+    // stage A offers one row per 32 sample rows and query (the best of each lane's rows): with >= 4 k' offers the k' best of them
+    // are, up to rare collisions, the sample's k' best, so tau_A is as tight as an exact search of the sample would make it
+    const int64_t rows_a = 128 * (int64_t)bp->kp > 4096 ? 128 * (int64_t)bp->kp : 4096;
+    int64_t stride_a = (N + rows_a - 1) / rows_a, stride = stride_a;
     if (stride > smax) stride = smax;                  // stage B's (or, for small stores, stage A's own) stride
     bp->stride_a = stride_a;
     bp->stride = stride;
-    bp->S = (N + stride_a - 1) / stride_a;               // rows of the unfiltered stage-A sample (<= 4096)
-    const int64_t expect = (int64_t)bp->kp * stride;             // E[candidates per query] = N * k' / S
+    bp->S = (N + stride_a - 1) / stride_a;               // rows of the stage-A sample
+    const int64_t expect = (int64_t)bp->kp * stride;             // E[candidates per query] of the main sweep = k' * stride
     int cap = 1024;
-    while ((cap < 2 * expect || cap < bp->S) && cap < 16384) cap <<= 1;
+    while (cap < 2 * expect && cap < 16384) cap <<= 1;
     bp->cap = cap;
     bp->q_rows = ((int64_t)nq + 255) / 256 * 256;
     const size_t sub = 256;                                // (the exact sample search of round 2 needed a workspace of its own)
@@ -1279,7 +1282,7 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
         AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4, stream));
         rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
                                   (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci),
-                                  (int32_t*)(ws + bp.off_cnt), bp.cap, sst, stream);
+                                  (int32_t*)(ws + bp.off_cnt), bp.cap, sst, st == 0 ? 1 : 0, stream);
         if (rc != AC_OK) return rc;
         sp.N = (N + sst - 1) / sst; sp.ldP = ldP * sst;           // logical sample row i = store row i * sst
         hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), bp.merge_lds, stream, sp);
@@ -1301,7 +1304,7 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     // 3. the GEMM-form sweep: candidates (row, v) with v below the query's threshold
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
     rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
-                              (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, 1, stream);
+                              (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, 1, 0, stream);
     if (rc != AC_OK) return rc;
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_stop, stream));
     // 4. merge + exact re-rank + certificate, then the exact fallback for uncertified queries
