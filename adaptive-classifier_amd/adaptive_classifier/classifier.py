@@ -39,6 +39,20 @@ from .training import HeadTrainer
 logger = logging.getLogger(__name__)
 
 
+def select_representative_examples(examples: List[Example], k: int = 5) -> List[Example]:
+    """classifier.py:1533-1573: the examples closest to the k centroids of sklearn's KMeans(n_clusters=k,
+    random_state=42, n_init=10) over the L2-normalised embeddings (host side, run once per class by save(); the same
+    library call as the reference, so the same examples are chosen -- one per centroid, repeats kept as it keeps them)."""
+    if len(examples) <= k:
+        return examples
+    from sklearn.cluster import KMeans
+    emb = F.normalize(torch.stack([torch.as_tensor(ex.embedding).detach().cpu().float() for ex in examples]), p=2, dim=1)
+    km = KMeans(n_clusters=k, random_state=42, n_init=10)
+    km.fit(emb.numpy())
+    chosen = [int(torch.argmin(torch.norm(emb - c, dim=1)).item()) for c in torch.tensor(km.cluster_centers_)]
+    return [examples[i] for i in chosen]
+
+
 class AdaptiveClassifier:
     """A classifier that can adapt to new classes and examples (hot path on MI355X)."""
 
@@ -585,10 +599,14 @@ class AdaptiveClassifier:
         return self
 
     # ------------------------------------------------------------------------------ persistence (N1)
-    def save(self, save_dir: str):
+    def select_representative_examples(self, examples: List[Example], k: int = 5) -> List[Example]:
+        """classifier.py:1533-1573."""
+        return select_representative_examples(examples, k)
+
+    def save(self, save_dir: str, all_examples: bool = False):
         """On-disk layout of classifier.py:524-628 (config.json, examples.json, model.safetensors).
-        Deviation: ALL stored examples are written (the reference k-means-selects
-        num_representative_examples per class, :560-566, which is outside the hot path)."""
+        Like the reference, examples.json holds the k-means representatives of every class
+        (config.num_representative_examples, :560-566); `all_examples=True` (additive) writes every stored example."""
         from safetensors.torch import save_file
         d = Path(save_dir)
         d.mkdir(parents=True, exist_ok=True)
@@ -596,9 +614,11 @@ class AdaptiveClassifier:
                "label_to_id": self.label_to_id, "id_to_label": {str(k): v for k, v in self.id_to_label.items()},
                "train_steps": self.train_steps, "training_history": self.training_history,
                "config": self.config.to_dict(), "library_name": "adaptive-classifier"}
-        (d / "config.json").write_text(json.dumps(cfg, indent=2))
-        ex = {label: [e.to_dict() for e in exs] for label, exs in self.memory.examples.items()}
-        (d / "examples.json").write_text(json.dumps(ex))
+        (d / "config.json").write_text(json.dumps(cfg, indent=2, sort_keys=True))
+        keep = (lambda exs: exs) if all_examples else \
+            (lambda exs: select_representative_examples(exs, k=self.config.num_representative_examples))
+        ex = {label: [e.to_dict() for e in keep(exs)] for label, exs in self.memory.examples.items()}
+        (d / "examples.json").write_text(json.dumps(ex, indent=2, sort_keys=True))
         tensors = {f"prototype_{label}": p.contiguous() for label, p in self.memory.prototypes.items()}
         if self.adaptive_head is not None:
             for key, value in self.adaptive_head.state_dict().items():

@@ -435,3 +435,28 @@ def test_wordpiece_hash_and_tokenizer_recognition():
     assert spec is not None and spec[0] == vocab and spec[1] is False and "[SEP]" in spec[2]
     from helpers import HashTokenizer
     assert _wordpiece_spec(HashTokenizer()) is None
+
+
+def test_representative_examples_equal_the_reference_written_file():
+    """N1: tests/golden/ref_saved_d64/examples.json was written by the reference's _save_pretrained from the store that
+    gen_golden.py's build_memory(C=4, per_class=12, D=64, seed=50) makes; select_representative_examples must keep the
+    same examples in the same order (classifier.py:560-566, :1533-1573)."""
+    import json
+    import os
+    import numpy as np
+    from adaptive_classifier.classifier import select_representative_examples
+    from oracle import synth
+    C, per, D, seed = 4, 12, 64, 50
+    X, cent = synth.synth_unit_rows(C * per, D, seed), synth.synth_unit_rows(C, D, seed + 1)
+    store = {f"c{c}": [] for c in range(C)}
+    for i in range(C * per):
+        c = i % C
+        v = X[i] * 0.5 + cent[c]
+        store[f"c{c}"].append(Example(f"t{i:03d}", f"c{c}", torch.from_numpy((v / np.linalg.norm(v)).astype(np.float32))))
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_saved_d64", "examples.json")))
+    for label, exs in store.items():
+        got = select_representative_examples(exs, k=5)
+        assert [e.text for e in got] == [e["text"] for e in ref[label]]
+        assert all(np.array_equal(np.asarray(r["embedding"], np.float32), g.embedding.numpy()) for r, g in zip(ref[label], got))
+    few = store["c0"][:4]
+    assert select_representative_examples(few, k=5) is few               # <= k: returned as they are (:1543-1544)
