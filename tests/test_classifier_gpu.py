@@ -290,6 +290,41 @@ def test_load_classmethod_and_legacy_layout(clf, tmp_path, cuda_dev):
             assert np.allclose([s for _, s in got], [s for _, s in want], atol=1e-6)
 
 
+def test_history_and_confidence_survive_save_load(tmp_path, cuda_dev):
+    """tests/test_confidence_consistency.py:9-86, tests/test_single_example_confidence.py:7-54: the confidences of a
+    restored classifier equal the saved one's (prototypes, head and training_history travel), examples.json holds the
+    k-means representatives (<= num_representative_examples per class), and learning continues cumulatively."""
+    import json
+    from adaptive_classifier import AdaptiveClassifier
+    c = _fresh(cuda_dev)
+    np.random.seed(0)
+    c.add_examples(["This is a foo example number %d" % (i % 7) for i in range(100)] +
+                   ["This is a bar example number %d" % (i % 7) for i in range(100)], ["foo"] * 100 + ["bar"] * 100)
+    before = dict(c.predict("This is a foo example"))
+    c.save(str(tmp_path / "m"))
+    saved = json.loads((tmp_path / "m" / "examples.json").read_text())
+    assert {l: len(v) for l, v in saved.items()} == {"foo": 5, "bar": 5}
+    r = AdaptiveClassifier.load(str(tmp_path / "m"), device="cuda:0", encoder=c.model, tokenizer=HashTokenizer())
+    assert r.training_history == {"foo": 100, "bar": 100} and r.train_steps == c.train_steps
+    assert {l: len(v) for l, v in r.memory.examples.items()} == {"foo": 5, "bar": 5}
+    after = dict(r.predict("This is a foo example"))
+    assert abs(before["foo"] - after["foo"]) < 1e-6 and abs(before["bar"] - after["bar"]) < 1e-6
+    assert max(before, key=before.get) == "foo"
+    np.random.seed(1)
+    r.add_examples(["Additional foo example"] * 20 + ["Additional bar example"] * 20, ["foo"] * 20 + ["bar"] * 20)
+    assert r.training_history == {"foo": 120, "bar": 120}
+    assert set(dict(r.predict("This is a foo example"))) == {"foo", "bar"}
+    # one example per class: the estimate path must not kick in when the history was saved (:909-913)
+    s1 = _fresh(cuda_dev)
+    s1.add_examples(["fish swim in water", "cats say meow"], ["foo", "bar"])
+    b1 = dict(s1.predict("fish swim"))
+    s1.save(str(tmp_path / "s"))
+    r1 = AdaptiveClassifier.load(str(tmp_path / "s"), device="cuda:0", encoder=s1.model, tokenizer=HashTokenizer())
+    assert r1.training_history == {"foo": 1, "bar": 1}
+    a1 = dict(r1.predict("fish swim"))
+    assert all(abs(b1[l] - a1[l]) < 1e-6 for l in b1)
+
+
 @pytest.mark.parametrize("C,kp,k,regular", [(4, 4, 3, False), (4, 4, 3, True), (3, 16, 5, False), (37, 16, 5, False),
                                             (37, 37, 37, True), (300, 24, 7, False), (2048, 8, 4, True)])
 def test_device_blend_equals_numpy_formula(C, kp, k, regular, cuda_dev):
