@@ -105,6 +105,8 @@ _SIGNATURES = {
     "ac_gemm_set_variant": (c_int, [c_int]),
     "ac_gemm_debug_stamps": (c_int, [c_void_p, c_int64]),
     "ac_gemm_set_pipe_table": (c_int, [ctypes.c_char_p]),
+    "ac_gemm_set_ln_fusion": (c_int, [c_int]),
+    "ac_gemm_ln_fusion_launches": (c_int64, []),
     "ac_set_persistent_kernels": (c_int, [c_int]),
     "ac_gemm_occupancy": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "ac_split_bf16x3": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
@@ -161,6 +163,8 @@ _SIGNATURES = {
                                         ctypes.POINTER(c_int), c_void_p]),
     "ac_bert_one_launch_status": (c_int, [ctypes.POINTER(ac_bert_config), c_int, c_int, c_void_p, c_size_t,
                                           ctypes.POINTER(c_int), c_void_p]),
+    "ac_bert_ln_fusion_status": (c_int, [ctypes.POINTER(ac_bert_config), c_int, c_int, c_void_p, c_size_t,
+                                         ctypes.POINTER(c_int), c_void_p]),
     "ac_bert_encode_cls": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
                                    c_void_p]),

@@ -451,7 +451,19 @@ class AdaptiveClassifier:
             return self._blend(None if S is None else S.cpu().numpy(), None if S is None else Cid.cpu().numpy(),
                                None if P is None else P.cpu().numpy(), k, regular)
         out, layout = self._blend_device(S, Cid, P, k, regular)
-        return self._unpack(out.cpu().numpy(), layout, k)
+        host = out.cpu().numpy()
+        if np.isnan(host).any():
+            self._raise_if_encoder_gave_up()
+        return self._unpack(host, layout, k)
+
+    def _raise_if_encoder_gave_up(self):
+        """NaN scores: if the encoder's fused-LayerNorm GEMM epilogues timed out (a device that cannot hold one workgroup per
+        CU at once, e.g. under a CU mask; include/acamd.h ac_bert_ln_fusion_status) say so loudly and switch the fusion off."""
+        gave_up = getattr(self.model, "ln_fusion_aborted", None)
+        if gave_up is not None and gave_up():
+            nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
+            raise nv.NativeError("encoder: the fused LayerNorm epilogue gave up waiting for the tiles of a row panel "
+                                 "(device shared or CU-masked?); the fusion is now off for this process -- repeat the call")
 
     def predict(self, text: str, k: int = 5) -> List[Tuple[str, float]]:
         if not text:

@@ -41,6 +41,7 @@ class HipBertEncoder:
         self.unpad = bool(unpad)
         self.last_tokens = 0                  # token rows the last encode_cls call actually ran (roofline accounting)
         self.last_one_launch = False          # the last native call ran as the one persistent launch (bert_small.hip)
+        self._last_chunk = None               # (rows, S) of the last native call: where its workspace keeps the verdicts
         cfg = hf_bert.config
         mtype = getattr(cfg, "model_type", "bert")
         if mtype not in ("bert", "distilbert"):
@@ -168,6 +169,7 @@ class HipBertEncoder:
             for r0 in range(0, b, cb):
                 r1 = min(b, r0 + cb)
                 nb = r1 - r0
+                self._last_chunk = (nb, S)
                 if self.unpad and mk is not None and S > 1 and nb * S > SMALL_TOKENS:
                     # padding-free path: pack on the device, read back {rows, prefix flag, longest} (one 16-byte D2H)
                     cu = torch.empty(nb + 1, dtype=torch.int32, device=self.device)
@@ -206,6 +208,16 @@ class HipBertEncoder:
                         call(nv.AC_BERT_LAYERED)
                 self.last_tokens += nb * S
         return out
+
+    def ln_fusion_aborted(self) -> bool:
+        """Verdict of the fused-LayerNorm GEMM epilogues of the last encode_cls() chunk (a 4-byte D2H: stream sync)."""
+        if self._ws is None or self._last_chunk is None:
+            return False
+        aborted = ctypes.c_int(0)
+        nb, S = self._last_chunk
+        nv.check(nv.lib().ac_bert_ln_fusion_status(ctypes.byref(self.ccfg), nb, S, nv.ptr(self._ws), self._ws.numel(),
+                                                   ctypes.byref(aborted), nv.stream_ptr(self.device)), "ac_bert_ln_fusion_status")
+        return bool(aborted.value)
 
     def flops(self, b, S, executed=True, tokens=None, sum_len_sq=None):
         """FLOPs of one forward (dense projections + attention), for roofline reports.

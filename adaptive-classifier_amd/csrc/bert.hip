@@ -474,8 +474,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 struct BertWs {
-    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
+    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
+    size_t lnctl_bytes;
 };
+constexpr size_t kLnCtlHead = 256;     // the abort word of the fused-LayerNorm GEMM epilogues, then their row-panel counters
 BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     BertWs w;
     const size_t T = (size_t)b * S;
@@ -493,6 +495,12 @@ BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     // the one-launch small-batch path (bert_small.hip) works on 32 padded rows of its own
     w.small = off;
     if (T <= 32) off += ac::bert_small_ws_bytes(c.hidden, c.intermediate);
+    // fused LayerNorm epilogues (gemm_pipe.hip): abort word + one counter per (layer, LayerNorm, 128-row panel), partials
+    w.lnctl = off;
+    w.lnctl_bytes = kLnCtlHead + ac::align_up((size_t)c.layers * 2 * ac::pipe_ln_panels((int)T) * sizeof(unsigned), 256);
+    off += w.lnctl_bytes;
+    w.lnpart = off;
+    off += ac::align_up(ac::pipe_ln_part_bytes((int)T, c.hidden), 256);
     w.total = off;
     return w;
 }
@@ -547,6 +555,12 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
     // layers 0 .. L-2 qualify; the CLS-only last layer (b rows) keeps fp32 activations.
     const bool wplanes = w->qkv_w3 && w->ao_w3 && w->ff1_w3 && w->ff2_w3;
     const bool pl = wplanes && ac::linear_takes_planes(T, H, H) && ac::linear_takes_planes(T, H, I) && (H % 8) == 0;
+    // bias + residual + LayerNorm in the epilogue of the attention-output and FFN2 GEMMs (one-round launches only)
+    const bool fuse_ln = pl && c.layers > 1 && ac::pipe_ln_applies(T, H, H) && ac::pipe_ln_applies(T, H, I);
+    unsigned* ln_abort = (unsigned*)(base + ws.lnctl);
+    unsigned* ln_count = (unsigned*)(base + ws.lnctl + kLnCtlHead);
+    const int ln_panels = ac::pipe_ln_panels(T);
+    AC_HIP_CHECK(hipMemsetAsync(base + ws.lnctl, 0, fuse_ln ? ws.lnctl_bytes : kLnCtlHead, stream));   // (the abort word always: ac_bert_ln_fusion_status)
 
     hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, T, S, H,
                        w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x,
@@ -583,17 +597,30 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         }
         AC_LAUNCH_CHECK();
         const int lblocks = (Ml + 3) / 4;
-        rc = ac::linear_f32(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f, stream,
-                            0.f, 0, ao_w3, lp ? ctxp : nullptr);
-        if (rc) return rc;
-        // (last layer: x is overwritten with b compact rows; its old contents are no longer needed)
-        hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln1_g[l], w->ln1_b[l],
-                           c.ln_eps, last ? ctx : x, lp ? xp : nullptr, (int64_t)H);
-        AC_LAUNCH_CHECK();
+        const bool fl = fuse_ln && lp;                 // x <- LayerNorm(x + ctx Wo^T + b) in ONE launch, in place
+        if (fl) {
+            rc = ac::launch_gemm_pipe_ln(ctxp, Ml, ao_w3, H, w->ao_b[l], x, H, x, H, Ml, H, H, w->ln1_g[l], w->ln1_b[l], c.ln_eps,
+                                         base + ws.lnpart, ln_count + (size_t)(2 * l) * ln_panels, ln_abort, xp, stream);
+            if (rc) return rc;
+        } else {
+            rc = ac::linear_f32(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f, stream,
+                                0.f, 0, ao_w3, lp ? ctxp : nullptr);
+            if (rc) return rc;
+            // (last layer: x is overwritten with b compact rows; its old contents are no longer needed)
+            hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln1_g[l], w->ln1_b[l],
+                               c.ln_eps, last ? ctx : x, lp ? xp : nullptr, (int64_t)H);
+            AC_LAUNCH_CHECK();
+        }
         float* x1 = last ? ctx : x;                    // ctx is free again after the AO projection
         rc = ac::linear_f32(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, nullptr, 1.f, stream,
                             0.f, 0, ff1_w3, lp ? xp : nullptr, lp ? ffnp : nullptr);
         if (rc) return rc;
+        if (fl) {                                      // x <- LayerNorm(x + ffn W2^T + b), planes for the next layer's QKV GEMM
+            rc = ac::launch_gemm_pipe_ln(ffnp, Ml, ff2_w3, H, w->ff2_b[l], x, H, x, H, Ml, H, I, w->ln2_g[l], w->ln2_b[l], c.ln_eps,
+                                         base + ws.lnpart, ln_count + (size_t)(2 * l + 1) * ln_panels, ln_abort, xp, stream);
+            if (rc) return rc;
+            continue;
+        }
         rc = ac::linear_f32(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, nullptr, 1.f, stream, 0.f, 0,
                             ff2_w3, lp ? ffnp : nullptr);
         if (rc) return rc;
@@ -645,6 +672,20 @@ extern "C" int ac_bert_one_launch_status(const ac_bert_config* cfg, int b, int S
     const BertWs ws = bert_ws(*cfg, b, S);
     AC_REQUIRE(ws_bytes >= ws.total, AC_EWORKSPACE, "bert_one_launch_status: workspace %zu < %zu", ws_bytes, ws.total);
     return ac::bert_small_aborted(cfg->hidden, cfg->intermediate, (const char*)d_ws + ws.small, (hipStream_t)stream_, aborted);
+}
+
+extern "C" int ac_bert_ln_fusion_status(const ac_bert_config* cfg, int b, int S, const void* d_ws, size_t ws_bytes,
+                                       int* aborted, ac_stream_t stream_) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    AC_REQUIRE(aborted && d_ws && b > 0 && S >= 1, AC_EINVAL, "bert_ln_fusion_status: bad arguments");
+    const BertWs ws = bert_ws(*cfg, b, S);
+    AC_REQUIRE(ws_bytes >= ws.total, AC_EWORKSPACE, "bert_ln_fusion_status: workspace %zu < %zu", ws_bytes, ws.total);
+    unsigned flag = 0;
+    AC_HIP_CHECK(hipMemcpyAsync(&flag, (const char*)d_ws + ws.lnctl, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    AC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+    *aborted = flag != 0;
+    return AC_OK;
 }
 
 extern "C" int ac_bert_pack(const int64_t* d_mask, int b, int S, int32_t* d_cu, int32_t* d_tok_src, int32_t* d_info,

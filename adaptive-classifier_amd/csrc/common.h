@@ -56,6 +56,16 @@ int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const f
                const uint8_t* mask, float mask_scale, hipStream_t stream, float drop_p = 0.f,
                uint64_t drop_seed = 0, const uint16_t* W_planes = nullptr, const uint16_t* A_planes = nullptr,
                uint16_t* C_planes = nullptr);
+// gemm_pipe.hip:
+// bias + residual + LayerNorm fused into the epilogue (one-round launches of the 128 x 128 tile only: see gemm_pipe.hip);
+// `count` = one zeroed word per 128-row panel, `part` = pipe_ln_part_bytes() of scratch, C may alias the residual
+bool pipe_ln_applies(int M, int N, int K);
+size_t pipe_ln_part_bytes(int M, int N);
+int pipe_ln_panels(int M);
+int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias,
+                        const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, const float* gamma,
+                        const float* beta, float eps, void* part, unsigned* count, unsigned* abort_flag, uint16_t* planes,
+                        hipStream_t stream);
 // true when linear_f32(M, N, K) with W planes takes the pre-split kernel (only then may A / C planes be passed)
 bool linear_takes_planes(int M, int N, int K);
 

@@ -33,6 +33,19 @@ struct Epilogue {
     float gate_scale;
 };
 
+// EPI_BIAS_RES_LN (gemm_pipe.hip): LayerNorm of the output rows fused into the epilogue.  The tiles of one row panel
+// exchange per-row (mean, M2) of their columns through `part` and count themselves into `count[panel]` (zero before the
+// launch); C receives the normalised rows (it may alias the residual), `planes` their operand planes for the next GEMM.
+struct LnFuse {
+    const float* gamma;
+    const float* beta;
+    float eps;
+    float2* part;           // [row panels][column tiles][BM]
+    unsigned* count;        // [row panels]
+    unsigned* abort_;       // set when a row panel's tiles did not all arrive (the results are NaN then)
+    uint16_t* planes;       // [3][N/8][M][8] or null
+};
+
 __device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, int64_t row, int col,
                                                 const float* C, int64_t ldc, int N) {
     float v = e.alpha * acc;
@@ -51,10 +64,13 @@ __device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, in
 enum { EPI_GENERIC = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RES = 3, EPI_BIAS_RELU = 4,
        // GeGLU over 32-column blocks: output columns [64t, 64t+32) are the inputs and [64t+32, 64t+64) the gates of
        // result columns [32t, 32t+32) -- a wave's two 32x32 tiles hold input_j and gate_j in the same lane/register
-       EPI_GEGLU32 = 5 };
+       EPI_GEGLU32 = 5,
+       EPI_IDENT = 6,          // store the accumulators as they are (second half of the fused-LayerNorm epilogue)
+       EPI_BIAS_RES_LN = 7 };  // bias + residual, then LayerNorm over the whole row (gemm_pipe.hip)
 
 template <int EPI>
 __device__ __forceinline__ float fast_epilogue(float acc, float bias, float res) {
+    if (EPI == EPI_IDENT) return acc;
     float v = acc + bias;
     if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     if (EPI == EPI_BIAS_RELU) v = v < 0.f ? 0.f : v;
@@ -84,7 +100,7 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* __restr
                     if (row < M) C[row * ldc + col] = apply_epilogue(epi, acc[mi][ni][r], row, col, C, ldc, N);
                 }
             } else {
-                const float bias = epi.bias[col];
+                const float bias = EPI == EPI_IDENT ? 0.f : epi.bias[col];
                 float res[16];
                 if (EPI == EPI_BIAS_RES) {   // issue all residual loads first, then compute + store
 #pragma unroll
@@ -133,7 +149,7 @@ __device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][TN], uint16_
             const int c0 = GLU ? n0 / 2 + wn * 32 : n0 + wn * (32 * TN) + ni * 32;      // first result column of the tile
             const int col = n0 + wn * (32 * TN) + ni * 32 + (lane & 31);                  // GEMM column of acc[mi][ni]
             const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
-            const float bias = col < N ? epi.bias[col] : 0.f;
+            const float bias = (EPI != EPI_IDENT && col < N) ? epi.bias[col] : 0.f;
             const float bias_g = (GLU && col + 32 < N) ? epi.bias[col + 32] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

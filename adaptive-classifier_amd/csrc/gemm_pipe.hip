@@ -19,9 +19,12 @@
 // waves is not what limits the loop.
 #include "common.h"
 #include "gemm_common.h"
+#include "grid_sync.h"
 
 #include <stdio.h>
 #include <stdlib.h>
+
+#include <atomic>
 
 namespace {
 using namespace acg;
@@ -34,6 +37,7 @@ struct PipeParams {
     float* C; int64_t ldc;              // fp32 result, or (C_PLANES) the planes of the next GEMM's operand
     int M, N, K;
     Epilogue epi;
+    LnFuse ln;                          // EPI_BIAS_RES_LN only
     unsigned long long* stamps;         // diagnostic (ac_gemm_debug_stamps): 4 shader-clock stamps per workgroup, or null
 };
 
@@ -64,6 +68,140 @@ template <int TM, int TN, int WMW, int WNW, int NS> struct PipeGeom {
     static constexpr int WAVES_PER_SIMD = (BPC * NW + 3) / 4;
 };
 
+// the residual block of this wave's accumulators, in their layout (issued at kernel start, consumed by store_tile_ln)
+template <int TM, int TN, int WMW, int WNW>
+__device__ __forceinline__ void ln_prefetch_residual(float (&res)[TM * TN * 16], const PipeParams& prm, int m0, int n0, int wm,
+                                                     int wn, int lane) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = n0 + wn * (32 * TN) + ni * 32 + (lane & 31);
+            const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int64_t row = rbase + acc_row32(r, lane);
+                if (row > prm.M - 1) row = prm.M - 1;
+                res[(mi * TN + ni) * 16 + r] = prm.epi.residual[row * prm.epi.ldr + col];
+            }
+        }
+}
+
+// ---- EPI_BIAS_RES_LN: y = acc + bias + residual, LayerNorm over the whole row, result as fp32 rows AND operand planes ----
+// A row of the output spans the N / BN tiles of its row panel; each tile reduces its BN columns to a per-row (mean, M2),
+// publishes them (sc1 stores), counts itself into the panel's counter and waits for the others -- all tiles of a panel are
+// co-resident because the launch is ONE round of one workgroup per CU (launch_gemm_pipe_ln refuses anything else) -- then
+// combines the partials (Chan et al.: equal counts), normalises its accumulators in place and stores them twice.
+// Replaces a separate LayerNorm launch (read fp32 y, write fp32 x + planes: 20 us at 5141 x 768) by ~3 us of exchange.
+template <int TM, int TN, int WMW, int WNW>
+__device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float (&res)[TM * TN * 16], const PipeParams& prm,
+                                              int bm, int bn, int ntn, int wm, int wn, int lane, int tid, int wave, float* lds_f) {
+    constexpr int BM = 32 * TM * WMW, BN = 32 * TN * WNW, NW = WMW * WNW, WC = 32 * TN;
+    static_assert(BM <= 64 * NW, "one thread per tile row in the combine steps");
+    const Epilogue& e = prm.epi;
+    const LnFuse& ln = prm.ln;
+    float2* wstat = reinterpret_cast<float2*>(lds_f + NW * kTrFloats);      // [WNW][BM]: (mean, M2) over a wave's WC columns
+    float2* rstat = wstat + WNW * BM;                                       // [BM]: (mean, rstd) of the whole row
+    unsigned* okf = reinterpret_cast<unsigned*>(rstat + BM);
+    const int m0 = bm * BM, n0 = bn * BN, c = lane & 31;
+    // 1. v = (acc + bias) + residual -- the operation order of the unfused epilogue; the residual was requested before the
+    //    k-loop (ln_prefetch_residual), so its HBM latency is not part of this exposed epilogue
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const float bias = e.bias[n0 + wn * WC + ni * 32 + c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = (acc[mi][ni][r] + bias) + res[(mi * TN + ni) * 16 + r];
+        }
+    // 2. per row: mean and M2 over this wave's WC columns (two passes over registers; 32 lanes of a half hold one row)
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) s += acc[mi][ni][r];
+            s = acp::row16_sum(s);
+            s += __shfl_xor(s, 16);
+            const float mw = s * (1.0f / WC);
+            float q = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) { const float d = acc[mi][ni][r] - mw; q = fmaf(d, d, q); }
+            q = acp::row16_sum(q);
+            q += __shfl_xor(q, 16);
+            if (c == r) wstat[wn * BM + wm * (32 * TM) + mi * 32 + acc_row32(r, lane)] = make_float2(mw, q);
+        }
+    __syncthreads();
+    // 3. the tile's partial of every row -> global (sc1: visible to the other XCDs without cache maintenance); count in
+    if (tid < BM) {
+        float mean = 0.f;
+#pragma unroll
+        for (int w = 0; w < WNW; ++w) mean += wstat[w * BM + tid].x;
+        mean *= 1.0f / WNW;
+        float m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WNW; ++w) { const float2 pw = wstat[w * BM + tid]; const float d = pw.x - mean; m2 += fmaf((float)WC * d, d, pw.y); }
+        const unsigned long long bits = (unsigned long long)__float_as_uint(mean) | ((unsigned long long)__float_as_uint(m2) << 32);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(ln.part + ((size_t)bm * ntn + bn) * BM + tid), bits,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(ln.count + bm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // 4. wait for the panel's other tiles (bounded: a bug or a CU mask must not hang the GPU -- the rows become NaN instead)
+    if (tid < 64) {
+        unsigned ok = 1;
+        for (long spins = 0;; ++spins) {
+            const unsigned v = __hip_atomic_load(ln.count + bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v >= (unsigned)ntn) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 1023) == 1023 && (spins > (1l << 22) || __hip_atomic_load(ln.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (lane == 0) __hip_atomic_store(ln.abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        if (lane == 0) *okf = ok;
+    }
+    __syncthreads();
+    // 5. whole-row statistics from the ntn partials (<= 8 column tiles: all loads in flight together)
+    if (tid < BM) {
+        float2 pj[8];
+        const float* base = reinterpret_cast<const float*>(ln.part + (size_t)bm * ntn * BM + tid);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pj[j] = j < ntn ? acp::ld2_sc1(base + (size_t)j * BM * 2) : make_float2(0.f, 0.f);
+        float mean = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mean += pj[j].x;                         // (absent tiles add 0)
+        mean /= (float)ntn;
+        float m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j < ntn) { const float d = pj[j].x - mean; m2 += fmaf((float)BN * d, d, pj[j].y); }
+        const float var = m2 / (float)prm.N;
+        const float rstd = 1.0f / sqrtf(var + ln.eps);
+        rstat[tid] = make_float2(mean, *okf ? rstd : __uint_as_float(0x7fc00000u));
+    }
+    __syncthreads();
+    // 6. normalise in place
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = n0 + wn * WC + ni * 32 + c;
+            const float g = ln.gamma[col], b = ln.beta[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float2 st = rstat[wm * (32 * TM) + mi * 32 + acc_row32(r, lane)];
+                acc[mi][ni][r] = (acc[mi][ni][r] - st.x) * st.y * g + b;
+            }
+        }
+    // 7. fp32 rows (later residuals) and the operand planes of the next GEMM
+    store_tile<EPI_IDENT, TM, BM, TN>(acc, prm.C, prm.ldc, prm.M, prm.N, m0, n0, wm, wn, lane, e);
+    if (ln.planes)
+        store_tile_planes<EPI_IDENT, TM, TN>(acc, ln.planes, prm.M, prm.N, m0, n0, wm, wn, lane, e, lds_f + wave * kTrFloats);
+}
+
 template <int EPI, int TM, int TN, int WMW, int WNW, int NS, bool C_PLANES, int PIPE>
 __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS>::WAVES_PER_SIMD)) void gemm_pipe_nt(PipeParams prm) {
     using G = PipeGeom<TM, TN, WMW, WNW, NS>;
@@ -81,6 +219,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS>::WA
     const int m0 = bm * BM, n0 = bn * BN;
     const int nk = prm.K / PSBK;
     stamp(prm, wave, 0);
+    float lnres[EPI == EPI_BIAS_RES_LN ? TM * TN * 16 : 1];
+    if constexpr (EPI == EPI_BIAS_RES_LN) ln_prefetch_residual<TM, TN, WMW, WNW>(lnres, prm, m0, n0, wm, wn, lane);
 
     // ---- DMA stream: piece j = wave + NW t -> (plane j / RG, group j % RG); lane (i, kg) copies 16 B of row i, k-slot kg
     const uint16_t* pp[PPW];
@@ -199,7 +339,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS>::WA
     }
     wait_vm<0>();                                                       // the over-issued tail stages: LDS is about to be reused / released
     stamp(prm, wave, 2);
-    if (C_PLANES) {
+    if constexpr (EPI == EPI_BIAS_RES_LN) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                                   // nobody's DMA may land in the epilogue's LDS scratch
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile_ln<TM, TN, WMW, WNW>(acc, lnres, prm, bm, bn, ntn, wm, wn, lane, tid, wave, reinterpret_cast<float*>(lds));
+    } else if (C_PLANES) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                                   // nobody's DMA may land in the transpose scratch
         __builtin_amdgcn_sched_barrier(0);
@@ -218,7 +363,9 @@ template <int EPI, int TM, int TN, int WMW, int WNW, int NS, bool CP, int PIPE>
 int launch_one(PipeParams p, hipStream_t stream) {
     using G = PipeGeom<TM, TN, WMW, WNW, NS>;
     const int64_t tiles = (int64_t)((p.M + G::BM - 1) / G::BM) * ((p.N + G::BN - 1) / G::BN);
-    const size_t lds = (size_t)(G::LDS_BYTES > G::TR_BYTES || !CP ? G::LDS_BYTES : G::TR_BYTES);
+    constexpr int LN_BYTES = G::TR_BYTES + (WNW + 1) * G::BM * 8 + 16;                       // EPI_BIAS_RES_LN scratch
+    const size_t lds = EPI == EPI_BIAS_RES_LN ? (size_t)(G::LDS_BYTES > LN_BYTES ? G::LDS_BYTES : LN_BYTES)
+                                              : (size_t)(G::LDS_BYTES > G::TR_BYTES || !CP ? G::LDS_BYTES : G::TR_BYTES);
     static bool attr_set = false;                                      // (per instantiation)
     if (!attr_set) {
         AC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE>,
@@ -241,6 +388,8 @@ int launch_cfg(int cls, bool cp, const PipeParams& p, hipStream_t stream) {
     } else {
         if (cls == EPI_BIAS) return launch_one<EPI_BIAS, TM, TN, WMW, WNW, NS, false, PIPE>(p, stream);
         if (cls == EPI_BIAS_RES) return launch_one<EPI_BIAS_RES, TM, TN, WMW, WNW, NS, false, PIPE>(p, stream);
+        if constexpr (TM == 1 && TN == 2 && WMW == 4 && WNW == 2 && NS == 6 && PIPE == 2)      // (built for the one tile that uses it)
+            if (cls == EPI_BIAS_RES_LN) return launch_one<EPI_BIAS_RES_LN, TM, TN, WMW, WNW, NS, false, PIPE>(p, stream);
     }
     ac::set_error("gemm_pipe: epilogue class %d (planes out %d) not built for this tile", cls, (int)cp);
     return AC_EUNSUPPORTED;
@@ -318,6 +467,7 @@ int launch_gemm_pipe(int cfg, const uint16_t* Ap, int64_t a_rows, const uint16_t
     PipeParams p;
     p.Ap = Ap; p.a_rows = a_rows; p.Wp = Wp; p.w_rows = w_rows;
     p.C = Cp ? reinterpret_cast<float*>(Cp) : C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epi;
+    p.ln = LnFuse{};
     p.stamps = nullptr;
     const bool cp = Cp != nullptr;
 #define AC_CASE(TM, TN, WMW, WNW, NS, PIPE) \
@@ -328,11 +478,62 @@ int launch_gemm_pipe(int cfg, const uint16_t* Ap, int64_t a_rows, const uint16_t
     return AC_EUNSUPPORTED;
 }
 
+
+// ---- bias + residual + LayerNorm fused into the N-wide GEMMs of an encoder layer (EPI_BIAS_RES_LN) ----
+constexpr int kLnCfg = 124262, kLnBM = 128, kLnBN = 128;     // the one tile the fused epilogue is built for
+static std::atomic<int> g_ln_fusion{-1};
+static std::atomic<long long> g_ln_launches{0};
+bool ln_fusion_enabled() {
+    int v = g_ln_fusion.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("AC_LN_FUSION");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+        g_ln_fusion.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+// The launch must be ONE round of one workgroup per CU (all tiles of a row panel co-resident) and the default dispatch must
+// pick the 128 x 128 eight-wave tile for the shape anyway.
+bool pipe_ln_applies(int M, int N, int K) {
+    if (!ln_fusion_enabled() || gemm_arith() != AC_GEMM_BF16X3 || gemm_variant() != 0) return false;
+    if (M < 192 || (N % kLnBN) != 0 || N / kLnBN > 8 || (K % 32) != 0 || K < 64) return false;
+    const int64_t tiles = (int64_t)((M + kLnBM - 1) / kLnBM) * (N / kLnBN);
+    return tiles <= dev_info().cus && pipe_choose(M, N, K, EPI_BIAS_RES, false) == kLnCfg;
+}
+size_t pipe_ln_part_bytes(int M, int N) { return (size_t)((M + kLnBM - 1) / kLnBM) * (size_t)(N / kLnBN) * kLnBM * sizeof(float2); }
+int pipe_ln_panels(int M) { return (M + kLnBM - 1) / kLnBM; }
+
+int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias,
+                        const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, const float* gamma,
+                        const float* beta, float eps, void* part, unsigned* count, unsigned* abort_flag, uint16_t* planes,
+                        hipStream_t stream) {
+    AC_REQUIRE(pipe_ln_applies(M, N, K), AC_EUNSUPPORTED, "gemm_pipe: fused LayerNorm epilogue not applicable to %d x %d x %d", M, N, K);
+    AC_REQUIRE(Ap && Wp && bias && residual && C && gamma && beta && part && count && abort_flag, AC_EINVAL, "gemm_pipe_ln: null pointer");
+    PipeParams p;
+    p.Ap = Ap; p.a_rows = a_rows; p.Wp = Wp; p.w_rows = w_rows; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    Epilogue e;
+    e.bias = bias; e.residual = residual; e.ldr = ldr; e.act = ACT_NONE; e.alpha = 1.f; e.beta = 0.f; e.mask = nullptr;
+    e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;
+    p.epi = e;
+    p.ln.gamma = gamma; p.ln.beta = beta; p.ln.eps = eps; p.ln.part = (float2*)part; p.ln.count = count; p.ln.abort_ = abort_flag;
+    p.ln.planes = planes;
+    p.stamps = nullptr;
+    g_ln_launches.fetch_add(1, std::memory_order_relaxed);
+    return launch_cfg<1, 2, 4, 2, 6, 2>(EPI_BIAS_RES_LN, false, p, stream);
+}
 }  // namespace ac
 
 /* tuning / A-B: "NxK=cfg;NxK=cfg;..." overrides the built-in per-shape choice of the ring-staged kernels for GEMMs with N output
  * columns and inner dimension K (cfg 0 = two-buffer tile kernels); an empty string = no ring kernel anywhere; NULL restores
  * the built-in table. */
+/* process-wide switch (A/B runs, tests): 0 = the encoder keeps its LayerNorms as separate launches; default 1, or AC_LN_FUSION=0 */
+extern "C" int ac_gemm_set_ln_fusion(int on) {
+    ac::g_ln_fusion.store(on ? 1 : 0, std::memory_order_relaxed);
+    return AC_OK;
+}
+
+extern "C" int64_t ac_gemm_ln_fusion_launches(void) { return (int64_t)ac::g_ln_launches.load(std::memory_order_relaxed); }
+
 extern "C" int ac_gemm_set_pipe_table(const char* spec) {
     if (!spec) { ac::g_nrules = -1; return AC_OK; }
     int n = 0;

@@ -221,6 +221,12 @@ int ac_gemm_debug_stamps(unsigned long long* d_buf, int64_t capacity_workgroups)
  * one ring configuration (cfg as in ac_gemm_set_variant) for planes GEMMs with N output columns and inner dimension K;
  * "" = two-buffer kernels everywhere; NULL restores the built-in table (tools/encode_ab.py). */
 int ac_gemm_set_pipe_table(const char* spec);
+/* The BERT encoder folds `x = LayerNorm(x + A W^T + b)` (BertSelfOutput / BertOutput, transformers modeling_bert.py) into
+ * the epilogue of the attention-output and FFN2 GEMMs when the launch is one round of 128 x 128 tiles, one per CU: the
+ * tiles of a 128-row panel exchange per-row (mean, M2) partials and each normalises its own block (gemm_pipe.hip).
+ * 0 keeps the LayerNorms as separate launches (A/B, tests); default 1; env AC_LN_FUSION=0 sets the initial value. */
+int ac_gemm_set_ln_fusion(int on);
+int64_t ac_gemm_ln_fusion_launches(void);      /* fused launches of this process so far (tests: "did the fused path run") */
 
 /* The persistent one-launch kernels of the latency-bound ends of the path are chosen automatically when the shape fits;
  * this switch (A/B tests, diagnosis) turns them off or on process-wide.  mask bit 0: ac_head_train_step / _epoch through
@@ -503,6 +509,12 @@ int ac_bert_encode_cls_opts(const ac_bert_config* cfg, const ac_bert_weights* w,
                             void* d_ws, size_t ws_bytes, int opts, int* used_one_launch, ac_stream_t stream);
 int ac_bert_one_launch_status(const ac_bert_config* cfg, int b, int S, const void* d_ws, size_t ws_bytes,
                               int* aborted, ac_stream_t stream);
+/* Verdict of the fused-LayerNorm GEMM epilogues (ac_gemm_set_ln_fusion) of the LAST ac_bert_encode_cls[_opts|_packed] call
+ * that used this workspace (same cfg, b, S): *aborted = 1 when the tiles of a row panel did not all arrive within the
+ * bounded wait (possible only if the device cannot hold one workgroup per CU at once, e.g. under a CU mask); the output
+ * rows are NaN then -- repeat after ac_gemm_set_ln_fusion(0).  Synchronises the stream (a 4-byte D2H). */
+int ac_bert_ln_fusion_status(const ac_bert_config* cfg, int b, int S, const void* d_ws, size_t ws_bytes,
+                             int* aborted, ac_stream_t stream);
 
 /*
  * Padding-free ("packed") form of the same forward.  The reference pads every text to the longest of the batch and

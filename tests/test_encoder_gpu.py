@@ -258,3 +258,41 @@ def test_modernbert_padding_free_path_equals_padded_path(hidden, layers, heads, 
     assert packed.last_tokens == int(mask.sum()) < b * S == padded.last_tokens
     assert (got_p - got_f).abs().max().item() < 2e-6
     assert (got_p - want).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("hidden,layers,heads,inter,b,S,ragged", [
+    (768, 3, 12, 3072, 200, 32, True),     # ~4000 packed rows, 32 row panels x 6 column tiles: the bench's launch shape
+    (768, 2, 12, 3072, 24, 16, False),     # 384 rows = exactly 3 panels, padded layout
+    (128, 3, 2, 512, 40, 16, True),        # one column tile per panel (H = 128), ragged last panel
+    (1024, 3, 16, 4096, 20, 24, True),     # 8 column tiles per panel (bert-large width)
+])
+@pytest.mark.parametrize("regime", REGIMES)
+def test_layernorm_fused_into_the_gemm_epilogue(hidden, layers, heads, inter, b, S, ragged, regime, cuda_dev):
+    """x = LayerNorm(x + A W^T + b) inside the attention-output / FFN2 GEMM epilogues (gemm_pipe.hip EPI_BIAS_RES_LN: the tiles
+    of a row panel exchange (mean, M2) partials): the fused launches really run (counter), their result equals the separate
+    LayerNorm launches to rounding and transformers to the 1e-4 bar -- also with LayerNorm outlier channels (peaked regime)."""
+    from adaptive_classifier import _native as nv
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    vocab = 2000
+    model = bert_oracle.make_bert(hidden, layers, heads, inter, vocab=vocab, seed=3, **regime_kw(regime, hidden))
+    ids, types, mask = bert_oracle.synthetic_batch(b, S, vocab=vocab, seed=99, ragged=ragged)
+    want = bert_oracle.encode_cls(model, ids, types, mask)
+    enc = HipBertEncoder(model, device=cuda_dev)
+    lib = nv.lib()
+    try:
+        nv.check(lib.ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
+        n0 = lib.ac_gemm_ln_fusion_launches()
+        separate = enc.encode_cls(ids, types, mask).cpu()
+        assert lib.ac_gemm_ln_fusion_launches() == n0
+        nv.check(lib.ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
+        fused = enc.encode_cls(ids, types, mask).cpu()
+        assert lib.ac_gemm_ln_fusion_launches() == n0 + 2 * (layers - 1)       # every layer but the CLS-only last one
+        assert not enc.ln_fusion_aborted()
+        again = enc.encode_cls(ids, types, mask).cpu()
+    finally:
+        nv.check(lib.ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
+    assert torch.equal(fused, again)                                            # the exchange order does not leak into the result
+    assert (fused - separate).abs().max().item() < 5e-6, (fused - separate).abs().max().item()
+    for got in (fused, separate):
+        assert (got - want).abs().max().item() < 1e-4

@@ -1,5 +1,6 @@
 """A/B of per-shape GEMM kernel tables INSIDE the encoder (bert-base, the bench's ragged 256 x 32 batch): interleaved rounds,
-median encode time per table.  usage: encode_ab.py [--large] "name=NxK=cfg;NxK=cfg" ...   (name=  alone = two-buffer kernels)"""
+median encode time per table.  usage: encode_ab.py [--large] "name=NxK=cfg;NxK=cfg" ...   (name=  alone = two-buffer kernels;
+name=@builtin = the built-in choice; name=@builtin-nofuse = the same with the LayerNorms as separate launches)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "adaptive-classifier_amd")]
@@ -26,7 +27,8 @@ times = {n: [] for n, _ in tables}
 ref = None
 for rnd in range(int(os.environ.get("ROUNDS", 3))):
     for name, spec in tables:
-        nv.check(nv.lib().ac_gemm_set_pipe_table(None if spec == "@builtin" else spec.encode()), "table")
+        nv.check(nv.lib().ac_gemm_set_pipe_table(None if spec.startswith("@builtin") else spec.encode()), "table")
+        nv.check(nv.lib().ac_gemm_set_ln_fusion(0 if spec.endswith("-nofuse") else 1), "ln fusion")
         for _ in range(2): out = enc.encode_cls(ids, types, mask)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 10
@@ -35,7 +37,8 @@ for rnd in range(int(os.environ.get("ROUNDS", 3))):
         e1.record(); torch.cuda.synchronize()
         times[name].append(e0.elapsed_time(e1) / n)
         if ref is None: ref = out.clone()
-        assert torch.equal(out, ref), name            # every table computes the same bits
+        if spec.endswith("-nofuse") or tables[0][1].endswith("-nofuse"): assert (out - ref).abs().max().item() < 5e-6, name
+        else: assert torch.equal(out, ref), name       # every table computes the same bits
 for name, spec in tables:
     t = sorted(times[name])
     print(f"{name:12s} med {t[len(t)//2]:.3f} ms  min {t[0]:.3f} ms   tokens {enc.last_tokens}   [{spec}]")
