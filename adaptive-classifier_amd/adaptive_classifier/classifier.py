@@ -435,7 +435,10 @@ class AdaptiveClassifier:
         b, kk, off_cls, off_val, C = layout
         n = host[:off_cls].view(np.int32).tolist()
         cls = host[off_cls:off_cls + 4 * b * kk].view(np.int32).reshape(b, kk)
-        val = host[off_val:].view(np.float64).reshape(b, kk).tolist()
+        val = host[off_val:].view(np.float64).reshape(b, kk)
+        if np.isnan(val).any():
+            self._raise_if_encoder_gave_up()
+        val = val.tolist()
         names = np.array([self.id_to_label[c] for c in range(C)], dtype=object)
         labs = names[np.clip(cls, 0, C - 1)].tolist()
         kcap = k if k >= 0 else 0
@@ -451,10 +454,7 @@ class AdaptiveClassifier:
             return self._blend(None if S is None else S.cpu().numpy(), None if S is None else Cid.cpu().numpy(),
                                None if P is None else P.cpu().numpy(), k, regular)
         out, layout = self._blend_device(S, Cid, P, k, regular)
-        host = out.cpu().numpy()
-        if np.isnan(host).any():
-            self._raise_if_encoder_gave_up()
-        return self._unpack(host, layout, k)
+        return self._unpack(out.cpu().numpy(), layout, k)
 
     def _raise_if_encoder_gave_up(self):
         """NaN scores: if the encoder's fused-LayerNorm GEMM epilogues timed out (a device that cannot hold one workgroup per

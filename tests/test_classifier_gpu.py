@@ -479,3 +479,21 @@ def test_void_persistent_launches_are_repeated_launch_by_launch(cuda_dev, monkey
     assert np.isfinite(got_clf.last_train_info["final_loss"])
     assert torch.allclose(got_clf.adaptive_head.flat_params(), want_clf.adaptive_head.flat_params(), atol=1e-6)
     assert [l for l, _ in got] == [l for l, _ in want] and np.allclose([s for _, s in got], [s for _, s in want], atol=1e-6)
+
+
+def test_gave_up_layernorm_exchange_is_reported_loudly(clf, monkeypatch):
+    """The fused-LayerNorm GEMM epilogues poison their rows with NaN when the tiles of a row panel do not all arrive (a
+    device that cannot hold one workgroup per CU at once); predict paths must then raise, naming the cause, and switch the
+    fusion off for the process -- never hand out NaN scores silently.  Simulated: NaN embeddings + the encoder's verdict."""
+    from adaptive_classifier import _native as nv
+    emb = clf._embed_device(["great product", "awful thing"])
+    monkeypatch.setattr(clf.model, "ln_fusion_aborted", lambda: True, raising=False)
+    before = nv.lib().ac_gemm_ln_fusion_launches()
+    try:
+        with pytest.raises(nv.NativeError, match="fused LayerNorm"):
+            clf.predict_embeddings(emb * float("nan"), k=2)
+        # the switch is off now: an encoder call at a fusable shape launches no fused GEMM
+        clf.model.encode_cls(torch.randint(1000, 2000, (24, 16)), None, torch.ones(24, 16, dtype=torch.int64))
+        assert nv.lib().ac_gemm_ln_fusion_launches() == before
+    finally:
+        nv.check(nv.lib().ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
