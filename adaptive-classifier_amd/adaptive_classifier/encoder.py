@@ -179,6 +179,7 @@ class HipBertEncoder:
                                                    nv.stream_ptr(self.device)), "ac_bert_pack")
                     total, not_prefix, longest, _ = info.tolist()
                     if not not_prefix and total < nb * S:
+                        self.last_one_launch = False
                         nv.check(nv.lib().ac_bert_encode_cls_packed(
                             ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
                             nv.ptr(None if tt is None else tt[r0:r1]), nb, S, nv.ptr(cu), nv.ptr(src), total, longest,
@@ -211,8 +212,8 @@ class HipBertEncoder:
 
     def ln_fusion_aborted(self) -> bool:
         """Verdict of the fused-LayerNorm GEMM epilogues of the last encode_cls() chunk (a 4-byte D2H: stream sync)."""
-        if self._ws is None or self._last_chunk is None:
-            return False
+        if self._ws is None or self._last_chunk is None or self.last_one_launch:
+            return False                      # (the one-launch path has no such epilogue and does not touch the verdict word)
         aborted = ctypes.c_int(0)
         nb, S = self._last_chunk
         nv.check(nv.lib().ac_bert_ln_fusion_status(ctypes.byref(self.ccfg), nb, S, nv.ptr(self._ws), self._ws.numel(),

@@ -121,9 +121,10 @@ int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t l
                         double gamma, uint16_t* qplane, float* thr, float* qfac, hipStream_t stream);
 int knn_thresholds(const double* tauD, int kp, const float* Q, int64_t ldQ, int D, int nq, const uint32_t* maxnorm_bits, double gamma,
                    float* thr, hipStream_t stream);
+int64_t knn_sample_rows(int64_t N, int64_t stride);
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
-                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int64_t row_stride, int best_only,
-                     hipStream_t stream);
+                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int segs, int64_t row_stride,
+                     int best_only, hipStream_t stream);
 
 // arithmetic of the LDS-tiled GEMMs (ac_gemm_set_arith / env AC_GEMM_ARITH = f32 | bf16x3)
 int gemm_arith();

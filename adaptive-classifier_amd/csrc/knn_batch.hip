@@ -145,8 +145,9 @@ struct BatchParams {
     const uint16_t* Qp; int64_t q_rows;      // query plane, q_rows = round_up(nq, 256)
     const float* thr;                        // [q_rows]
     const float* qfac;                       // [q_rows]
-    int64_t N;                               // LOGICAL rows swept: logical row i is store row i * row_stride
-    int64_t row_stride;                      // 1 = the whole store; > 1 = a strided sample (threshold stages)
+    int64_t N;                               // LOGICAL rows swept: logical row i is store row (i >> 3) * 8 * row_stride + (i & 7)
+    int64_t row_stride;                      // 1 = the whole store; > 1 = a sample (threshold stages): runs of 8 consecutive rows --
+                                             // whole 128-byte lines of every k-slot of the plane -- every 8 * row_stride rows
     int best_only;                           // unfiltered sample stage: every lane offers only the best of its 32 rows per query column
     int Kp;
     int nqt;                                 // query tiles of 256 in this launch
@@ -154,7 +155,10 @@ struct BatchParams {
     int sets;                                // query-tile sets (power of two <= 8): XCD x works on set x % sets
     int64_t ntiles;                          // row tiles of 256
     float* cand_d; int32_t* cand_i; int32_t* cand_cnt; int cap;
+    int segs, segcap;                        // a query's list = segs segments of segcap = cap / segs entries, one counter each
 };
+
+typedef const BatchParams __attribute__((address_space(4)))* KArgs;
 
 template <int N> __device__ __forceinline__ void bwait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -164,7 +168,9 @@ template <int N> __device__ __forceinline__ void bwait_vm() { asm volatile("s_wa
 //            (matrix pipe busy 49 % of the SIMD cycles, profiles/r03/knn_batch_sweep_pmc.json).
 //   NWV = 4: 2 x 2 waves of 128 x 128, ONE per SIMD with the 512-register budget (a third fewer fragment bytes per MFMA):
 //            builds, exact, 1.5x slower under hipcc's schedule -- kept as a template argument, not instantiated.
-template <int BNS, int NWV>                   // ring depth, waves
+// BURST: the form for short launches -- sample stages (row_stride > 1, best_only) and sweeps of small stores (segmented
+// lists); BURST = false is the plain whole-store sweep with one list per query that long launches run.
+template <int BNS, int NWV, bool BURST>        // ring depth, waves
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams prm) {
     constexpr int WMW = NWV / 2, TM = BBM / (32 * WMW), TN = 4;    // wave grid WMW x 2, wave tile (32 TM) x 128
     constexpr int GPW = BGA / NWV;                                  // store / query groups each wave stages
@@ -181,7 +187,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
     const int rgx = per_xcd / prm.b;                                // row groups per XCD
     const int g = xr * rgx + j / prm.b, G = xs * rgx;
     if (qt >= prm.nqt) return;                                      // (whole workgroup)
-    const int64_t my_tiles = prm.ntiles > g ? (prm.ntiles - 1 - g) / G + 1 : 0;
+    const int ntiles = (int)prm.ntiles, nrows = (int)prm.N;       // (row and tile indices fit 32 bits: checked at launch)
+    const int my_tiles = ntiles > g ? (ntiles - 1 - g) / G + 1 : 0;
     if (my_tiles == 0) return;
     const int nk = prm.Kp / BSBK;                                   // even (Kp % 64 == 0)
 
@@ -191,12 +198,13 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
     const int64_t a_c1 = 2 * prm.p_rows * 8, w_c1 = 2 * prm.q_rows * 8;   // chunk 1 = two k-slots further
     const uint16_t* pa[GPW];
     const uint16_t* pw[GPW];
-    auto a_base = [&](int64_t it) {
+    const int rs8i = 8 * (int)prm.row_stride;
+    auto a_base = [&](int it) {
 #pragma unroll
         for (int t = 0; t < GPW; ++t) {
-            int64_t row = (it * G + g) * BBM + 32 * (wave + NWV * t) + i32;
-            if (row > prm.N - 1) row = prm.N - 1;
-            pa[t] = prm.Pp + ((int64_t)kg * prm.p_rows + row * prm.row_stride) * 8;
+            int row = (it * G + g) * BBM + 32 * (wave + NWV * t) + i32;
+            if (row > nrows - 1) row = nrows - 1;
+            pa[t] = prm.Pp + ((int64_t)kg * prm.p_rows + (BURST ? (row >> 3) * rs8i + (row & 7) : row)) * 8;
         }
     };
     auto w_base = [&]() {
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
             pw[t] = prm.Qp + ((int64_t)kg * prm.q_rows + ((int64_t)qt * BBN + 32 * (wave + NWV * t) + i32)) * 8;
     };
     a_base(0); w_base();
-    int64_t st_it = 0; int st_k = 0, st_slot = 0;                   // unit / ring slot the next issue() loads
+    int st_it = 0, st_k = 0, st_slot = 0;                   // unit / ring slot the next issue() loads
     auto issue = [&]() {                                            // always PPW DMA instructions (exact vmcnt accounting)
         uint4* dst = lds + st_slot * BSLOT;
 #pragma unroll
@@ -262,54 +270,79 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
     // tile done: v = |p|^2 + f_q acc; keep what beats the query's threshold.  Two passes, so that a wave waits for memory
     // ONCE per tile: (1) a bit mask of the qualifying elements per query column and their count -- no memory operations;
     // (2) one slot reservation (atomicAdd) per query column with candidates, issued back to back, then the stores.
-    int64_t it = 0;
+    int it = 0;
     auto filter = [&]() {
-        const int64_t row0 = (it * G + g) * BBM + wm * (32 * TM);
+        // (the filter's parameters are re-read from the kernel-argument segment here: kept live across the k-loop they exceed
+        //  the scalar registers, and hipcc then parks them in vector lanes and pays ~40 v_readlane per stage to get them back)
+        KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const float* const f_pnorm = ka->pnorm; const float* const f_thr = ka->thr; const float* const f_qfac = ka->qfac;
+        float* const f_cand_d = ka->cand_d; int32_t* const f_cand_i = ka->cand_i; int32_t* const f_cand_cnt = ka->cand_cnt;
+        const int f_cap = ka->cap, f_segs = ka->segs, f_segcap = ka->segcap, f_best_only = ka->best_only;
+        const int row0 = (it * G + g) * BBM + wm * (32 * TM);
+        // Appends reserve their slots with one atomic per lane and query column.  Device-scope atomics on ONE address from all
+        // XCDs serialise at ~0.1 us each (they execute at the memory side): a single counter per query cost 84 of the 140 us
+        // of a 256 x 100k sweep.  So a query's list is split into segments with a counter each, and this lane's (tile, wave
+        // row, lane half) picks the segment -- consecutive 32-row blocks of the store go round the segments, which also keeps
+        // a cluster of neighbouring rows from filling one of them.
+        const int seg = BURST ? (((it * G + g) * (BBM / (32 * TM)) + wm) * 2 + kg) & (f_segs - 1) : 0;
+        const int cidx0 = qcol0 * f_segs + seg, sbase = seg * f_segcap;       // (32-bit: q_rows * segs and cap are far below 2^31)
         // rows (r & 3) + 8 (r >> 2) + 4 kg of a 32-row tile: four runs of 4 norms (the array is padded to whole tiles with
         // +inf: rows past N never qualify)
+        // (logical rows come in runs of 8 = one group of BatchParams::row_stride; a group past the end never qualifies --
+        //  with row_stride == 1 the array is also padded with +inf to whole tiles)
+        const int rs8 = 8 * (int)ka->row_stride, nr = (int)ka->N;
         auto load_pn = [&](int mi, float (&pn)[16]) {
-            if (prm.row_stride == 1) {
+            const int l0 = row0 + mi * 32;                          // multiple of 32
+            if constexpr (!BURST) {                                 // the whole store: contiguous, padded with +inf -- nothing to check
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(prm.pnorm + row0 + mi * 32 + 8 * r4 + 4 * kg);
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(f_pnorm + l0 + 8 * r4 + 4 * kg);
                     pn[4 * r4] = t.x; pn[4 * r4 + 1] = t.y; pn[4 * r4 + 2] = t.z; pn[4 * r4 + 3] = t.w;
                 }
-            } else {                                                // strided sample: one norm at a time, rows past the end never qualify
+            } else {
+                const float* base = f_pnorm + ((l0 >> 3) * rs8 + 4 * kg);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t lr = row0 + mi * 32 + acc_row32(r, lane);
-                    pn[r] = lr < prm.N ? prm.pnorm[lr * prm.row_stride] : INFINITY;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const bool in = l0 + 8 * r4 < nr;
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(in ? base + r4 * rs8 : f_pnorm);
+                    pn[4 * r4] = in ? t.x : INFINITY; pn[4 * r4 + 1] = in ? t.y : INFINITY;
+                    pn[4 * r4 + 2] = in ? t.z : INFINITY; pn[4 * r4 + 3] = in ? t.w : INFINITY;
                 }
             }
         };
         float thr[4], qf[4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) { thr[ni] = prm.thr[qcol0 + 32 * ni]; qf[ni] = prm.qfac[qcol0 + 32 * ni]; }
-        if (prm.best_only) {
+        for (int ni = 0; ni < 4; ++ni) { thr[ni] = f_thr[qcol0 + 32 * ni]; qf[ni] = f_qfac[qcol0 + 32 * ni]; }
+        if (BURST && f_best_only) {
             // The first threshold stage has no threshold yet.  Any k' rows bound the k'-th smallest distance from above, so
             // instead of offering all of the sample (a million appends from the few workgroups a 4096-row sample occupies)
             // every lane offers the best of the 32 * TM rows it holds per query column: 8 offers per (query, 256-row tile).
+            float best[4]; int bidx[4], slot[4];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                float best = INFINITY; int bidx = 0;
+            for (int ni = 0; ni < 4; ++ni) { best[ni] = INFINITY; bidx[ni] = 0; }
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    float pn[16];
-                    load_pn(mi, pn);
+            for (int mi = 0; mi < TM; ++mi) {
+                float pn[16];
+                load_pn(mi, pn);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float val = fmaf(acc[mi][ni][r], qf[ni], pn[r]);
-                        if (val < best) { best = val; bidx = 16 * mi + r; }
+                        if (val < best[ni]) { best[ni] = val; bidx[ni] = 16 * mi + r; }
                     }
-                }
-                if (best < thr[ni]) {
-                    const int slot = atomicAdd(&prm.cand_cnt[qcol0 + 32 * ni], 1);
-                    if (slot < prm.cap) {
-                        prm.cand_d[(size_t)(qcol0 + 32 * ni) * prm.cap + slot] = best;
-                        prm.cand_i[(size_t)(qcol0 + 32 * ni) * prm.cap + slot] = (int32_t)(row0 + (bidx >> 4) * 32 + acc_row32(bidx & 15, lane));
-                    }
-                }
             }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)                          // the four reservations in flight together
+                slot[ni] = best[ni] < thr[ni] ? atomicAdd(&f_cand_cnt[cidx0 + 32 * ni * f_segs], 1) : f_segcap;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                if (slot[ni] < f_segcap) {
+                    const size_t e = (size_t)(qcol0 + 32 * ni) * f_cap + (unsigned)(sbase + slot[ni]);
+                    f_cand_d[e] = best[ni];
+                    f_cand_i[e] = (int32_t)(row0 + (bidx[ni] >> 4) * 32 + acc_row32(bidx[ni] & 15, lane));
+                }
             return;
         }
         unsigned mask[TM / 2][4];                                   // bit 16 (mi & 1) + r of query column ni, row tiles 2 h, 2 h + 1
@@ -338,7 +371,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
             int c = 0;
 #pragma unroll
             for (int h = 0; h < TM / 2; ++h) c += __builtin_popcount(mask[h][ni]);
-            base[ni] = c ? atomicAdd(&prm.cand_cnt[qcol0 + 32 * ni], c) : 0;
+            base[ni] = c ? atomicAdd(&f_cand_cnt[cidx0 + 32 * ni * f_segs], c) : 0;
         }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
@@ -354,9 +387,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
                 for (int r = 0; r < 16; ++r)
                     if ((mask[mi / 2][ni] >> (16 * (mi & 1) + r)) & 1u) {
                         const int slot = base[ni]++;
-                        if (slot < prm.cap) {
-                            prm.cand_d[(size_t)(qcol0 + 32 * ni) * prm.cap + slot] = fmaf(acc[mi][ni][r], qf[ni], pn[r]);
-                            prm.cand_i[(size_t)(qcol0 + 32 * ni) * prm.cap + slot] = (int32_t)(row0 + mi * 32 + acc_row32(r, lane));
+                        if (slot < f_segcap) {
+                            const size_t e = (size_t)(qcol0 + 32 * ni) * f_cap + (unsigned)(sbase + slot);
+                            f_cand_d[e] = fmaf(acc[mi][ni][r], qf[ni], pn[r]);
+                            f_cand_i[e] = (int32_t)(row0 + mi * 32 + acc_row32(r, lane));
                         }
                     }
         }
@@ -417,6 +451,9 @@ namespace ac {
 
 static int knn_kp(int D) { return (D + 63) / 64 * 64; }
 
+// rows of the sample with stride s: runs of 8 consecutive rows every 8 s rows (the incomplete last run is left out)
+int64_t knn_sample_rows(int64_t N, int64_t s) { return s <= 1 ? N : N / (8 * s) * 8; }
+
 size_t knn_planes_bytes(int64_t rows, int D) {
     const int64_t rp = (rows + 255) / 256 * 256;
     return (size_t)rp * knn_kp(D) * sizeof(uint16_t);
@@ -459,10 +496,10 @@ int knn_thresholds(const double* tauD, int kp, const float* Q, int64_t ldQ, int 
     return AC_OK;
 }
 
-// N = rows of the prepared store, row_stride >= 1: sweep the logical rows 0, row_stride, 2 row_stride, ... (ceil(N / row_stride) of them)
+// N = rows of the prepared store, row_stride >= 1: sweep the knn_sample_rows(N, row_stride) logical rows (BatchParams::row_stride)
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
-                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int64_t row_stride, int best_only,
-                     hipStream_t stream) {
+                     const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int segs, int64_t row_stride,
+                     int best_only, hipStream_t stream) {
     // (measured and dropped, profiles/r03/knn_batch_probe*.txt: a ring of 5 slots -- no change, the DMA depth is not the limit;
     //  2 x 2 waves of 128 x 128 with the 512-register budget, one wave per SIMD -- 120 vs 80 ms at 4096 x 10M: hipcc shuffles
     //  ~200 accumulator registers per iteration and a lone wave per SIMD hides nothing)
@@ -470,7 +507,8 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
     const size_t lds = (size_t)ns * BSLOT * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     BatchParams p;
@@ -478,9 +516,10 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
     p.q_rows = ((int64_t)nq + 255) / 256 * 256;
     p.row_stride = row_stride < 1 ? 1 : row_stride;
     p.best_only = best_only;
-    p.N = (N + p.row_stride - 1) / p.row_stride; p.Kp = knn_kp(D);
+    p.N = knn_sample_rows(N, p.row_stride); p.Kp = knn_kp(D);
     p.ntiles = (p.N + BBM - 1) / BBM;
-    p.cap = cap;
+    AC_REQUIRE(N < (int64_t)1 << 31, AC_EUNSUPPORTED, "knn batch: %lld rows (row indices are 32-bit here)", (long long)N);
+    p.cap = cap; p.segs = segs; p.segcap = cap / segs;
     // one persistent workgroup per CU (128 KB of LDS); the grid is a multiple of 8 so every XCD gets the same share
     int nblk = ac::dev_info().cus / 8 * 8;
     if (nblk < 8) nblk = 8;
@@ -498,9 +537,10 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
         const size_t qoff = (size_t)t0 * BBN;
         p.Qp = Qp + qoff * 8;                                       // plane[k/8][q_rows][8]: tile t0 starts at row t0 * 256 of every k-slot
         p.thr = thr + qoff; p.qfac = qfac + qoff;
-        p.cand_d = cand_d + qoff * cap; p.cand_i = cand_i + qoff * cap; p.cand_cnt = cand_cnt + qoff;
+        p.cand_d = cand_d + qoff * cap; p.cand_i = cand_i + qoff * cap; p.cand_cnt = cand_cnt + qoff * segs;
         const dim3 grid((unsigned)nblk), block(64 * nwv);
-        hipLaunchKernelGGL((knn_batch_sweep<ns, nwv>), grid, block, lds, stream, p);
+        if (segs > 1 || p.row_stride > 1 || best_only) hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, false>), grid, block, lds, stream, p);
         AC_LAUNCH_CHECK();
     }
     return AC_OK;

@@ -406,9 +406,11 @@ struct MergeParams {
     double gamma;   // |sweep value - exact| <= gamma (|p| + |q|)^2: n * 2^-24 for the fp32 fma chain (n roundings per term);
                     // the fp16 GEMM-form sweep uses its own bound (knn_batch_gamma, knn_batch.hip)
     // candidate-buffer mode (knn_batch.hip): one list of up to cand_cap entries per query instead of G lists of kp;
-    // cand_cnt[q] = entries offered (may exceed cand_cap: overflow -> exact fallback)
+    // the list is cand_segs segments of cand_cap / cand_segs entries; cand_cnt[q * cand_segs + s] = entries offered to segment s
+    // (may exceed the segment: overflow -> exact fallback)
     const int32_t* cand_cnt;
-    int cand_cap;
+    int cand_cap, cand_segs;
+    int64_t run_stride;      // 0, or 8 * stride of a threshold stage's sample: candidate id i is store row (i >> 3) * run_stride + (i & 7)
     int64_t row_offset;
     const float* part_d;
     const int32_t* part_i;
@@ -483,12 +485,16 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
     const int wave = tid >> 6;
     const int n = prm.cand_cnt ? prm.cand_cap : prm.G * prm.kp;
     const int kp = prm.kp;
-    const int nfill = prm.cand_cnt ? (prm.cand_cnt[q] < n ? prm.cand_cnt[q] : n) : n;    // entries actually written
-    const bool overflow = prm.cand_cnt && prm.cand_cnt[q] > n;
+    // candidate mode (knn_batch.hip): the list is cand_segs segments of segcap entries with a count each; the entries in use
+    // are compacted into LDS (keys + ids), so the selection below walks the ~k' * stride real candidates, not the capacity
+    const int segs = prm.cand_cnt ? prm.cand_segs : 1, segcap = n / segs;
+    const bool cand = segs > 1;                            // (one segment: the list is walked in place, like the per-block lists)
 
-    // LDS: keys[n] u32 | qrow[Dp] f32 | sel[kp] u64 | exact[kp] f64 | hist[256] | misc
+    // LDS: keys[n] u32 | (cand) cid[n] i32 | qrow[Dp] f32 | sel[kp] u64 | exact[kp] f64 | hist[256] | misc
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
     size_t off = ac::align_up((size_t)n * 4, 16);
+    int32_t* cid = reinterpret_cast<int32_t*>(smem + off);
+    if (cand) off += ac::align_up((size_t)n * 4, 16);
     float* qrow = reinterpret_cast<float*>(smem + off);
     off += ac::align_up((size_t)prm.Dp * 4, 16);
     unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem + off);
@@ -497,46 +503,79 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
     off += (size_t)kp * 8;
     int* hist = reinterpret_cast<int*>(smem + off);
     off += 256 * 4;
-    int* misc = reinterpret_cast<int*>(smem + off);       // [0..2] radix broadcast, [4] nsel counter, [5] nreal
+    int* misc = reinterpret_cast<int*>(smem + off);       // [0..2] radix broadcast, [4] nsel counter, [5] nreal, [6] segment overflow
     double* dmisc = reinterpret_cast<double*>(misc + 8);  // [0] qnorm2, [1] exact k-th
 
-    // monotone 32-bit key of the sweep value; padding (id < 0) sorts last
     const float* pd = prm.part_d + (size_t)q * n;
     const int32_t* pi = prm.part_i + (size_t)q * n;
-    int nreal_local = 0;
-#pragma unroll 8
-    for (int t = tid; t < n; t += kMergeThreads) {          // (unrolled: the loads of several candidates in flight)
-        const bool real = t < nfill && pi[t] >= 0;
-        keys[t] = real ? fkey(pd[t]) : 0xffffffffu;
-        nreal_local += real ? 1 : 0;
-    }
+    if (tid < 8) misc[tid] = 0;
     for (int c = tid; c < prm.Dp; c += kMergeThreads)
         qrow[c] = c < prm.D ? prm.Q[(size_t)q * prm.ldQ + c] : 0.f;
-    if (tid < 8) misc[tid] = 0;
+    int nkeys = n;                                         // key slots the selection walks
+    if (cand) {
+        // segment s holds min(count, segcap) entries; exclusive offsets by a block scan (segs <= 256 = one per thread)
+        __shared__ int seg_off[kMergeThreads + 1];
+        __shared__ int scan_tot[kMergeThreads / 64];
+        const int raw = tid < segs ? prm.cand_cnt[(size_t)q * segs + tid] : 0;
+        const int mine = raw < segcap ? raw : segcap;
+        int c = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(c, o); if (lane >= o) c += v; }
+        if (lane == 63) scan_tot[wave] = c;
+        __syncthreads();
+        if (raw > segcap) misc[6] = 1;                     // (benign race: every writer stores 1)
+        for (int w = 0; w < wave; ++w) c += scan_tot[w];
+        seg_off[tid + 1] = c;
+        if (tid == 0) seg_off[0] = 0;
+        __syncthreads();
+        nkeys = seg_off[kMergeThreads];
+        for (int j = tid; j < nkeys; j += kMergeThreads) {
+            int lo = 0, hi = segs;                         // largest s with seg_off[s] <= j
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_off[mid] <= j) lo = mid; else hi = mid; }
+            const int t = lo * segcap + (j - seg_off[lo]);
+            keys[j] = fkey(pd[t]);
+            cid[j] = pi[t];
+        }
+        if (tid == 0) misc[5] = nkeys;
+    } else {
+        // monotone 32-bit key of the sweep value; padding (id < 0) and slots past the count sort last
+        const int raw = prm.cand_cnt ? prm.cand_cnt[q] : n;
+        const int nfill = raw < n ? raw : n;
+        if (tid == 0 && raw > n) misc[6] = 1;
+        int nreal_local = 0;
+#pragma unroll 8
+        for (int t = tid; t < n; t += kMergeThreads) {      // (unrolled: the loads of several candidates in flight)
+            const bool real = t < nfill && pi[t] >= 0;
+            keys[t] = real ? fkey(pd[t]) : 0xffffffffu;
+            nreal_local += real ? 1 : 0;
+        }
+        __syncthreads();
+        atomicAdd(&misc[5], nreal_local);
+    }
     __syncthreads();
-    atomicAdd(&misc[5], nreal_local);
-    __syncthreads();
+    const bool overflow = misc[6] != 0;
     const int nreal = misc[5];
     const int nsel = nreal < kp ? nreal : kp;     // how many candidates we re-rank
+    auto id_of = [&](int t) -> int32_t { return cand ? cid[t] : pi[t]; };
 
     // ---- the nsel-th smallest sweep value T; ties at T are resolved by the lowest ids ----
     uint32_t T = 0xffffffffu;
     int32_t tie_id_max = 0x7fffffff;
     if (nsel > 0) {
         int r = 0, c_eq = 0;
-        T = block_radix_select(n, nsel, [&](int t) { return keys[t]; },
+        T = block_radix_select(nkeys, nsel, [&](int t) { return keys[t]; },
                                [&](int t) { return keys[t] != 0xffffffffu; }, hist, misc, &r, &c_eq);
         if (c_eq != r) {     // rare: several candidates share the boundary value -> r lowest ids of them
             int r2 = 0, c2 = 0;
             tie_id_max = (int32_t)block_radix_select(
-                n, r, [&](int t) { return (uint32_t)pi[t]; },
+                nkeys, r, [&](int t) { return (uint32_t)id_of(t); },
                 [&](int t) { return keys[t] != 0xffffffffu && keys[t] == T; }, hist, misc, &r2, &c2);
         }
     }
     // ---- compact the selected candidates ----
-    for (int t = tid; t < n; t += kMergeThreads) {
+    for (int t = tid; t < nkeys; t += kMergeThreads) {
         const uint32_t key0 = keys[t];
-        const int32_t id = key0 != 0xffffffffu ? pi[t] : -1;
+        const int32_t id = key0 != 0xffffffffu ? id_of(t) : -1;
         if (nsel > 0 && id >= 0) {
             const uint32_t key = key0;
             if (key < T || (key == T && id <= tie_id_max)) {
@@ -553,7 +592,8 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
     const int nc4 = prm.Dp >> 2;
     for (int s = wave; s < ns; s += kMergeThreads / 64) {
         const int32_t id = (int32_t)(uint32_t)(sel[s] & 0xffffffffull);
-        const f32x4* prow = reinterpret_cast<const f32x4*>(prm.P + (size_t)id * prm.ldP);
+        const int64_t prow_i = prm.run_stride ? (int64_t)(id >> 3) * prm.run_stride + (id & 7) : (int64_t)id;     // (threshold stages: sample row -> store row)
+        const f32x4* prow = reinterpret_cast<const f32x4*>(prm.P + (size_t)prow_i * prm.ldP);
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll 4
         for (int c4 = lane; c4 < nc4; c4 += 64) {
@@ -1073,7 +1113,7 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
     mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = pl.Dp;
     mp.k = k; mp.kp = pl.kp; mp.G = pl.G; mp.nblk = pl.G * pl.nqt;
     mp.gamma = 1.01 * (double)(pl.ng * kGroup * 16 + 16) * 5.9604644775390625e-08;    // n * 2^-24, n roundings per term
-    mp.cand_cnt = nullptr; mp.cand_cap = 0;
+    mp.cand_cnt = nullptr; mp.cand_cap = 0; mp.cand_segs = 1; mp.run_stride = 0;
     mp.row_offset = row_offset;
     mp.part_d = (const float*)(ws + pl.off_part_d);
     mp.part_i = (const int32_t*)(ws + pl.off_part_i);
@@ -1146,6 +1186,7 @@ constexpr int64_t kBatchMinRows = 65536;
 struct BatchPlan {
     int kp, cap, Dp;
     int64_t stride, stride_a, S, q_rows;
+    int segs;
     size_t off_sD32, off_sD64, off_sI, off_thr, off_qfac, off_cnt, off_qp, off_cd, off_ci, off_flags, off_fb_d, off_fb_i, off_fb_ctr,
         off_sub, sub_bytes, total;
     int fb_S, fb_F;
@@ -1177,11 +1218,20 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     if (stride > smax) stride = smax;                  // stage B's (or, for small stores, stage A's own) stride
     bp->stride_a = stride_a;
     bp->stride = stride;
-    bp->S = (N + stride_a - 1) / stride_a;               // rows of the stage-A sample
+    bp->S = ac::knn_sample_rows(N, stride_a);            // rows of the stage-A sample
     const int64_t expect = (int64_t)bp->kp * stride;             // E[candidates per query] of the main sweep = k' * stride
     int cap = 1024;
     while (cap < 2 * expect && cap < 16384) cap <<= 1;
+    // Short launches (a sample stage, or the whole sweep of a small store) fire all their appends in one burst, and the
+    // device-scope atomics that reserve the slots serialise per address (~0.1 - 0.5 us each: 84 of the 140 us of a 256 x 100k
+    // sweep with one counter per query).  Such launches split a query's list into up to 64 segments with a counter each
+    // (>= 256 entries per segment: a segment overflows no more easily than the whole list would); long launches keep ONE list
+    // -- their workgroups drift apart, and a single hot counter line per query is then the cheaper form (10M x 768 x 4096: 68.8 ms
+    // against 75.8 with 16 segments).  batch_segs() picks per launch.
+    const int segs_want = nq <= 256 ? 64 : (nq <= 1024 ? 32 : 16);
+    if (cap < 256 * segs_want) cap = 256 * segs_want;
     bp->cap = cap;
+    bp->segs = cap / 256 < segs_want ? cap / 256 : segs_want;          // the most any launch of this call uses
     bp->q_rows = ((int64_t)nq + 255) / 256 * 256;
     const size_t sub = 256;                                // (the exact sample search of round 2 needed a workspace of its own)
     bp->sub_bytes = sub;
@@ -1192,7 +1242,7 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     bp->off_sI = take((size_t)nq * bp->kp * 8);
     bp->off_thr = take((size_t)bp->q_rows * 4);
     bp->off_qfac = take((size_t)bp->q_rows * 4);
-    bp->off_cnt = take((size_t)bp->q_rows * 4);
+    bp->off_cnt = take((size_t)bp->q_rows * 4 * bp->segs);
     bp->off_qp = take(ac::knn_planes_bytes(nq, D));
     bp->off_cd = take((size_t)bp->q_rows * cap * 4);
     bp->off_ci = take((size_t)bp->q_rows * cap * 4);
@@ -1206,7 +1256,7 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     bp->off_fb_ctr = take(256);
     bp->off_sub = take(sub);
     bp->total = off;
-    bp->merge_lds = ac::align_up((size_t)cap * 4, 16) + ac::align_up((size_t)bp->Dp * 4, 16) + (size_t)bp->kp * 16 + 256 * 4 + 64;
+    bp->merge_lds = 2 * ac::align_up((size_t)cap * 4, 16) + ac::align_up((size_t)bp->Dp * 4, 16) + (size_t)bp->kp * 16 + 256 * 4 + 64;   // (segmented form; one segment needs cap * 4 less)
     bp->fb_lds = (size_t)kFbCap * 12 + ac::align_up((size_t)bp->Dp, 4) * 4 + 64;
     return AC_OK;
 }
@@ -1240,6 +1290,13 @@ extern "C" int ac_knn_l2_topk_batch_workspace(int64_t N, int D, int nq, int k, s
     return AC_OK;
 }
 
+// segments of a query's candidate list for a launch that sweeps `rows` rows (see make_batch_plan)
+static int batch_segs(const BatchPlan& bp, int64_t rows, int nq) {
+    const int64_t tiles = ((rows + 255) / 256) * (((int64_t)nq + 255) / 256);
+    const int64_t per_wg = (tiles + ac::dev_info().cus - 1) / ac::dev_info().cus;
+    return per_wg <= 8 ? bp.segs : 1;
+}
+
 extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, int D, const uint16_t* d_planes,
                                     const float* d_norms, const float* d_Q, int nq, int64_t ldQ, int k, int64_t row_offset,
                                     float* d_outD, double* d_outD64, int64_t* d_outI, void* d_ws, size_t ws_bytes,
@@ -1267,7 +1324,7 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     MergeParams sp;
     sp.P = d_P; sp.Q = d_Q; sp.ldQ = ldQ; sp.D = D; sp.Dp = bp.Dp;
     sp.k = bp.kp; sp.kp = bp.kp; sp.G = 1; sp.nblk = 1; sp.gamma = gamma;
-    sp.cand_cnt = (const int32_t*)(ws + bp.off_cnt); sp.cand_cap = bp.cap; sp.row_offset = 0;
+    sp.cand_cnt = (const int32_t*)(ws + bp.off_cnt); sp.cand_cap = bp.cap; sp.cand_segs = bp.segs; sp.row_offset = 0;
     sp.part_d = (const float*)(ws + bp.off_cd); sp.part_i = (const int32_t*)(ws + bp.off_ci);
     sp.part_maxnorm = reinterpret_cast<const float*>(d_maxnorm);
     sp.outD = (float*)(ws + bp.off_sD32); sp.outD64 = (double*)(ws + bp.off_sD64); sp.outI = (int64_t*)(ws + bp.off_sI);
@@ -1279,13 +1336,16 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     const int nstages = bp.stride_a > bp.stride ? 2 : 1;
     for (int st = 0; st < nstages; ++st) {
         const int64_t sst = stage_stride[st];
-        AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4, stream));
+        const int segs = batch_segs(bp, ac::knn_sample_rows(N, sst), nq);
+        const size_t mlds = bp.merge_lds - (segs > 1 ? 0 : ac::align_up((size_t)bp.cap * 4, 16));
+        sp.cand_segs = segs;
+        AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4 * segs, stream));
         rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
                                   (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci),
-                                  (int32_t*)(ws + bp.off_cnt), bp.cap, sst, st == 0 ? 1 : 0, stream);
+                                  (int32_t*)(ws + bp.off_cnt), bp.cap, segs, sst, st == 0 ? 1 : 0, stream);
         if (rc != AC_OK) return rc;
-        sp.N = (N + sst - 1) / sst; sp.ldP = ldP * sst;           // logical sample row i = store row i * sst
-        hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), bp.merge_lds, stream, sp);
+        sp.N = ac::knn_sample_rows(N, sst); sp.ldP = ldP; sp.run_stride = sst > 1 ? 8 * sst : 0;   // sample row i = store row (i >> 3) * 8 sst + (i & 7)
+        hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), mlds, stream, sp);
         AC_LAUNCH_CHECK();
         rc = ac::knn_thresholds((const double*)(ws + bp.off_sD64), bp.kp, d_Q, ldQ, D, nq, d_maxnorm, gamma, (float*)(ws + bp.off_thr), stream);
         if (rc != AC_OK) return rc;
@@ -1300,11 +1360,13 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
                     (long long)sst, (long long)sp.N, bp.cap, bp.kp, cnt[0], cnt[1], cnt[2], cnt[3], tau[0], tau[1], tau[2], tau[3], thr[0], thr[1], thr[2], thr[3]);
         }
     }
-    AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4, stream));
+    const int msegs = batch_segs(bp, N, nq);
+    const size_t mlds = bp.merge_lds - (msegs > 1 ? 0 : ac::align_up((size_t)bp.cap * 4, 16));
+    AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4 * msegs, stream));
     // 3. the GEMM-form sweep: candidates (row, v) with v below the query's threshold
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
     rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
-                              (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, 1, 0, stream);
+                              (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, msegs, 1, 0, stream);
     if (rc != AC_OK) return rc;
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_stop, stream));
     // 4. merge + exact re-rank + certificate, then the exact fallback for uncertified queries
@@ -1312,7 +1374,7 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     MergeParams mp;
     mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = bp.Dp;
     mp.k = k; mp.kp = bp.kp; mp.G = 1; mp.nblk = 1; mp.gamma = gamma;
-    mp.cand_cnt = (const int32_t*)(ws + bp.off_cnt); mp.cand_cap = bp.cap;
+    mp.cand_cnt = (const int32_t*)(ws + bp.off_cnt); mp.cand_cap = bp.cap; mp.cand_segs = msegs; mp.run_stride = 0;
     mp.row_offset = row_offset;
     mp.part_d = (const float*)(ws + bp.off_cd); mp.part_i = (const int32_t*)(ws + bp.off_ci);
     mp.part_maxnorm = reinterpret_cast<const float*>(d_maxnorm);
@@ -1323,7 +1385,7 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     mp.fb_d = (double*)(ws + bp.off_fb_d); mp.fb_i = (int32_t*)(ws + bp.off_fb_i); mp.fb_slotctr = (int32_t*)(ws + bp.off_fb_ctr);
     AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_fb_ctr, 0, 256, stream));
     (void)hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.merge_lds);
-    hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), bp.merge_lds, stream, mp);
+    hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), mlds, stream, mp);
     AC_LAUNCH_CHECK();
     (void)hipFuncSetAttribute((const void*)knn_exact_fallback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.fb_lds);
     hipLaunchKernelGGL(knn_exact_fallback, dim3(bp.fb_S, nq), dim3(kFbThreads), bp.fb_lds, stream, mp);

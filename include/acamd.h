@@ -510,7 +510,8 @@ int ac_bert_encode_cls_opts(const ac_bert_config* cfg, const ac_bert_weights* w,
 int ac_bert_one_launch_status(const ac_bert_config* cfg, int b, int S, const void* d_ws, size_t ws_bytes,
                               int* aborted, ac_stream_t stream);
 /* Verdict of the fused-LayerNorm GEMM epilogues (ac_gemm_set_ln_fusion) of the LAST ac_bert_encode_cls[_opts|_packed] call
- * that used this workspace (same cfg, b, S): *aborted = 1 when the tiles of a row panel did not all arrive within the
+ * that used this workspace (same cfg, b, S) and ran layer by layer (the one-launch path of <= 32 token rows neither has such
+ * an epilogue nor resets the verdict word: do not ask after it): *aborted = 1 when the tiles of a row panel did not all arrive within the
  * bounded wait (possible only if the device cannot hold one workgroup per CU at once, e.g. under a CU mask); the output
  * rows are NaN then -- repeat after ac_gemm_set_ln_fusion(0).  Synchronises the stream (a 4-byte D2H). */
 int ac_bert_ln_fusion_status(const ac_bert_config* cfg, int b, int S, const void* d_ws, size_t ws_bytes,

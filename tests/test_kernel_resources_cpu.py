@@ -1,0 +1,39 @@
+"""Build hygiene of the two MFMA pipelines (no GPU needed: hipcc cross-compiles): the ring-staged kernels run at the register
+limit of their occupancy (256 VGPRs, two waves per SIMD), and a few more live values make hipcc spill -- a scratch reload with
+its s_waitcnt vmcnt(0) inside the k-loop drains the whole LDS-DMA ring every stage (seen twice while tuning: +8 .. 14 % time).
+The device listing must show no scratch for them."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "adaptive-classifier_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def kernel_resources(src):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-S",
+                               "--cuda-device-only", os.path.join(CSRC, src), "-o", out], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+        name, body = m.group(1), m.group(2)
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        res[name] = (scratch, vgpr)
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src,pattern", [("knn_batch.hip", "knn_batch_sweep"), ("gemm_pipe.hip", "gemm_pipe_nt")])
+def test_ring_staged_kernels_do_not_spill(src, pattern):
+    res = {k: v for k, v in kernel_resources(src).items() if pattern in k}
+    assert res, "no %s kernels found in the listing" % pattern
+    spilled = {k: v for k, v in res.items() if v[0] != 0}
+    assert not spilled, "kernels with scratch (scratch bytes, vgprs): %r" % spilled
+    assert all(v[1] <= 512 for v in res.values())
