@@ -433,16 +433,21 @@ class AdaptiveClassifier:
     def _unpack(self, host, layout, k: int):
         """The packed result of _blend_device (already on the host, numpy uint8) -> list of (label, score) per query."""
         b, kk, off_cls, off_val, C = layout
-        n = host[:off_cls].view(np.int32).tolist()
-        cls = host[off_cls:off_cls + 4 * b * kk].view(np.int32).reshape(b, kk)
-        val = host[off_val:].view(np.float64).reshape(b, kk)
+        n = host[:off_cls].view(np.int32)
+        cls = host[off_cls:off_cls + 4 * b * kk].view(np.int32)
+        val = host[off_val:].view(np.float64)
         if np.isnan(val).any():
             self._raise_if_encoder_gave_up()
-        val = val.tolist()
-        names = np.array([self.id_to_label[c] for c in range(C)], dtype=object)
-        labs = names[np.clip(cls, 0, C - 1)].tolist()
-        kcap = k if k >= 0 else 0
-        return [list(zip(labs[q][:min(n[q], kcap)], val[q][:min(n[q], kcap)])) for q in range(b)]
+        names = getattr(self, "_label_array", None)              # (kept for big label sets only: small ones are rebuilt per call)
+        if C <= 64 or names is None or names[0] is not self.id_to_label or len(names[1]) != C:
+            names = self._label_array = (self.id_to_label, np.array([self.id_to_label[c] for c in range(C)], dtype=object))
+        # one pass over the flat arrays (a tuple per hit is what the reference returns); rows are slices of it
+        pairs = list(zip(names[1][np.clip(cls, 0, C - 1)].tolist(), val.tolist()))
+        kcap = min(kk, k) if k >= 0 else 0
+        if int(n.min()) >= kcap:
+            return [pairs[i:i + kcap] for i in range(0, b * kk, kk)]
+        n = n.tolist()
+        return [pairs[q * kk:q * kk + min(n[q], kcap)] for q in range(b)]
 
     def _finish(self, S, Cid, P, k: int, regular: bool, b: int = 0):
         """Blend + normalise + top-k of one device stage -> the reference's list of (label, score) per query.
