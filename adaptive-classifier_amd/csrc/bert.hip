@@ -603,8 +603,11 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
                                          base + ws.lnpart, ln_count + (size_t)(2 * l) * ln_panels, ln_abort, xp, stream);
             if (rc) return rc;
         } else {
-            rc = ac::linear_f32(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f, stream,
-                                0.f, 0, ao_w3, lp ? ctxp : nullptr);
+            // (last layer: b CLS rows = a handful of output tiles -> split-K over the qkv buffer, which is dead by now)
+            rc = last ? ac::linear_f32_splitk(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, ao_w3, qkv,
+                                              (size_t)T * 3 * H * sizeof(float), stream)
+                      : ac::linear_f32(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f, stream,
+                                       0.f, 0, ao_w3, lp ? ctxp : nullptr);
             if (rc) return rc;
             // (last layer: x is overwritten with b compact rows; its old contents are no longer needed)
             hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln1_g[l], w->ln1_b[l],
@@ -612,8 +615,10 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
             AC_LAUNCH_CHECK();
         }
         float* x1 = last ? ctx : x;                    // ctx is free again after the AO projection
-        rc = ac::linear_f32(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, nullptr, 1.f, stream,
-                            0.f, 0, ff1_w3, lp ? xp : nullptr, lp ? ffnp : nullptr);
+        rc = last ? ac::linear_f32_splitk(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, ff1_w3, qkv,
+                                          (size_t)T * 3 * H * sizeof(float), stream)
+                  : ac::linear_f32(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, nullptr, 1.f, stream,
+                                   0.f, 0, ff1_w3, lp ? xp : nullptr, lp ? ffnp : nullptr);
         if (rc) return rc;
         if (fl) {                                      // x <- LayerNorm(x + ffn W2^T + b), planes for the next layer's QKV GEMM
             rc = ac::launch_gemm_pipe_ln(ffnp, Ml, ff2_w3, H, w->ff2_b[l], x, H, x, H, Ml, H, I, w->ln2_g[l], w->ln2_b[l], c.ln_eps,
@@ -621,8 +626,10 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
             if (rc) return rc;
             continue;
         }
-        rc = ac::linear_f32(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, nullptr, 1.f, stream, 0.f, 0,
-                            ff2_w3, lp ? ffnp : nullptr);
+        rc = last ? ac::linear_f32_splitk(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, ff2_w3, qkv,
+                                          (size_t)T * 3 * H * sizeof(float), stream)
+                  : ac::linear_f32(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, nullptr, 1.f, stream, 0.f, 0,
+                                   ff2_w3, lp ? ffnp : nullptr);
         if (rc) return rc;
         // the next layer's QKV GEMM reads x as planes; the last layer's output (b compact rows) stays fp32
         hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln2_g[l], w->ln2_b[l],

@@ -409,6 +409,102 @@ __global__ __launch_bounds__(128 * WMW, (WMW == 2 ? 3 : 4)) void gemm_planes_nt(
     } else store_tile<EPI, TM, BM>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, epi);
 }
 
+// ---- split-K form for GEMMs with few output tiles (the CLS-only last encoder layer: 256 rows) ----
+// 24 tiles of 64 x 128 on 256 CUs leave 90 % of the chip idle through a K = 3072 loop (185 us for 1.2 GFLOP).  Here the
+// grid is tiles x ksplit: workgroup (tile, z) accumulates k in [z K / ksplit, (z + 1) K / ksplit) and stores its raw fp32
+// tile into slice z of a scratch buffer; gemm_splitk_reduce adds the slices in order z = 0, 1, ... (deterministic) and
+// applies the epilogue.  Staging and MFMA order inside a slice are those of gemm_planes_nt<., 1, false, false>.
+__global__ __launch_bounds__(256, 3) void gemm_planes_splitk_nt(const float* __restrict__ A, int64_t lda,
+                                                                const uint16_t* __restrict__ Wp, int64_t w_rows,
+                                                                float* __restrict__ part, int M, int N, int K, int ksplit) {
+    constexpr int BM = 64, RA = 2, RW = BN / 32;
+    __shared__ uint4 lds[2][3][(RA + RW) * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (N + BN - 1) / BN;
+    const int ntiles = (int)gridDim.x / ksplit, z = (int)blockIdx.x / ntiles, tile = (int)blockIdx.x - z * ntiles;
+    const int bn = tile % ntn, bm = tile / ntn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int i = lane & 31, kg = lane >> 5;
+    int wrow = n0 + 32 * (wave & 3) + i; if (wrow > N - 1) wrow = N - 1;
+    const uint16_t* wsrc = Wp + ((int64_t)kg * w_rows + wrow) * 8;
+    const int64_t w_plane = w_rows * (int64_t)K, w_step = 2 * w_rows * 8;
+    const int frow = tid >> 1, fkg = tid & 1;
+    int farow = m0 + frow; if (farow > M - 1) farow = M - 1;
+    const float* fsrc = A + (int64_t)farow * lda + 8 * fkg;
+    const int fslot = (frow >> 5) * 64 + fkg * 32 + (frow & 31);
+    const bool fact = frow < BM;
+    auto stage_glds = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc + p * w_plane + kt * w_step),
+                                             (lds_void_t*)&lds[buf][p][(RA + wave) * 64], 16, 0, 0);
+    };
+    f32x4 fa0, fa1;
+    auto load_a = [&](int kt) {
+        fa0 = *reinterpret_cast<const f32x4*>(fsrc + kt * SBK);
+        fa1 = *reinterpret_cast<const f32x4*>(fsrc + kt * SBK + 4);
+    };
+    auto store_a = [&](int buf) {
+        uint4 H, Mi, L;
+        split8(fa0, fa1, H, Mi, L);
+        if (fact) { lds[buf][0][fslot] = H; lds[buf][1][fslot] = Mi; lds[buf][2][fslot] = L; }
+    };
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+    const int nks = K / SBK / ksplit, kt_lo = z * nks, kt_hi = kt_lo + nks;
+    stage_glds(kt_lo, 0);
+    load_a(kt_lo); store_a(0);
+    __syncthreads();
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int cur = (kt - kt_lo) & 1;
+        const int nxt = (kt + 1 < kt_hi) ? kt + 1 : kt;
+        stage_glds(nxt, cur ^ 1);
+        load_a(nxt);
+        bf16x8_t af[3], bf[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            af[pl] = __builtin_bit_cast(bf16x8_t, lds[cur][pl][wm * 64 + lane]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b][pl] = __builtin_bit_cast(bf16x8_t, lds[cur][pl][(RA + 2 * wn + b) * 64 + lane]);
+        }
+        constexpr int PAIRS[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};   // smallest products first
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PAIRS[pr][0]], bf[b][PAIRS[pr][1]], acc[0][b], 0, 0, 0);
+        store_a(cur ^ 1);
+        __syncthreads();
+    }
+    Epilogue none{};
+    store_tile<EPI_IDENT, 1, BM>(acc, part + (size_t)z * M * N, N, M, N, m0, n0, wm, wn, lane, none);
+}
+
+// C = epi(sum_z part[z]): four outputs per thread, slices added in order
+__global__ __launch_bounds__(256) void gemm_splitk_reduce(const float* __restrict__ part, int ksplit, int M, int N, float* __restrict__ C,
+                                                          int64_t ldc, Epilogue epi) {
+    const int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = N >> 2;
+    if (e4 >= (int64_t)M * n4) return;
+    const int row = (int)(e4 / n4), col = (int)(e4 % n4) * 4;
+    const size_t slice = (size_t)M * N;
+    f32x4 s = *reinterpret_cast<const f32x4*>(part + (size_t)row * N + col);
+    for (int z = 1; z < ksplit; ++z) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(part + z * slice + (size_t)row * N + col);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    float* dst = C + (int64_t)row * ldc + col;
+    dst[0] = apply_epilogue(epi, s.x, row, col, C, ldc, N);
+    dst[1] = apply_epilogue(epi, s.y, row, col + 1, C, ldc, N);
+    dst[2] = apply_epilogue(epi, s.z, row, col + 2, C, ldc, N);
+    dst[3] = apply_epilogue(epi, s.w, row, col + 3, C, ldc, N);
+}
+
 // ---------------------------------------------------------------------------------------------
 // direct kernel: one 32x32 tile per block, K split over 4 waves
 //   AK: A element (m,k) at A[m*lda + k] (K-major) else A[k*lda + m]
@@ -779,6 +875,33 @@ int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const f
     e.mask = mask; e.mask_scale = mask_scale; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f;
     e.drop_p = mask ? 0.f : drop_p; e.drop_seed = drop_seed;
     return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream, Wp, N, Ap, M, Cp);
+}
+// linear_f32 for shapes with few output tiles: split-K over `scratch` (see gemm_planes_splitk_nt); falls back to
+// linear_f32 when the shape has enough tiles, the arithmetic is not bf16x3, or the scratch is too small.
+int linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,
+                      int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act, const uint16_t* Wp, float* scratch,
+                      size_t scratch_bytes, hipStream_t stream) {
+    const int cus = dev_info().cus;
+    const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + BN - 1) / BN);
+    int ksplit = 1;
+    if (Wp && scratch && gemm_arith() == AC_GEMM_BF16X3 && gemm_variant() == 0 && M >= 65 && M <= 512 && (N % 4) == 0 &&
+        (K % 32) == 0 && (lda % 4) == 0 && ((((uintptr_t)A) & 15) == 0) && 2 * tiles <= cus) {
+        const int nk = K / SBK;
+        // as many slices as fill ~1.5 workgroups per CU, each at least 6 stages long, dividing the stage count
+        for (int c = 2; c <= 32; ++c)
+            if (nk % c == 0 && nk / c >= 6 && tiles * c <= (int64_t)cus * 3 / 2 && (size_t)c * M * N * sizeof(float) <= scratch_bytes) ksplit = c;
+    }
+    if (ksplit == 1)
+        return linear_f32(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, nullptr, 1.f, stream, 0.f, 0, Wp);
+    hipLaunchKernelGGL(gemm_planes_splitk_nt, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, stream, A, lda, Wp, (int64_t)N, scratch, M, N, K, ksplit);
+    AC_LAUNCH_CHECK();
+    Epilogue e;
+    e.bias = bias; e.residual = residual; e.ldr = ldr; e.act = act; e.alpha = 1.f; e.beta = 0.f;
+    e.mask = nullptr; e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;
+    const int64_t n4 = (int64_t)M * (N / 4);
+    hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, scratch, ksplit, M, N, C, ldc, e);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
 }
 int head_backward_pair(const float* dY, int64_t ldy, const float* Aact, int64_t lda_act, const float* W, int64_t ldw, int B,
                        int Hout, int Hin, float gate_scale, float* gW, float* dA, float* gb_in, hipStream_t stream) {
