@@ -742,9 +742,12 @@ def main():
                                                           "note": "NOT a roofline fraction: the FLOPs the reference's padded forward spends on this "
                                                                   "batch divided by the time this path takes for the same outputs"}},
             "roofline_knn_batch": {"bound": "mfma", "achieved": knn_flops / stages["knn_ms"] / 1e9,
-                                   "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                   "frac": knn_flops / stages["knn_ms"] / 1e9 / F32_MFMA_PEAK_TF,
-                                   "note": "kNN of the timed step (256 queries/GPU) is compute bound, not HBM bound"},
+                                   "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": knn_flops / stages["knn_ms"] / 1e9 / BF16_MFMA_PEAK_TF,
+                                   "note": "the WHOLE kNN stage of the timed step (threshold stage, fp16 one-product sweep, merges / "
+                                           "exact re-rank) against the fp16 dense MFMA peak: at 256 queries x 100k rows the stage is "
+                                           "launch- and append-bound, not MFMA-bound (the sweep kernel alone reaches 0.38 of that peak "
+                                           "at 4096 x 10M: profiles/r03/knn_batch_sweep_pmc.json)"},
         }
         if world == 1 and not args.no_sweep:
             free, _ = torch.cuda.mem_get_info(dev)
