@@ -44,6 +44,7 @@ struct LnFuse {
     unsigned* count;        // [row panels]
     unsigned* abort_;       // set when a row panel's tiles did not all arrive (the results are NaN then)
     uint16_t* planes;       // [3][N/8][M][8] or null
+    int starve;             // test hook (ac_gemm_set_ln_fusion(2)): wait for one arrival more than will ever come
 };
 
 __device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, int64_t row, int col,

@@ -90,7 +90,8 @@ __device__ __forceinline__ void ln_prefetch_residual(float (&res)[TM * TN * 16],
 // ---- EPI_BIAS_RES_LN: y = acc + bias + residual, LayerNorm over the whole row, result as fp32 rows AND operand planes ----
 // A row of the output spans the N / BN tiles of its row panel; each tile reduces its BN columns to a per-row (mean, M2),
 // publishes them (sc1 stores), counts itself into the panel's counter and waits for the others -- all tiles of a panel are
-// co-resident because the launch is ONE round of one workgroup per CU (launch_gemm_pipe_ln refuses anything else) -- then
+// co-resident because the launch is ONE round of one workgroup per CU (launch_gemm_pipe_ln refuses anything else; two such launches interleaved on one
+// device by two processes could still starve each other: the wait is bounded and the rows turn NaN, which the host reports) -- then
 // combines the partials (Chan et al.: equal counts), normalises its accumulators in place and stores them twice.
 // Replaces a separate LayerNorm launch (read fp32 y, write fp32 x + planes: 20 us at 5141 x 768) by ~3 us of exchange.
 template <int TM, int TN, int WMW, int WNW>
@@ -151,12 +152,14 @@ __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float
     if (tid == 0) __hip_atomic_fetch_add(ln.count + bm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // 4. wait for the panel's other tiles (bounded: a bug or a CU mask must not hang the GPU -- the rows become NaN instead)
     if (tid < 64) {
+        // (~1 us per poll: gives up after about a second; once one panel has given up -- the flag is per encoder call -- the
+        //  later launches of that call stop waiting at their first look at it instead of a second each)
         unsigned ok = 1;
         for (long spins = 0;; ++spins) {
             const unsigned v = __hip_atomic_load(ln.count + bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v >= (unsigned)ntn) break;
+            if (v >= (unsigned)(ntn + ln.starve)) break;
             __builtin_amdgcn_s_sleep(1);
-            if ((spins & 1023) == 1023 && (spins > (1l << 22) || __hip_atomic_load(ln.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if ((spins & 63) == 63 && (spins > (1l << 20) || __hip_atomic_load(ln.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 if (lane == 0) __hip_atomic_store(ln.abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
@@ -516,7 +519,7 @@ int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, 
     e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;
     p.epi = e;
     p.ln.gamma = gamma; p.ln.beta = beta; p.ln.eps = eps; p.ln.part = (float2*)part; p.ln.count = count; p.ln.abort_ = abort_flag;
-    p.ln.planes = planes;
+    p.ln.planes = planes; p.ln.starve = g_ln_fusion.load(std::memory_order_relaxed) == 2 ? 1 : 0;
     p.stamps = nullptr;
     g_ln_launches.fetch_add(1, std::memory_order_relaxed);
     return launch_cfg<1, 2, 4, 2, 6, 2>(EPI_BIAS_RES_LN, false, p, stream);
@@ -528,7 +531,7 @@ int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, 
  * the built-in table. */
 /* process-wide switch (A/B runs, tests): 0 = the encoder keeps its LayerNorms as separate launches; default 1, or AC_LN_FUSION=0 */
 extern "C" int ac_gemm_set_ln_fusion(int on) {
-    ac::g_ln_fusion.store(on ? 1 : 0, std::memory_order_relaxed);
+    ac::g_ln_fusion.store(on == 2 ? 2 : (on ? 1 : 0), std::memory_order_relaxed);
     return AC_OK;
 }
 

@@ -224,7 +224,8 @@ int ac_gemm_set_pipe_table(const char* spec);
 /* The BERT encoder folds `x = LayerNorm(x + A W^T + b)` (BertSelfOutput / BertOutput, transformers modeling_bert.py) into
  * the epilogue of the attention-output and FFN2 GEMMs when the launch is one round of 128 x 128 tiles, one per CU: the
  * tiles of a 128-row panel exchange per-row (mean, M2) partials and each normalises its own block (gemm_pipe.hip).
- * 0 keeps the LayerNorms as separate launches (A/B, tests); default 1; env AC_LN_FUSION=0 sets the initial value. */
+ * 0 keeps the LayerNorms as separate launches (A/B, tests); default 1; env AC_LN_FUSION=0 sets the initial value.
+ * 2 = on, with a starved exchange: every tile waits for an arrival that never comes (tests of the give-up path only). */
 int ac_gemm_set_ln_fusion(int on);
 int64_t ac_gemm_ln_fusion_launches(void);      /* fused launches of this process so far (tests: "did the fused path run") */
 

@@ -296,3 +296,32 @@ def test_layernorm_fused_into_the_gemm_epilogue(hidden, layers, heads, inter, b,
     assert (fused - separate).abs().max().item() < 5e-6, (fused - separate).abs().max().item()
     for got in (fused, separate):
         assert (got - want).abs().max().item() < 1e-4
+
+
+def test_starved_layernorm_exchange_gives_up_loudly(cuda_dev):
+    """The give-up path of the fused-LayerNorm epilogue for real: with the exchange starved (every tile waits for one arrival
+    more than will come) the launches must END within their bounded wait, the rows must come out NaN, the verdict must say
+    so -- and the next call with the fusion off must be right again."""
+    import time
+    from adaptive_classifier import _native as nv
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_bert(128, 3, 2, 512, vocab=2000, seed=5)
+    ids, types, mask = bert_oracle.synthetic_batch(24, 16, vocab=2000, seed=7, ragged=False)
+    want = bert_oracle.encode_cls(model, ids, types, mask)
+    enc = HipBertEncoder(model, device=cuda_dev)
+    lib = nv.lib()
+    try:
+        nv.check(lib.ac_gemm_set_ln_fusion(2), "ac_gemm_set_ln_fusion")
+        t0 = time.time()
+        bad = enc.encode_cls(ids, types, mask).cpu()
+        assert time.time() - t0 < 30.0
+        assert torch.isnan(bad).all()
+        assert enc.ln_fusion_aborted()
+        nv.check(lib.ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
+        good = enc.encode_cls(ids, types, mask).cpu()
+        assert not enc.ln_fusion_aborted()
+        assert (good - want).abs().max().item() < 1e-4
+    finally:
+        nv.check(lib.ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
+    assert (enc.encode_cls(ids, types, mask).cpu() - want).abs().max().item() < 1e-4
