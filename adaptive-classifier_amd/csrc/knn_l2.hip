@@ -1256,6 +1256,7 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     bp->off_fb_ctr = take(256);
     bp->off_sub = take(sub);
     bp->total = off;
+    // (the static LDS of the merge kernel -- segment offsets, scan totals -- is ~1.1 KB)
     bp->merge_lds = 2 * ac::align_up((size_t)cap * 4, 16) + ac::align_up((size_t)bp->Dp * 4, 16) + (size_t)bp->kp * 16 + 256 * 4 + 64;   // (segmented form; one segment needs cap * 4 less)
     bp->fb_lds = (size_t)kFbCap * 12 + ac::align_up((size_t)bp->Dp, 4) * 4 + 64;
     return AC_OK;
@@ -1330,7 +1331,7 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     sp.outD = (float*)(ws + bp.off_sD32); sp.outD64 = (double*)(ws + bp.off_sD64); sp.outI = (int64_t*)(ws + bp.off_sI);
     sp.flags = (int32_t*)(ws + bp.off_flags); sp.stats = nullptr;
     sp.fb_S = bp.fb_S; sp.fb_F = 0; sp.fb_d = nullptr; sp.fb_i = nullptr; sp.fb_slotctr = (int32_t*)(ws + bp.off_fb_ctr) + 8;
-    (void)hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.merge_lds);
+    AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.merge_lds));
     static const bool dbg = getenv("AC_KNN_BATCH_DEBUG") != nullptr;
     const int64_t stage_stride[2] = {bp.stride_a, bp.stride};
     const int nstages = bp.stride_a > bp.stride ? 2 : 1;
@@ -1384,7 +1385,7 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     mp.fb_S = bp.fb_S; mp.fb_F = bp.fb_F;
     mp.fb_d = (double*)(ws + bp.off_fb_d); mp.fb_i = (int32_t*)(ws + bp.off_fb_i); mp.fb_slotctr = (int32_t*)(ws + bp.off_fb_ctr);
     AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_fb_ctr, 0, 256, stream));
-    (void)hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.merge_lds);
+    AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.merge_lds));
     hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), mlds, stream, mp);
     AC_LAUNCH_CHECK();
     (void)hipFuncSetAttribute((const void*)knn_exact_fallback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.fb_lds);
