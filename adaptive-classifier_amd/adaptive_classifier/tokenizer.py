@@ -117,16 +117,28 @@ class HipWordPieceTokenizer:
         b = len(texts)
         M = int(max_length)
         dev = self.device
-        raws = [t.encode("utf-8") for t in texts]
-        on_dev = [self._device_ok(t, r) for t, r in zip(texts, raws)]
+        # common case first: one pass over the joined batch decides that every text is plain ASCII, short enough and free
+        # of special-token strings (a match across a text boundary only costs the slow path)
+        joined = "".join(texts)
+        if joined.isascii() and not any(sp in joined for sp in self.specials) and max(map(len, texts), default=0) <= MAX_DEVICE_BYTES:
+            on_dev = [True] * b
+            sizes = [len(t) for t in texts]
+            blob = joined.encode("ascii")
+        else:
+            raws = [t.encode("utf-8") for t in texts]
+            on_dev = [self._device_ok(t, r) for t, r in zip(texts, raws)]
+            sizes = [len(r) if ok else 0 for r, ok in zip(raws, on_dev)]
+            blob = b"".join(r for r, ok in zip(raws, on_dev) if ok)
         ids = torch.empty((b, M), dtype=torch.int64, device=dev)
         mask = torch.empty((b, M), dtype=torch.int64, device=dev)
         lens = torch.empty(b, dtype=torch.int32, device=dev)
-        offs = np.zeros(b + 1, np.int32)
-        offs[1:] = np.cumsum([len(r) if ok else 0 for r, ok in zip(raws, on_dev)])
-        blob = b"".join(r for r, ok in zip(raws, on_dev) if ok) + b"\0" * 64
-        d_text = torch.from_numpy(np.frombuffer(blob, np.uint8).copy()).to(dev)
-        d_offs = torch.from_numpy(offs).to(dev)
+        # offsets and text travel in ONE host-to-device copy: [int32 offs[b + 1] | pad to 16 | text bytes | 64 zero bytes]
+        head = (4 * (b + 1) + 15) // 16 * 16
+        buf = np.zeros(head + len(blob) + 64, np.uint8)
+        buf[:4 * (b + 1)].view(np.int32)[1:] = np.cumsum(sizes, dtype=np.int64).astype(np.int32)
+        buf[head:head + len(blob)] = np.frombuffer(blob, np.uint8)
+        d_buf = torch.from_numpy(buf).to(dev)
+        d_offs, d_text = d_buf[:4 * (b + 1)], d_buf[head:]
         with torch.cuda.device(dev):
             nv.check(nv.lib().ac_wordpiece_encode(nv.ptr(d_text), nv.ptr(d_offs), b, ctypes.byref(self.vocab), M, nv.ptr(ids),
                                                   nv.ptr(mask), nv.ptr(lens), nv.stream_ptr(dev)), "ac_wordpiece_encode")
