@@ -380,6 +380,242 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
 }
 
 // --------------------------------------------------------------------------------------
+// knn_sweep_ring: the sweep for <= 16 resident queries (the HBM-bound regime the roofline target is stated for), with the
+// store rows staged through wave-private LDS rings by whole-line NON-TEMPORAL LDS-DMA and the query tile held in REGISTERS.
+//   Why (profiles/r03/hbm_read_ceiling.txt, tools/sweep_ring_bench.hip): plain 16-byte loads stream at <= 6.1 TB/s on an
+//   MI355X whatever the occupancy -- knn_sweep<1> sits at that ceiling (6.13 - 6.19) -- while non-temporal accesses reach
+//   6.8 - 7.0.  knn_sweep's operand layout (4 lanes per row: 64 bytes of 16 rows per instruction, the other half of every line
+//   with the NEXT instruction out of the L1) cannot use them: a non-temporal load does not stay in the L1 (6.13 -> 5.21 TB/s).
+//   Here one DMA instruction moves 8 rows x 128 bytes = eight whole lines (8 consecutive lanes per line) into LDS; the
+//   fragments are read back in the MFMA layout.  LDS slot of (row a of the 8, 16-byte piece p) = 8 a + (p ^ a): the four
+//   k-slices of a row group spread over the banks.  With the rows in LDS the query tile no longer fits there (48 KB at
+//   D = 768) -- its B fragments live in registers for the first 512 dimensions (128 VGPRs; all 192 made hipcc spill and reload
+//   inside the k-loop) and in 16 KB of LDS for the rest; hence D <= 768, D % 32 == 0 and <= 16 queries.
+//   Per output element the same MFMA sequence in the same k order as knn_sweep<1>; candidate lists, pruning, the row-norm
+//   maximum and the partial results are knn_sweep's, unchanged.
+// A chunk = 16 rows x 32 floats (2 DMA instructions); RINGC chunks per wave; each wave waits on its OWN DMA queue
+// (counted vmcnt), no barrier in the k-loop; the block meets once per 128-row tile in the list-maintenance barrier.
+constexpr int kRingMaxChunks = 24;            // D <= 768
+constexpr int kRingRegChunks = 16;            // chunks whose query fragments stay in registers (128 VGPRs); the rest sit in LDS
+constexpr int kRingQsBytes = (kRingMaxChunks - kRingRegChunks) * 2 * 64 * 16;
+
+template <int N> __device__ __forceinline__ void sweep_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int RINGC>
+__global__ __launch_bounds__(kThreads, 2) void knn_sweep_ring(SweepParams prm) {
+    typedef Shape S;
+    typedef S::acc_t acc_t;
+    constexpr int J = 1, TQ = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef const __attribute__((address_space(1))) void glb_void_t;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int v = xcd_remap(blockIdx.x, prm.G);       // (nqt == 1)
+    const int g = v;
+    if (blockIdx.x == 0 && tid < 64) {          // consumed by the kernels launched after this one
+        prm.clear_ctr[tid] = 0;
+        if (tid < 4 && prm.clear_stats) prm.clear_stats[tid] = tid == 1 ? 1 : 0;      // [1] = 1: the rows went through the LDS ring
+    }
+    // ---- LDS: rings [kWaves][RINGC][2 halves][64 lanes] x 16 B | lists | counters ----
+    uint4* ring = reinterpret_cast<uint4*>(smem) + (size_t)wave * RINGC * 128;
+    f32x4* Qs = reinterpret_cast<f32x4*>(smem + (size_t)kWaves * RINGC * 2048);      // B fragments of chunks >= kRingRegChunks: [kb][lane]
+    float* list_d = reinterpret_cast<float*>(smem + (size_t)kWaves * RINGC * 2048 + kRingQsBytes);
+    int32_t* list_i = reinterpret_cast<int32_t*>(list_d + (size_t)TQ * prm.cap);
+    int* cnt = reinterpret_cast<int*>(list_i + (size_t)TQ * prm.cap);
+    float* tau_s = reinterpret_cast<float*>(cnt + TQ);
+    float* wmax_s = tau_s + TQ;                       // [kWaves]
+    int* need_s = reinterpret_cast<int*>(wmax_s + kWaves);     // [2][8] per-tile verdicts of the waves
+    int bar_parity = 0;
+    for (int t = tid; t < TQ; t += kThreads) {
+        cnt[t] = 0;
+        tau_s[t] = (t < prm.nq) ? INFINITY : -INFINITY;
+    }
+    const int nch = prm.D >> 5;                       // chunks per row (D % 32 == 0)
+    const int j = lane & 15;            // query column this lane owns in C/D and feeds in B
+    const int ksub = lane / S::ROWS;    // k sub-slice this lane feeds in the A/B layout
+    const int arow = lane % S::ROWS;    // tile row this lane feeds in the A layout
+    // ---- the query tile as B fragments: -2 * Q[j][16 kb + 4 ksub ..] ----
+    f32x4 bq[2 * kRingRegChunks];
+    const bool q_vec = (prm.ldQ & 3) == 0 && (((uintptr_t)prm.Q) & 15) == 0;        // 16-byte aligned query rows
+#pragma unroll
+    for (int kb = 0; kb < 2 * kRingMaxChunks; ++kb) {
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (kb < 2 * nch && j < prm.nq) {
+            const float* src = prm.Q + (size_t)j * prm.ldQ + 16 * kb + 4 * ksub;
+            if (q_vec) val = -2.f * *reinterpret_cast<const f32x4*>(src);
+            else { val.x = -2.f * src[0]; val.y = -2.f * src[1]; val.z = -2.f * src[2]; val.w = -2.f * src[3]; }
+        }
+        if (kb < 2 * kRingRegChunks) bq[kb < 2 * kRingRegChunks ? kb : 0] = val;
+        else if (wave == 0) Qs[(kb - 2 * kRingRegChunks) * 64 + lane] = val;
+    }
+    __syncthreads();
+    float tau[J];
+    tau[0] = tau_s[j];
+    float wave_maxnorm = 0.f;
+
+    const int64_t my_tiles = (prm.ntiles > g) ? (prm.ntiles - 1 - g) / prm.G + 1 : 0;
+    const int64_t total = my_tiles * nch;             // chunks this wave streams
+
+    // ---- DMA stream of this wave: lane (a = lane / 8, piece = (lane % 8) ^ a) of instruction h copies 16 bytes of row 8 h + a
+    const int da = lane >> 3, dp = (lane & 7) ^ da;
+    int64_t is_tile = 0;                              // tile / chunk of the next DMA issue
+    int is_ch = 0, is_slot = 0;
+    const float* rp0;
+    const float* rp1;
+    auto tile_rows = [&](int64_t it) {
+        int64_t r0 = (it * prm.G + g) * (int64_t)(kWaves * S::ROWS) + wave * S::ROWS + da, r1 = r0 + 8;
+        if (r0 > prm.N - 1) r0 = prm.N - 1;
+        if (r1 > prm.N - 1) r1 = prm.N - 1;
+        rp0 = prm.P + (size_t)r0 * prm.ldP + 4 * dp;
+        rp1 = prm.P + (size_t)r1 * prm.ldP + 4 * dp;
+    };
+    tile_rows(0);
+    auto issue = [&]() {                              // always two DMA instructions (exact vmcnt accounting); past the end: the last chunk again
+        uint4* dst = ring + (size_t)is_slot * 128;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(rp0 + 32 * is_ch), (lds_void_t*)dst, 16, 0, 2);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(rp1 + 32 * is_ch), (lds_void_t*)(dst + 64), 16, 0, 2);
+        is_slot = is_slot + 1 == RINGC ? 0 : is_slot + 1;
+        if (is_ch + 1 < nch) ++is_ch;
+        else if (is_tile + 1 < my_tiles) { is_ch = 0; ++is_tile; tile_rows(is_tile); }
+    };
+
+    acc_t acc[J];
+    float nsq = 0.f;
+    int64_t cur_tile = 0;
+
+    auto epilogue = [&]() {
+        // fold |p|^2 in: A = this lane's partial sum of squares, B = 1
+        acc[0] = S::mfma(nsq, 1.0f, acc[0]);
+        // row norm for the error-bound certificate
+        float rn = nsq;                     // lanes i, i+16, i+32, i+48 hold the 4 k-slices of row i
+        rn += __shfl_xor(rn, 16);
+        rn += __shfl_xor(rn, 32);
+        wave_maxnorm = fmaxf(wave_maxnorm, rn);
+
+        const int64_t row_base = (cur_tile * prm.G + g) * (int64_t)(kWaves * S::ROWS) + wave * S::ROWS;
+        bool maybe = false;
+#pragma unroll
+        for (int r = 0; r < S::NACC; ++r) maybe |= (acc[0][r] < tau[0]);
+        unsigned done = 0;
+        bool pend = __any(maybe) != 0;
+        for (;;) {
+            bool lane_pend = false;
+            if (pend) {
+                const int q = j;
+#pragma unroll
+                for (int r = 0; r < S::NACC; ++r) {
+                    const int64_t row = row_base + S::acc_row(r, lane);
+                    const float d = acc[0][r];
+                    const unsigned bit = 1u << r;
+                    if (!(done & bit) && d < tau[0] && row < prm.N) {
+                        const int slot = atomicAdd(&cnt[q], 1);
+                        if (slot < prm.cap) {
+                            list_d[q * prm.cap + slot] = d;
+                            list_i[q * prm.cap + slot] = (int32_t)row;
+                            done |= bit;
+                        } else {
+                            lane_pend = true;
+                        }
+                    }
+                }
+            }
+            // one barrier per tile: decide (uniformly) whether lists must be pruned.  NOT __syncthreads_or: its fence waits
+            // vmcnt(0), i.e. drains this wave's DMA ring once per 128 rows.  Only LDS traffic has to be ordered here: every
+            // wave posts its verdict in a flag word of this tile's parity, waits for its LDS operations, meets the others at
+            // a raw s_barrier and reads the eight words (the other parity is rewritten only after the next barrier).
+            int over = 0;
+            if (tid < TQ) over = cnt[tid] > (prm.cap - prm.cap / 4);
+            const int w_need = __any((int)lane_pend | over) != 0;
+            volatile int* fl = need_s + 8 * (bar_parity & 1);
+            if (lane == 0) fl[wave] = w_need;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int need = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) need |= fl[w];
+            ++bar_parity;
+            if (!need) break;
+            for (int q = wave; q < TQ; q += kWaves) {
+                if (cnt[q] > prm.kp)
+                    prune_dispatch(list_d + q * prm.cap, list_i + q * prm.cap, &cnt[q], &tau_s[q],
+                                   prm.cap, prm.kp, lane);
+            }
+            __syncthreads();
+            tau[0] = tau_s[j];
+            pend = true;   // re-test un-pushed entries against the tightened tau
+        }
+        nsq = 0.f;
+    };
+
+    if (total > 0) {
+#pragma unroll
+        for (int i = 0; i < RINGC - 1; ++i) issue();
+        const int rh = arow >> 3, ra = arow & 7;
+        int slot = 0;
+        for (int64_t it = 0; it < my_tiles; ++it) {
+            acc[0] = acc_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < kRingMaxChunks; ++ch) {               // (unrolled: bq[] is indexed statically)
+                if (ch < nch) {                                         // wave-uniform
+                    sweep_wait_vm<(RINGC - 2) * 2>();                   // this chunk has landed (the wave's own DMA queue)
+                    __builtin_amdgcn_sched_barrier(0);
+                    const uint4* sl = ring + (size_t)slot * 128 + rh * 64 + 8 * ra;
+                    const f32x4 a0 = __builtin_bit_cast(f32x4, sl[ksub ^ ra]);
+                    const f32x4 a1 = __builtin_bit_cast(f32x4, sl[(4 + ksub) ^ ra]);
+                    slot = slot + 1 == RINGC ? 0 : slot + 1;
+                    issue();                                            // refills the slot the PREVIOUS chunk used (its reads are consumed)
+                    f32x4 b0, b1;
+                    if (ch < kRingRegChunks) { b0 = bq[ch < kRingRegChunks ? 2 * ch : 0]; b1 = bq[ch < kRingRegChunks ? 2 * ch + 1 : 0]; }
+                    else { b0 = Qs[(2 * (ch - kRingRegChunks)) * 64 + lane]; b1 = Qs[(2 * (ch - kRingRegChunks) + 1) * 64 + lane]; }
+                    acc[0] = S::mfma(a0.x, b0.x, acc[0]);
+                    nsq = fmaf(a0.x, a0.x, nsq); nsq = fmaf(a0.y, a0.y, nsq);
+                    acc[0] = S::mfma(a0.y, b0.y, acc[0]);
+                    nsq = fmaf(a0.z, a0.z, nsq); nsq = fmaf(a0.w, a0.w, nsq);
+                    acc[0] = S::mfma(a0.z, b0.z, acc[0]);
+                    acc[0] = S::mfma(a0.w, b0.w, acc[0]);
+                    acc[0] = S::mfma(a1.x, b1.x, acc[0]);
+                    nsq = fmaf(a1.x, a1.x, nsq); nsq = fmaf(a1.y, a1.y, nsq);
+                    acc[0] = S::mfma(a1.y, b1.y, acc[0]);
+                    nsq = fmaf(a1.z, a1.z, nsq); nsq = fmaf(a1.w, a1.w, nsq);
+                    acc[0] = S::mfma(a1.z, b1.z, acc[0]);
+                    acc[0] = S::mfma(a1.w, b1.w, acc[0]);
+                }
+            }
+            epilogue();
+            ++cur_tile;
+        }
+        sweep_wait_vm<0>();                                             // the over-issued tail chunks must land before LDS is released
+    }
+
+    // ---- final: sort + cut every list to kp, write the block's partial result ----
+    __syncthreads();
+    for (int q = wave; q < TQ; q += kWaves) {
+        prune_dispatch(list_d + q * prm.cap, list_i + q * prm.cap, &cnt[q], &tau_s[q], prm.cap,
+                       prm.kp, lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int n = cnt[q];
+        const size_t base = ((size_t)q * prm.G + g) * prm.kp;
+        for (int e = lane; e < prm.kp; e += 64) {
+            prm.part_d[base + e] = e < n ? list_d[q * prm.cap + e] : INFINITY;
+            prm.part_i[base + e] = e < n ? list_i[q * prm.cap + e] : -1;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) wave_maxnorm = fmaxf(wave_maxnorm, __shfl_xor(wave_maxnorm, o));
+    if (lane == 0) wmax_s[wave] = wave_maxnorm;
+    __syncthreads();
+    if (tid == 0) {
+        float m = 0.f;
+        for (int w = 0; w < kWaves; ++w) m = fmaxf(m, wmax_s[w]);
+        prm.part_maxnorm[v] = m;
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // merge + exact re-rank + certificate.  One block (256 threads) per query.
 // --------------------------------------------------------------------------------------
 const float* zeros_device() {                 // (the symbol has one address per device)
@@ -951,6 +1187,7 @@ struct Plan {
     bool small;          // knn_small_exact instead of the fused sweep
     int small_pow2;
     int TQ, kp, cap, ng, Dp, G, nqt;
+    int ring;            // 0, or the chunks per wave of knn_sweep_ring (<= 16 queries, D % 32 == 0, D <= 768)
     int64_t ntiles;
     size_t sweep_lds, merge_lds, fb_lds;
     size_t off_part_d, off_part_i, off_maxnorm, off_flags, off_zeros, off_fb_d, off_fb_i, off_fb_ctr, total;
@@ -963,6 +1200,7 @@ static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
     AC_REQUIRE(N >= 0 && N < 2147483647LL, AC_EINVAL, "knn: N=%lld out of range", (long long)N);
     AC_REQUIRE(D >= 1 && nq >= 0 && k >= 1, AC_EINVAL, "knn: bad D=%d nq=%d k=%d", D, nq, k);
     pl->small = false;
+    pl->ring = 0;
     pl->Dp = (D + 3) / 4 * 4;
     {   // does the fused sweep cover (D, k)?  LDS: one 16-query tile + its candidate lists
         const int kp = k + kPad;
@@ -1006,10 +1244,20 @@ static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
     const ac::DevInfo& di = ac::dev_info();
     // blocks that are actually co-resident on a CU (VGPR/LDS limited); the grid is sized to exactly
     // one residency round so that no CU idles in a second, partial round
+    // <= 16 queries, D a multiple of 32 up to 768: the LDS-ring form (rows by non-temporal DMA, queries in registers)
+    static const int ring_env = getenv("AC_KNN_RING") ? atoi(getenv("AC_KNN_RING")) : -1;      // 0 = never (A/B)
+    if (TQ == 16 && pl->nqt == 1 && (D % 32) == 0 && D <= 32 * kRingMaxChunks && ring_env != 0) {
+        const size_t lists = kRingQsBytes + (size_t)TQ * pl->cap * 8 + TQ * 8 + kWaves * 4 + 64 + 64;
+        // (tools/sweep_ring_bench.hip: 4 chunks per wave stream as fast as 8; AC_KNN_RING=6 asks for the deeper ring)
+        pl->ring = (size_t)kWaves * 4 * 2048 + lists <= (size_t)kLdsLimit ? 4 : 0;
+        if (ring_env == 6 && (size_t)kWaves * 6 * 2048 + lists <= (size_t)kLdsLimit) pl->ring = 6;
+        if (pl->ring) pl->sweep_lds = (size_t)kWaves * pl->ring * 2048 + lists;
+    }
     int per_cu = 0;
-    hipError_t oe = (TQ == 32)
+    hipError_t oe = pl->ring ? hipSuccess : (TQ == 32)
         ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_sweep<2>, kThreads, pl->sweep_lds)
         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_sweep<1>, kThreads, pl->sweep_lds);
+    if (pl->ring) per_cu = 1;                        // (8 waves at the 256-register budget fill a CU)
     if (oe != hipSuccess) { (void)hipGetLastError(); per_cu = 1; }
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
@@ -1144,7 +1392,15 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
         sp.clear_stats = d_stats;
         const int nblk = pl.G * pl.nqt;
         if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
-        if (pl.TQ == 32) {
+        if (pl.ring) {
+            if (pl.ring == 6) {
+                AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_sweep_ring<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.sweep_lds));
+                hipLaunchKernelGGL(knn_sweep_ring<6>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
+            } else {
+                AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_sweep_ring<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.sweep_lds));
+                hipLaunchKernelGGL(knn_sweep_ring<4>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
+            }
+        } else if (pl.TQ == 32) {
             (void)hipFuncSetAttribute((const void*)knn_sweep<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)pl.sweep_lds);
             hipLaunchKernelGGL(knn_sweep<2>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);

@@ -239,7 +239,8 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
     torch.cuda.empty_cache()
     return {"bound": "hbm", "achieved": bytes_alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "knn_sweep<1> (16-query tile)", "rows": n_rows, "dim": DIM, "resident_queries": 16,
+            "kernel": "knn_sweep_ring (16 resident queries: rows through wave-private LDS rings by non-temporal DMA, query "
+                      "fragments in registers; knn_sweep<1> with AC_KNN_RING=0)", "rows": n_rows, "dim": DIM, "resident_queries": 16,
             "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": ms, "min_kernel_ms": ms_min,
             "whole_call_ms": call_ms, "exact_fallback_queries": nfb, "parity": par["v"], "by_resident_queries": table,
             "batch4096": batch}
@@ -692,7 +693,7 @@ def main():
         total_bytes = rows_rank * world * DIM * 4
         shard_roof = {"bound": "hbm", "achieved": total_bytes / slow / 1e6, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                       "frac": total_bytes / slow / 1e6 / (HBM_PEAK_GBS * world), "traffic": None,
-                      "kernel": "knn_sweep<1> (16-query tile), one shard per GPU", "rows": rows_rank * world,
+                      "kernel": "knn_sweep_ring (16 resident queries), one shard per GPU", "rows": rows_rank * world,
                       "rows_per_gpu": rows_rank, "dim": DIM, "resident_queries": 16,
                       "algorithmic_bytes_per_launch": rows_rank * DIM * 4, "avg_kernel_ms": slow,
                       "rank0_avg_kernel_ms": r["avg_kernel_ms"], "aggregation": "sum of shard bytes / max over ranks of the kernel time"}

@@ -30,7 +30,8 @@ def kernel_resources(src):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src,pattern", [("knn_batch.hip", "knn_batch_sweep"), ("gemm_pipe.hip", "gemm_pipe_nt")])
+@pytest.mark.parametrize("src,pattern", [("knn_batch.hip", "knn_batch_sweep"), ("gemm_pipe.hip", "gemm_pipe_nt"),
+                                         ("knn_l2.hip", "knn_sweep_ring")])
 def test_ring_staged_kernels_do_not_spill(src, pattern):
     res = {k: v for k, v in kernel_resources(src).items() if pattern in k}
     assert res, "no %s kernels found in the listing" % pattern

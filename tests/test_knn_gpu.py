@@ -224,3 +224,34 @@ def test_index_remove_ids_compacts_like_faiss(cuda_dev):
     d2, i2 = idx2.search(Q, 4)
     ref2 = faiss_shim.IndexFlatL2(D); ref2.add(X[:10]); ref2.remove_ids([2, 3])
     assert np.array_equal(i2, ref2.search(Q, 4)[1])
+
+
+@pytest.mark.parametrize("N,D,nq,k,ring", [
+    (200_000, 768, 16, 10, True),     # the roofline configuration's shape class: 16 resident queries
+    (70_001, 768, 1, 16, True),       # single query, ragged last tile (rows clamped)
+    (50_000, 384, 7, 32, True),       # 12 chunks per row: the register-resident fragments only
+    (30_000, 512, 16, 100, True),     # exactly the register-resident 16 chunks, long lists
+    (30_000, 544, 3, 5, True),        # one chunk of fragments in LDS
+    (20_000, 64, 12, 8, True),        # two chunks per row
+    (20_000, 768, 17, 8, False),      # 17 queries: two sub-tiles -> knn_sweep<2>
+    (20_000, 770, 4, 8, False),       # D % 32 != 0 -> knn_sweep<1>
+    (20_000, 1024, 4, 8, False),      # D > 768 -> knn_sweep<1>
+])
+def test_lds_ring_sweep_matches_oracle(N, D, nq, k, ring, cuda_dev):
+    """knn_sweep_ring (rows through wave-private LDS rings by non-temporal DMA, query fragments in registers / LDS) against
+    the oracle: identical ids, distances to 1 ulp -- and d_stats[1] says which form of the sweep ran."""
+    from adaptive_classifier import index as ix
+    from oracle import c_oracle, synth
+    P = synth.synth_unit_rows(N, D, seed=5)
+    Q = synth.synth_unit_rows(nq, D, seed=6)
+    ld = (D + 3) // 4 * 4
+    store = torch.zeros((N, ld), dtype=torch.float32, device=cuda_dev)
+    store[:, :D] = torch.from_numpy(P).to(cuda_dev)
+    stats = torch.zeros(4, dtype=torch.int32, device=cuda_dev)
+    Dd, Id = ix.knn_l2_topk(store, N, D, torch.from_numpy(Q).to(cuda_dev), k, stats=stats)
+    torch.cuda.synchronize()
+    oD, oI = c_oracle.knn_l2_topk(P, Q, k, 0)
+    assert np.array_equal(Id.cpu().numpy(), oI)
+    assert _ulp_close(Dd.cpu().numpy(), oD)
+    assert int(stats[1].item()) == (1 if ring else 0)
+    assert int(stats[0].item()) == 0
