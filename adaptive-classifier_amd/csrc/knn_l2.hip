@@ -390,19 +390,22 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep(SweepParams prm) {
 //   fragments are read back in the MFMA layout.  LDS slot of (row a of the 8, 16-byte piece p) = 8 a + (p ^ a): the four
 //   k-slices of a row group spread over the banks.  With the rows in LDS the query tile no longer fits there (48 KB at
 //   D = 768) -- its B fragments live in registers for the first 512 dimensions (128 VGPRs; all 192 made hipcc spill and reload
-//   inside the k-loop) and in 16 KB of LDS for the rest; hence D <= 768, D % 32 == 0 and <= 16 queries.
+//   inside the k-loop) and in 16 KB of LDS for the rest (16 KB at D <= 768, 32 KB at D <= 1024); hence D <= 1024, D % 32 == 0 and <= 16 queries.
 //   Per output element the same MFMA sequence in the same k order as knn_sweep<1>; candidate lists, pruning, the row-norm
 //   maximum and the partial results are knn_sweep's, unchanged.
 // A chunk = 16 rows x 32 floats (2 DMA instructions); RINGC chunks per wave; each wave waits on its OWN DMA queue
 // (counted vmcnt), no barrier in the k-loop; the block meets once per 128-row tile in the list-maintenance barrier.
-constexpr int kRingMaxChunks = 24;            // D <= 768
-constexpr int kRingRegChunks = 16;            // chunks whose query fragments stay in registers (128 VGPRs); the rest sit in LDS
-constexpr int kRingQsBytes = (kRingMaxChunks - kRingRegChunks) * 2 * 64 * 16;
+// MAXCH = chunks per row the instantiation is unrolled for: 24 (D <= 768) or 32 (D <= 1024); the query fragments of the first
+// ring_reg_chunks() chunks stay in registers (8 VGPRs per chunk), the rest sit in LDS (the longer unrolled loop of the 32-chunk
+// form left hipcc 12 bytes short with 16 chunks in registers)
+constexpr int ring_reg_chunks(int maxch) { return maxch <= 24 ? 16 : 14; }
+constexpr int ring_qs_bytes(int maxch) { return (maxch - ring_reg_chunks(maxch)) * 2 * 64 * 16; }
 
 template <int N> __device__ __forceinline__ void sweep_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int RINGC>
+template <int RINGC, int MAXCH>
 __global__ __launch_bounds__(kThreads, 2) void knn_sweep_ring(SweepParams prm) {
+    constexpr int kRingMaxChunks = MAXCH, kRingRegChunks = ring_reg_chunks(MAXCH), kRingQsBytes = ring_qs_bytes(MAXCH);
     typedef Shape S;
     typedef S::acc_t acc_t;
     constexpr int J = 1, TQ = 16;
@@ -1246,11 +1249,10 @@ static int make_plan(int64_t N, int D, int nq, int k, Plan* pl) {
     // one residency round so that no CU idles in a second, partial round
     // <= 16 queries, D a multiple of 32 up to 768: the LDS-ring form (rows by non-temporal DMA, queries in registers)
     static const int ring_env = getenv("AC_KNN_RING") ? atoi(getenv("AC_KNN_RING")) : -1;      // 0 = never (A/B)
-    if (TQ == 16 && pl->nqt == 1 && (D % 32) == 0 && D <= 32 * kRingMaxChunks && ring_env != 0) {
-        const size_t lists = kRingQsBytes + (size_t)TQ * pl->cap * 8 + TQ * 8 + kWaves * 4 + 64 + 64;
-        // (tools/sweep_ring_bench.hip: 4 chunks per wave stream as fast as 8; AC_KNN_RING=6 asks for the deeper ring)
+    if (TQ == 16 && pl->nqt == 1 && (D % 32) == 0 && D <= 1024 && ring_env != 0) {
+        const size_t lists = ring_qs_bytes(D <= 768 ? 24 : 32) + (size_t)TQ * pl->cap * 8 + TQ * 8 + kWaves * 4 + 64 + 64;
+        // (tools/sweep_ring_bench.hip: 4 chunks per wave stream as fast as 8)
         pl->ring = (size_t)kWaves * 4 * 2048 + lists <= (size_t)kLdsLimit ? 4 : 0;
-        if (ring_env == 6 && (size_t)kWaves * 6 * 2048 + lists <= (size_t)kLdsLimit) pl->ring = 6;
         if (pl->ring) pl->sweep_lds = (size_t)kWaves * pl->ring * 2048 + lists;
     }
     int per_cu = 0;
@@ -1393,12 +1395,12 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
         const int nblk = pl.G * pl.nqt;
         if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
         if (pl.ring) {
-            if (pl.ring == 6) {
-                AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_sweep_ring<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.sweep_lds));
-                hipLaunchKernelGGL(knn_sweep_ring<6>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
+            if (D <= 768) {
+                AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_sweep_ring<4, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.sweep_lds));
+                hipLaunchKernelGGL((knn_sweep_ring<4, 24>), dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
             } else {
-                AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_sweep_ring<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.sweep_lds));
-                hipLaunchKernelGGL(knn_sweep_ring<4>, dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
+                AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_sweep_ring<4, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.sweep_lds));
+                hipLaunchKernelGGL((knn_sweep_ring<4, 32>), dim3(nblk), dim3(kThreads), pl.sweep_lds, stream, sp);
             }
         } else if (pl.TQ == 32) {
             (void)hipFuncSetAttribute((const void*)knn_sweep<2>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -76,7 +76,7 @@ int ac_knn_l2_topk_workspace(int64_t N, int D, int nq, int k, size_t* bytes);
  *         with (FLT_MAX, -1) like faiss
  *   d_stats  optional int32[4] (may be NULL): {queries that took the exact
  *         fallback, 1 if the sweep streamed the rows through the LDS ring
- *         (knn_sweep_ring: nq <= 16, D % 32 == 0, D <= 768) else 0, 0, 0}
+ *         (knn_sweep_ring: nq <= 16, D % 32 == 0, D <= 1024) else 0, 0, 0}
  */
 int ac_knn_l2_topk(const float* d_P, int64_t N, int64_t ldP, int D,
                    const float* d_Q, int nq, int64_t ldQ, int k,

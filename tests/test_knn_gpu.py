@@ -235,7 +235,8 @@ def test_index_remove_ids_compacts_like_faiss(cuda_dev):
     (20_000, 64, 12, 8, True),        # two chunks per row
     (20_000, 768, 17, 8, False),      # 17 queries: two sub-tiles -> knn_sweep<2>
     (20_000, 770, 4, 8, False),       # D % 32 != 0 -> knn_sweep<1>
-    (20_000, 1024, 4, 8, False),      # D > 768 -> knn_sweep<1>
+    (20_000, 1024, 4, 8, True),       # e5-large width: 32 chunks per row, half of the fragments in LDS
+    (20_000, 1056, 4, 8, False),      # D > 1024 -> knn_sweep<1>
 ])
 def test_lds_ring_sweep_matches_oracle(N, D, nq, k, ring, cuda_dev):
     """knn_sweep_ring (rows through wave-private LDS rings by non-temporal DMA, query fragments in registers / LDS) against
