@@ -460,3 +460,41 @@ def test_representative_examples_equal_the_reference_written_file():
         assert all(np.array_equal(np.asarray(r["embedding"], np.float32), g.embedding.numpy()) for r, g in zip(ref[label], got))
     few = store["c0"][:4]
     assert select_representative_examples(few, k=5) is few               # <= k: returned as they are (:1543-1544)
+
+
+def test_unpack_of_the_packed_device_result():
+    """AdaptiveClassifier._unpack (packed n | class ids | fp64 scores -> the reference's list of (label, score) per query):
+    ragged result counts, k below / above the stored width, class ids mapped to labels, cached label array refreshed when
+    the label set changes."""
+    import numpy as np
+    from adaptive_classifier.classifier import AdaptiveClassifier
+
+    class Host:
+        id_to_label = {0: "a", 1: "b", 2: "c", 3: "d"}
+
+        def _raise_if_encoder_gave_up(self):
+            raise AssertionError("no NaN in this test")
+
+    h = Host()
+    b, kk, C = 37, 4, 4
+    rng = np.random.default_rng(0)
+    n = rng.integers(1, kk + 1, b).astype(np.int32)
+    cls = rng.integers(0, C, (b, kk)).astype(np.int32)
+    val = rng.random((b, kk))
+    off_cls = 4 * b
+    off_val = (off_cls + 4 * b * kk + 7) // 8 * 8
+    host = np.zeros(off_val + 8 * b * kk, np.uint8)
+    host[:off_cls] = n.view(np.uint8)
+    host[off_cls:off_cls + 4 * b * kk] = cls.view(np.uint8).ravel()
+    host[off_val:] = val.view(np.uint8).ravel()
+    layout = (b, kk, off_cls, off_val, C)
+    for k in (1, 3, 4, 9):
+        got = AdaptiveClassifier._unpack(h, host, layout, k)
+        want = [[("abcd"[cls[q, j]], float(val[q, j])) for j in range(min(int(n[q]), k, kk))] for q in range(b)]
+        assert got == want, k
+    n[:] = kk                                                    # the common case: every query has kk results (one slice per row)
+    host[:off_cls] = n.view(np.uint8)
+    got = AdaptiveClassifier._unpack(h, host, layout, 5)
+    assert got == [[("abcd"[cls[q, j]], float(val[q, j])) for j in range(kk)] for q in range(b)]
+    h.id_to_label = {0: "w", 1: "x", 2: "y", 3: "z"}             # relabelled: no stale names
+    assert AdaptiveClassifier._unpack(h, host, layout, 1)[0][0][0] == "wxyz"[cls[0, 0]]
