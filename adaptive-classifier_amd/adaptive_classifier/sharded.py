@@ -14,8 +14,13 @@
               `search()` (every rank wants the result of ALL queries) keeps step 3 as an all_gather.
 The messages are small (cfg2 at G = 8: 2.1 MB of queries in, 0.26 MB of candidates per peer), i.e. latency bound; there
 is no other collective on the data path.  One process per GPU, torch.distributed backend "nccl" (= RCCL).
+Query blocks may differ in size between ranks (an uneven last batch) and may be empty: the ranks first agree on the sizes
+(an 8-byte all_gather, skipped when the caller passes `block_sizes` or constructs with `equal_blocks=True`), queries travel
+padded to the largest block, candidates by an all_to_all with split sizes.  A `block_sizes` list that contradicts the
+rank's own block raises ValueError before any collective is entered.
 No multi-GPU scaling curve has been measured by the builder (one GPU per gpurun box); the RCCL calls themselves are
-exercised on a world-size-1 nccl group (tests/test_sharded_gpu.py::test_rccl_branch_world1).
+exercised on a world-size-1 nccl group (tests/test_sharded_gpu.py::test_rccl_branch_world1), the orchestration at world
+2 / 4 / 8 over gloo on CPU (tests/test_sharded_gloo.py) and at world 2 over gloo with the real kernels on one GPU.
 
 The local search and the merge are injected so that the orchestration (offsets, gather layout,
 merge semantics) can be exercised with world_size-2 `gloo` groups on CPU in tests, where the
@@ -44,11 +49,14 @@ def _unpack(both):
 
 class ShardedSearch:
     def __init__(self, local_rows, n_local, dim, row_offset, group=None, local_search=None, merge=None,
-                 force_collectives=False):
-        """force_collectives: run the collectives even on a one-rank group (tests: executes the RCCL calls on one GPU)."""
+                 force_collectives=False, equal_blocks=False):
+        """force_collectives: run the collectives even on a one-rank group (tests: executes the RCCL calls on one GPU).
+        equal_blocks: the caller guarantees that every rank passes the same number of queries to every search_block /
+        gather_queries call (a fixed per-rank batch): the ranks then skip the exchange of their block sizes."""
         self.rows, self.n_local, self.dim, self.row_offset = local_rows, n_local, dim, row_offset
         self.group = group
         self.force_collectives = bool(force_collectives)
+        self.equal_blocks = bool(equal_blocks)
         self._prepared = None          # bf16 planes + norms of the local shard (batched searches), built on first use
         if local_search is None or merge is None:
             from . import index as ix
@@ -106,12 +114,46 @@ class ShardedSearch:
         dist.all_to_all_single(out, t, group=self.group)
         return out
 
-    def gather_queries(self, q_local):
-        """Data-parallel query blocks -> the full [b, D] block on every rank (equal block sizes)."""
+    def block_sizes(self, m):
+        """Every rank's query-block size [world] (one tiny all_gather + a host read).  Callers that know the sizes by
+        construction (e.g. `shard_bounds(batch, world, r)`) pass them to search_block / gather_queries and skip this."""
+        if not self._collective:
+            return [int(m)]
+        if self.equal_blocks:
+            return [int(m)] * self.world
+        if dist.get_backend(self.group) == "nccl":
+            t = torch.tensor([int(m)], dtype=torch.int64, device=self.rows.device if self.rows.is_cuda else "cuda")
+            out = torch.empty(self.world, dtype=torch.int64, device=t.device)
+            dist.all_gather_into_tensor(out, t, group=self.group)
+            return [int(x) for x in out.tolist()]
+        parts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        dist.all_gather(parts, torch.tensor([int(m)], dtype=torch.int64), group=self.group)
+        return [int(p.item()) for p in parts]
+
+    def _check_sizes(self, sizes, m):
+        sizes = [int(x) for x in sizes]
+        if len(sizes) != self.world or any(x < 0 for x in sizes):
+            raise ValueError(f"block_sizes must hold one non-negative size per rank ({self.world}), got {sizes}")
+        if sizes[self.rank] != int(m):
+            raise ValueError(f"block_sizes[{self.rank}] = {sizes[self.rank]} but this rank's query block has {int(m)} rows")
+        return sizes
+
+    def gather_queries(self, q_local, block_sizes=None):
+        """Data-parallel query blocks -> the full [sum(sizes), D] block on every rank, rank order.  Blocks may differ in
+        size (an uneven last batch): they travel padded to the largest one and are compacted on arrival."""
         if not self._collective:
             return q_local
-        g = self._all_gather(q_local)
-        return g.reshape(-1, q_local.shape[-1])
+        sizes = self._check_sizes(self.block_sizes(q_local.shape[0]) if block_sizes is None else block_sizes, q_local.shape[0])
+        br = max(sizes)
+        if br == 0:
+            return q_local
+        if q_local.shape[0] < br:
+            pad = torch.zeros((br - q_local.shape[0], q_local.shape[1]), dtype=q_local.dtype, device=q_local.device)
+            q_local = torch.cat([q_local, pad])
+        g = self._all_gather(q_local)                                  # [world, br, D]
+        if all(x == br for x in sizes):
+            return g.reshape(-1, q_local.shape[-1])
+        return torch.cat([g[r, :sizes[r]] for r in range(self.world)])
 
     def search(self, queries, k):
         """queries [b, D] (identical on all ranks) -> global (dist fp32 [b,k], ids [b,k]) on EVERY rank.
@@ -122,16 +164,37 @@ class ShardedSearch:
         both = self._all_gather(_pack(D_loc, I_loc))            # ONE message per peer: fp64 bits and ids side by side
         return self._merge(*_unpack(both))
 
-    def search_block(self, q_local, k):
-        """The data-parallel step: this rank's query block [b/G, D] (equal sizes on all ranks) -> the global
-        (dist fp32 [b/G, k], ids [b/G, k]) of THOSE queries.  all_gather(queries) -> local search of all b queries ->
-        all_to_all of the candidate lists -> this rank merges only its own block."""
+    def search_block(self, q_local, k, block_sizes=None):
+        """The data-parallel step: this rank's query block [m, D] -> the global (dist fp32 [m, k], ids [m, k]) of THOSE
+        queries.  all_gather(queries) -> local search of all of them -> all_to_all of the candidate lists -> this rank
+        merges only its own block.  block_sizes: every rank's m when the caller knows them (validated against this rank's
+        block; a wrong list raises here instead of hanging in the collective); None = the ranks exchange their sizes first
+        (one extra 8-byte all_gather).  Sizes may differ and may be 0."""
         if not self._collective:
             D_loc, I_loc = self._search(self.rows, self.n_local, self.dim, q_local, k, self.row_offset)
             return D_loc.to(torch.float32), I_loc
         G, m = self.world, q_local.shape[0]
-        q_all = self.gather_queries(q_local)
+        sizes = self._check_sizes(self.block_sizes(m) if block_sizes is None else block_sizes, m)
+        total = sum(sizes)
+        dev = q_local.device
+        if total == 0:
+            return torch.empty((0, k), dtype=torch.float32, device=dev), torch.empty((0, k), dtype=torch.int64, device=dev)
+        q_all = self.gather_queries(q_local, sizes)
         D_loc, I_loc = self._search(self.rows, self.n_local, self.dim, q_all, k, self.row_offset)
-        both = _pack(D_loc, I_loc)                                 # [b, 2k] int64: one message per peer
-        both = self._all_to_all(both.reshape(G, m, both.shape[1]))   # -> [shard, own query, 2k]
+        both = _pack(D_loc, I_loc)                                 # [total, 2k] int64: one message per peer
+        if all(x == m for x in sizes):
+            both = self._all_to_all(both.reshape(G, m, both.shape[1]))   # -> [shard, own query, 2k]
+        else:
+            both = self._all_to_all_v(both, sizes, m).reshape(G, m, both.shape[1])
+        if m == 0:
+            return torch.empty((0, k), dtype=torch.float32, device=dev), torch.empty((0, k), dtype=torch.int64, device=dev)
         return self._merge(*_unpack(both))
+
+    def _all_to_all_v(self, t, in_sizes, m):
+        """t [sum(in_sizes), w]: rows of block j go to rank j; returns [world * m, w] (every peer sends this rank's m rows)."""
+        t = t.contiguous()
+        staged = self._staged(t)
+        src = t.cpu() if staged else t
+        out = torch.empty((self.world * m, t.shape[1]), dtype=t.dtype, device=src.device)
+        dist.all_to_all_single(out, src, output_split_sizes=[m] * self.world, input_split_sizes=list(in_sizes), group=self.group)
+        return out.to(t.device) if staged else out

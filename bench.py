@@ -1,15 +1,20 @@
 """bench.py -- the headline benchmark of BASELINE.json on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 either under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment) or plain `python bench.py --gpus N`, which spawns its own N ranks (launch_ranks).
 
 metric   predict() queries/sec + kNN GB/s vs HBM roofline, 768-d
-step     one predict() pass over one batch: BERT-base encoder (random init, fp32) on 256 pre-tokenised
-         synthetic texts (S = 32) -> exact L2 top-16 over the 100k x 768 prototype store -> AdaptiveHead
+N = 1    step = one predict() pass over one batch: BERT-base encoder (random init, fp32) on 256 pre-tokenised
+         synthetic texts (<= 32 tokens, ragged) -> exact L2 top-16 over the 100k x 768 prototype store -> AdaptiveHead
          (768-768-384-4) -> the reference's predict_batch blend -> Python result lists.  This is
          BASELINE.json configs[1]; token ids and prototypes are resident in HBM before the timed region.
-N GPUs   one process per GPU: every rank encodes its own 256-text batch (data parallel), the prototype
-         rows are sharded by rows across ranks, the exchange is all-gather(queries) + all-gather(per-shard
-         top-k) over RCCL and a merge.  value = (N * 256 * K) / max-over-ranks time.
+N > 1    one process per GPU.  step = one 4096-query batch of BASELINE configs[2]: the 10M x 768 store row-sharded over the
+         ranks, k = 32, every rank owns 4096 / N queries: all-gather(queries) + local exact search + all-to-all(exact fp64
+         distance, id) over RCCL + merge of the rank's own block.  value = 4096 * K / max-over-ranks time
+         ("scaling": "strong"; rank 0 also measures the one-GPU form of the same job inside the run).  configs[1] data
+         parallel (every rank encodes its own 256 texts, 100k rows sharded) is carried as `configs1_weak`.
 roofline the kNN distance sweep in its HBM-bound regime (the north star's roofline target): knn_sweep
          over 10M x 768 fp32 rows (30.7 GB) with 16 resident queries, timed with HIP events recorded
          around that kernel on its own stream (ac_knn_set_profile_events).  algorithmic bytes = N*D*4.
@@ -71,17 +76,20 @@ def make_classifier(dev, rank, world):
     lo, hi = shard_bounds(NPROTO, world, rank)
     rows = ix.synth_unit_rows(hi - lo, DIM, 1, row_offset=lo, device=dev)          # this rank's row shard
     row_labels = torch.arange(NPROTO, dtype=torch.int32) % NCLASS                  # replicated row->class map
-    sharded = ShardedSearch(rows, hi - lo, DIM, lo) if world > 1 else None
+    sharded = ShardedSearch(rows, hi - lo, DIM, lo, equal_blocks=True) if world > 1 else None      # 256 texts on every rank
     clf.memory.load_rows(rows, row_labels, labels, sharded=sharded)
     return clf, hf
 
 
-def synthetic_tokens(dev, rank):
+def synthetic_tokens(dev, rank, full_length=False):
+    """SURVEY 8d configs[1]: token ids ~U[1000, vocab), lengths ~U[8, 32] (full_length: every text 32 tokens)."""
     g = torch.Generator().manual_seed(1234 + rank)
     ids = torch.randint(1000, VOCAB, (BATCH, SEQ), generator=g)
     ids[:, 0] = 101
     lens = torch.randint(8, SEQ + 1, (BATCH,), generator=g)
     lens[0] = SEQ
+    if full_length:
+        lens[:] = SEQ
     mask = (torch.arange(SEQ)[None, :] < lens[:, None]).to(torch.int64)
     ids = ids * mask
     return ids.to(dev), torch.zeros_like(ids).to(dev), mask.to(dev)
@@ -275,31 +283,92 @@ def cpu_baseline(hf, clf, rows_dev, sample=2048, chunk=64):
             "encode_s": t1 - t0, "knn_s": t2 - t1, "head_s": t3 - t2}
 
 
-def sharded_cfg2(dev, rank, world, total_rows, batch=4096, k=32, reps=3):
-    """BASELINE configs[2] on N GPUs through ShardedSearch (the production exchange): returns the rank-0 report."""
+def _max_over_ranks(x, dev):
+    t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _job_barrier():
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def sharded_cfg2(dev, rank, world, total_rows, steps, warmup, batch=4096, k=32, parity_queries=16):
+    """BASELINE configs[2] on N GPUs through ShardedSearch (the production exchange): the 10M x 768 store row-sharded over
+    the ranks, 4096 queries per step (4096 / N per rank, data parallel): all-gather(queries) -> local exact search of all
+    4096 against the shard -> all-to-all of (exact fp64 distance, id) -> every rank merges its own block.  EXACTLY `steps`
+    timed steps between barriers, max over ranks.  Rank 0 then repeats the same 4096-query batch against the WHOLE store on
+    its own GPU (the one-GPU form of the same workload) -- the strong-scaling reference and, on its first `parity_queries`
+    queries, the check that the sharded ids equal the unsharded ones."""
     from adaptive_classifier import index as ix
     from adaptive_classifier.sharded import ShardedSearch, shard_bounds
     lo, hi = shard_bounds(total_rows, world, rank)
     rows = ix.synth_unit_rows(hi - lo, DIM, 1, row_offset=lo, device=dev)
-    b = batch // world
-    q_local = ix.synth_unit_rows(b, DIM, 2, row_offset=rank * b, device=dev)
+    qlo, qhi = shard_bounds(batch, world, rank)
+    q_local = ix.synth_unit_rows(qhi - qlo, DIM, 2, row_offset=qlo, device=dev)
     ss = ShardedSearch(rows, hi - lo, DIM, lo)
-    for _ in range(1):
-        ss.search_block(q_local, k)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    sizes = [shard_bounds(batch, world, r)[1] - shard_bounds(batch, world, r)[0] for r in range(world)]   # known by construction
+    for _ in range(max(1, warmup)):
+        ss.search_block(q_local, k, sizes)
+    _job_barrier()
     t0 = time.perf_counter()
-    for _ in range(reps):
-        Dg, Ig = ss.search_block(q_local, k)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    del rows
+    for _ in range(steps):
+        Dg, Ig = ss.search_block(q_local, k, sizes)
+    _job_barrier()
+    dt = _max_over_ranks(time.perf_counter() - t0, dev)
+    # where the step goes on this rank: local search vs the rest (exchange + merge), HIP events on the current stream
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    q_all = ss.gather_queries(q_local, sizes)
+    e[0].record()
+    ss._search(rows, hi - lo, DIM, q_all, k, lo)
+    e[1].record(); torch.cuda.synchronize()
+    local_ms = _max_over_ranks(e[0].elapsed_time(e[1]), dev)
+    ids_rank0 = Ig[:parity_queries].clone() if rank == 0 else None
+    del rows, ss
     torch.cuda.empty_cache()
-    return {"workload": "BASELINE configs[2]: %d x %d row-sharded over %d GPUs, k=%d, batch %d (all-gather queries, local "
-                        "sweep, all-to-all of exact fp64 dist + ids, every rank merges its own query block)" % (total_rows, DIM, world, k, b * world),
-            "ms_per_batch": dt / reps * 1e3, "queries_per_s": b * world * reps / dt, "rows_per_gpu": hi - lo}
+    one = None
+    if rank == 0:
+        P = ix.synth_unit_rows(total_rows, DIM, 1, device=dev)
+        Q = ix.synth_unit_rows(batch, DIM, 2, device=dev)
+        prep = ix.prepare_store(P, total_rows, DIM)
+        ws = torch.empty(ix.knn_batch_workspace_bytes(total_rows, DIM, batch, k), dtype=torch.uint8, device=dev)
+        out = (torch.empty((batch, k), dtype=torch.float32, device=dev), torch.empty((batch, k), dtype=torch.int64, device=dev))
+        ix.knn_l2_topk(P, total_rows, DIM, Q, k, out=out, workspace=ws, prepared=prep)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(3):
+            ix.knn_l2_topk(P, total_rows, DIM, Q, k, out=out, workspace=ws, prepared=prep)
+        torch.cuda.synchronize(); d1 = (time.perf_counter() - t1) / 3
+        one = {"ms_per_batch": d1 * 1e3, "queries_per_s": batch / d1,
+               "sharded_ids_equal_unsharded": bool(torch.equal(out[1][:parity_queries], ids_rank0)),
+               "checked_queries": int(parity_queries),
+               "note": "the same 4096-query batch against the whole store on rank 0's GPU alone, measured in this job while the "
+                       "other ranks wait (on a shared-device gloo run the other ranks' memory is still resident)"}
+        del P, Q, prep, ws, out
+        torch.cuda.empty_cache()
+    dist.barrier()
+    return {"ms_per_step": dt / steps * 1e3, "queries_per_s": batch * steps / dt, "rows_per_gpu": hi - lo,
+            "queries_per_gpu": qhi - qlo, "local_search_ms_max_over_ranks": local_ms,
+            "exchange_and_merge_ms": max(0.0, dt / steps * 1e3 - local_ms), "one_gpu_same_workload": one,
+            "speedup_vs_one_gpu": None if one is None else one["ms_per_batch"] / (dt / steps * 1e3)}
+
+
+def shard_sweep_roofline(dev, rank, world, total_rows):
+    """N > 1 roofline entry: the 10M-row store row-sharded, every rank sweeps its own shard with 16 resident queries (no
+    collective in the sweep); achieved = total algorithmic bytes / the slowest rank's kernel time, peak = N x 8 TB/s."""
+    from adaptive_classifier.sharded import shard_bounds
+    lo, hi = shard_bounds(total_rows, world, rank)
+    r = sweep_roofline(dev, hi - lo, full=False)
+    slow = _max_over_ranks(r["avg_kernel_ms"], dev)
+    total_bytes = total_rows * DIM * 4
+    return {"bound": "hbm", "achieved": total_bytes / slow / 1e6, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+            "frac": total_bytes / slow / 1e6 / (HBM_PEAK_GBS * world), "traffic": None,
+            "kernel": r["kernel"] + "; one shard per GPU", "rows": total_rows, "rows_per_gpu": hi - lo, "dim": DIM,
+            "resident_queries": 16, "algorithmic_bytes_per_launch": (hi - lo) * DIM * 4, "avg_kernel_ms": slow,
+            "rank0_avg_kernel_ms": r["avg_kernel_ms"],
+            "aggregation": "sum of the shards' algorithmic bytes / max over ranks of the per-launch kernel time (HIP events on the kernel's stream)"}
 
 
 def measure_cfg4(dev, args, steps=None, warmup=None, parity_queries=16):
@@ -594,6 +663,127 @@ def measure_predict_from_text(dev, clf, reps=5):
     return out
 
 
+def timed_predict(clf, ids, types, mask, steps, warmup):
+    """`warmup` untimed steps, then EXACTLY `steps` predict() steps between barrier + synchronize on both sides;
+    returns the elapsed seconds, max over ranks."""
+    for _ in range(warmup):
+        preds = predict_step(clf, ids, types, mask)
+    _job_barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        preds = predict_step(clf, ids, types, mask)
+    _job_barrier()
+    dt = time.perf_counter() - t0
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dt = _max_over_ranks(dt, ids.device)
+    assert len(preds) == ids.shape[0] and all(len(p) >= 1 for p in preds)
+    return dt
+
+
+def encoder_roofline(clf, stages, enc_flops, enc_peak, arith):
+    ref_flops = clf.model.flops(BATCH, SEQ, executed=False)
+    return {"bound": "mfma", "achieved": enc_flops / stages["encode_ms"] / 1e9,
+            "peak": enc_peak, "unit": "TFLOP/s",
+            "frac": enc_flops / stages["encode_ms"] / 1e9 / enc_peak,
+            "flops_per_step": enc_flops,
+            "peak_note": ("fp32-equivalent: bf16 MFMA dense peak 2500 / 6 products" if arith == 1
+                          else "fp32-input MFMA dense peak"),
+            "tokens_per_step": int(getattr(clf.model, "last_tokens", BATCH * SEQ)),
+            "tokens_per_step_padded": BATCH * SEQ,
+            "note": "executed FLOPs: the padding tokens of the ragged batch (lengths ~U[8,32], SURVEY 8d) are left "
+                    "out of the forward (ac_bert_encode_cls_packed: identical CLS vectors), and the last layer runs "
+                    "its post-attention part on the CLS rows only; the padded BertModel.forward the reference runs "
+                    "would be %.4g" % ref_flops,
+            "reference_flops_rate": {"TFLOPs": ref_flops / stages["encode_ms"] / 1e9,
+                                     "of_peak": ref_flops / stages["encode_ms"] / 1e9 / enc_peak,
+                                     "note": "NOT a roofline fraction: the FLOPs the reference's padded forward spends on this "
+                                             "batch divided by the time this path takes for the same outputs"}}
+
+
+def main_multi(args, dev, rank, world):
+    """The N > 1 line.  `value` = BASELINE configs[2] -- the 10M x 768 store row-sharded over the N ranks, k = 32, 4096
+    queries per step, through the production exchange (strong scaling: the job is the same at every N; the one-GPU form of
+    the same job is measured by rank 0 inside this run, `config.one_gpu_same_workload`).  `roofline` = every rank's shard
+    sweep against N x 8 TB/s.  `configs1_weak` = the N = 1 headline workload (configs[1], predict() end to end) run data
+    parallel with the 100k-row store row-sharded, 256 texts per rank per step."""
+    cfg2 = sharded_cfg2(dev, rank, world, args.sweep_rows, args.steps, args.warmup)
+    roof = None if args.no_sweep else shard_sweep_roofline(dev, rank, world, args.sweep_rows)
+    clf, hf = make_classifier(dev, rank, world)
+    ids, types, mask = synthetic_tokens(dev, rank)
+    dt = timed_predict(clf, ids, types, mask, args.steps, args.warmup)
+    stages = time_stages(clf, ids, types, mask)
+    backend = dist.get_backend()
+    line = {
+        "metric": "predict() queries/sec + kNN GB/s vs HBM roofline, 768-d",
+        "value": cfg2["queries_per_s"], "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": cfg2["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: %d x %d synthetic prototypes row-sharded over %d GPUs, k=32, batch 4096 "
+                               "(%d queries per rank): all-gather(queries) -> local exact search (fp16-plane proposals + fp64 "
+                               "re-rank) -> all-to-all of (exact fp64 distance, id) -> every rank merges its own block"
+                               % (args.sweep_rows, DIM, world, cfg2["queries_per_gpu"]),
+                   "rows": args.sweep_rows, "dim": DIM, "k": 32, "batch": 4096, "rows_per_gpu": cfg2["rows_per_gpu"],
+                   "parallelism": f"rowshard{world}+dp{world}", "backend": backend,
+                   "collectives": "all_gather_into_tensor(queries) + all_to_all_single(candidates) per step",
+                   "local_search_ms_max_over_ranks": cfg2["local_search_ms_max_over_ranks"],
+                   "exchange_and_merge_ms": cfg2["exchange_and_merge_ms"],
+                   "one_gpu_same_workload": cfg2["one_gpu_same_workload"],
+                   "speedup_vs_one_gpu": cfg2["speedup_vs_one_gpu"],
+                   "note": ("N = 1 of this file reports configs[1] (predict() end to end); the N > 1 line leads with the sharded "
+                            "kNN of configs[2] because at configs[1] the kNN is 4 % of a step -- its data-parallel weak scaling is "
+                            "carried as configs1_weak")},
+        "roofline": roof,
+        "configs1_weak": {"workload": "BASELINE configs[1] data parallel: 256 texts per rank per step, 100k x 768 store row-sharded "
+                                      "over the ranks, k=16 (all-gather queries, local search, all-to-all, merge), head, blend",
+                          "value": BATCH * world * args.steps / dt, "unit": "queries/s", "scaling": "weak",
+                          "ms_per_step": dt / args.steps * 1e3, "stages_ms": stages},
+    }
+    if backend != "nccl":
+        line["not_a_measurement"] = ("backend %s: ranks may share one GPU and device tensors are staged through the host -- this run "
+                                     "exercises the N-rank code path only" % backend)
+    return line
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (what `torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1` does, minus the elastic agent): rank r = LOCAL_RANK r -> cuda:r, rendezvous
+    on a free 127.0.0.1 port, rank 0's stdout (the ONE JSON line) is ours, the other ranks' output goes to stderr.
+    Returns the exit code (0 only if every rank exited 0); a failing rank takes the others down (exact PIDs)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("AC_BENCH_BACKEND", "nccl")
+    if ndev < n and backend == "nccl":
+        print(f"bench.py: --gpus {n} but {ndev} GPU(s) visible; RCCL needs one device per rank "
+              f"(AC_BENCH_BACKEND=gloo runs the N-rank code path on shared devices: a code-path exercise, not a measurement)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -615,8 +805,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks of itself (one per GPU)
+        raise SystemExit(launch_ranks(args.gpus))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or unset WORLD_SIZE and let bench.py spawn them)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
@@ -639,150 +832,97 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
+    if world > 1:
+        line = main_multi(args, dev, rank, world)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
     clf, hf = make_classifier(dev, rank, world)
     ids, types, mask = synthetic_tokens(dev, rank)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        preds = predict_step(clf, ids, types, mask)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        preds = predict_step(clf, ids, types, mask)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert len(preds) == BATCH and all(len(p) >= 1 for p in preds)
-
+    dt = timed_predict(clf, ids, types, mask, args.steps, args.warmup)
     stages = time_stages(clf, ids, types, mask)
 
     # the same loop with the fp32-input MFMA arithmetic for the large GEMMs (reported next to `value`)
     from adaptive_classifier import _native as nv
     arith = nv.lib().ac_gemm_get_arith()
     nv.check(nv.lib().ac_gemm_set_arith(0), "ac_gemm_set_arith")
-    for _ in range(2):
-        predict_step(clf, ids, types, mask)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        predict_step(clf, ids, types, mask)
-    barrier()
-    dt32 = time.perf_counter() - t0
+    dt32 = timed_predict(clf, ids, types, mask, args.steps, 2)
     nv.check(nv.lib().ac_gemm_set_arith(arith), "ac_gemm_set_arith")
-    if world > 1:
-        t = torch.tensor([dt32], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt32 = float(t.item())
-    # N > 1: the 10M x 768 store of BASELINE configs[2] row-sharded over the ranks; every rank sweeps its own shard
-    # (no collective in the sweep), the job's rate is total bytes / slowest rank's kernel time
-    shard_roof = None
-    if world > 1 and not args.no_sweep:
-        rows_rank = args.sweep_rows // world
-        r = sweep_roofline(dev, rows_rank, full=False)
-        tms = torch.tensor([r["avg_kernel_ms"]], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tms, op=dist.ReduceOp.MAX)
-        slow = float(tms.item())
-        total_bytes = rows_rank * world * DIM * 4
-        shard_roof = {"bound": "hbm", "achieved": total_bytes / slow / 1e6, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                      "frac": total_bytes / slow / 1e6 / (HBM_PEAK_GBS * world), "traffic": None,
-                      "kernel": "knn_sweep_ring (16 resident queries), one shard per GPU", "rows": rows_rank * world,
-                      "rows_per_gpu": rows_rank, "dim": DIM, "resident_queries": 16,
-                      "algorithmic_bytes_per_launch": rows_rank * DIM * 4, "avg_kernel_ms": slow,
-                      "rank0_avg_kernel_ms": r["avg_kernel_ms"], "aggregation": "sum of shard bytes / max over ranks of the kernel time"}
-    # N > 1: BASELINE configs[2] itself -- 10M x 768 row-sharded over the ranks, k = 32, 4096 queries per batch
-    # (4096 / N per rank, data parallel): all-gather(queries) -> local sweep -> all-to-all(exact dist, ids) -> merge of the rank's own block
-    cfg2 = None
-    if world > 1 and not args.no_sweep:
-        cfg2 = sharded_cfg2(dev, rank, world, args.sweep_rows)
+    # ... and with every text at the full 32 tokens (no padding to leave out): same timed loop, same arithmetic as `value`
+    ids_f, types_f, mask_f = synthetic_tokens(dev, rank, full_length=True)
+    dt_full = timed_predict(clf, ids_f, types_f, mask_f, args.steps, 2)
+    tokens_full = int(getattr(clf.model, "last_tokens", BATCH * SEQ))
+    predict_step(clf, ids, types, mask)          # (restores last_tokens of the headline batch for the accounting below)
+
     enc_peak = BF16_MFMA_PEAK_TF / 6.0 if arith == 1 else F32_MFMA_PEAK_TF
-    if rank == 0:
-        lens_h = mask.sum(1).double().cpu()
-        unpadded = getattr(clf.model, "last_tokens", BATCH * SEQ) < BATCH * SEQ
-        enc_flops = (clf.model.flops(BATCH, SEQ, tokens=float(lens_h.sum()), sum_len_sq=float((lens_h ** 2).sum()))
-                     if unpadded else clf.model.flops(BATCH, SEQ))
-        rows_local = clf.memory.index.ntotal
-        knn_flops = 2.0 * (BATCH * world) * rows_local * DIM
-        line = {
-            "metric": "predict() queries/sec + kNN GB/s vs HBM roofline, 768-d",
-            "value": BATCH * world * args.steps / dt, "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: bert-base-uncased arch (random init), 768-d, 100k prototypes "
-                                   "row-sharded over the ranks, k=16, batch=256 per GPU, S=32, 4 classes",
-                       "batch_per_gpu": BATCH, "seq_len": SEQ, "prototypes": NPROTO, "dim": DIM, "k": KNN_K,
-                       "classes": NCLASS, "parallelism": f"dp{world}+rowshard{world}",
-                       "gemm_arith": ("bf16x3 split: fp32 operands = h+m+l exactly, 6 bf16 MFMA products, fp32 "
-                                      "accumulate (fp32-grade; tests/test_gemm_split_gpu.py)" if arith == 1
-                                      else "fp32-input MFMA"),
-                       "value_f32_mfma": BATCH * world * args.steps / dt32,
-                       "ms_per_step_f32_mfma": dt32 / args.steps * 1e3},
-            "stages_ms": stages,
-            "roofline_encoder": {"bound": "mfma", "achieved": enc_flops / stages["encode_ms"] / 1e9,
-                                 "peak": enc_peak, "unit": "TFLOP/s",
-                                 "frac": enc_flops / stages["encode_ms"] / 1e9 / enc_peak,
-                                 "flops_per_step": enc_flops,
-                                 "peak_note": ("fp32-equivalent: bf16 MFMA dense peak 2500 / 6 products" if arith == 1
-                                               else "fp32-input MFMA dense peak"),
-                                 "tokens_per_step": int(getattr(clf.model, "last_tokens", BATCH * SEQ)),
-                                 "tokens_per_step_padded": BATCH * SEQ,
-                                 "note": "executed FLOPs: the padding tokens of the ragged batch (lengths ~U[8,32], SURVEY 8d) are left "
-                                         "out of the forward (ac_bert_encode_cls_packed: identical CLS vectors), and the last layer runs "
-                                         "its post-attention part on the CLS rows only; the padded BertModel.forward the reference runs "
-                                         "would be %.4g" % clf.model.flops(BATCH, SEQ, executed=False),
-                                 "reference_flops_rate": {"TFLOPs": clf.model.flops(BATCH, SEQ, executed=False) / stages["encode_ms"] / 1e9,
-                                                          "of_peak": clf.model.flops(BATCH, SEQ, executed=False) / stages["encode_ms"] / 1e9 / enc_peak,
-                                                          "note": "NOT a roofline fraction: the FLOPs the reference's padded forward spends on this "
-                                                                  "batch divided by the time this path takes for the same outputs"}},
-            "roofline_knn_batch": {"bound": "mfma", "achieved": knn_flops / stages["knn_ms"] / 1e9,
-                                   "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                   "frac": knn_flops / stages["knn_ms"] / 1e9 / BF16_MFMA_PEAK_TF,
-                                   "note": "the WHOLE kNN stage of the timed step (threshold stage, fp16 one-product sweep, merges / "
-                                           "exact re-rank) against the fp16 dense MFMA peak: at 256 queries x 100k rows the stage is "
-                                           "launch- and append-bound, not MFMA-bound (the sweep kernel alone reaches 0.38 of that peak "
-                                           "at 4096 x 10M: profiles/r03/knn_batch_sweep_pmc.json)"},
-        }
-        if world == 1 and not args.no_sweep:
-            free, _ = torch.cuda.mem_get_info(dev)
-            n_rows = args.sweep_rows
-            while n_rows * DIM * 4 > 0.8 * free and n_rows > 100_000:
-                n_rows //= 2
-            line["roofline"] = sweep_roofline(dev, n_rows, parity=not args.no_parity)
-        elif world > 1 and shard_roof is not None:
-            line["roofline"] = shard_roof
-            line["configs2_sharded"] = cfg2
-        if world == 1 and not args.no_parity:
-            line["parity"] = step_parity(clf, hf, ids, types, mask)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(hf, clf, clf.memory.index._store[:NPROTO])
-        if world == 1 and not args.no_extras:
-            # the other BASELINE configs, measured by the same run (outside the timed region of `value`), reduced so the whole
-            # command stays within ~90 s: `--config latency | cfg4 | add_examples` run them at full size on their own
-            torch.cuda.empty_cache()
-            line["predict_from_text"] = measure_predict_from_text(dev, clf)
-            lat = measure_latency(dev, args, reps=100, made=(clf, hf), with_cpu=not args.no_cpu_baseline, cpu_seconds=3.0)
-            line["latency_ms_b1"] = {k: lat[k] for k in ("value", "unit", "stages_ms", "cpu_baseline", "config", "reference_published")}
-            del clf
-            torch.cuda.empty_cache()
-            c4 = measure_cfg4(dev, args, steps=5, warmup=2, parity_queries=8)
-            line["cfg4"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "steps", "stages_ms", "roofline_encoder", "parity", "config")}
-            ae = measure_add_examples(dev, args, n=6000, modes=("as_wired",), with_cpu=False)
-            m = ae["modes"]["as_wired"]
-            line["add_examples"] = {"value": ae["value"], "unit": ae["unit"], "examples": m["examples"], "train_steps": m["train_steps"],
-                                    "steps_per_s": m["steps_per_s"], "host_seconds_by_phase": m["host_seconds_by_phase"],
-                                    "accuracy_5way": m["accuracy_5way"], "config": ae["config"]}
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    lens_h = mask.sum(1).double().cpu()
+    tokens = int(getattr(clf.model, "last_tokens", BATCH * SEQ))
+    unpadded = tokens < BATCH * SEQ
+    enc_flops = (clf.model.flops(BATCH, SEQ, tokens=float(lens_h.sum()), sum_len_sq=float((lens_h ** 2).sum()))
+                 if unpadded else clf.model.flops(BATCH, SEQ))
+    knn_flops = 2.0 * BATCH * clf.memory.index.ntotal * DIM
+    line = {
+        "metric": "predict() queries/sec + kNN GB/s vs HBM roofline, 768-d",
+        "value": BATCH * args.steps / dt, "unit": "queries/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: bert-base-uncased arch (random init), 768-d, 100k prototypes, k=16, "
+                               "batch=256, max 32 tokens per text (RAGGED: lengths ~U[8,32], SURVEY 8d; the forward is "
+                               "padding-free, so a step runs tokens_per_step token rows, not 256 x 32), 4 classes",
+                   "batch_per_gpu": BATCH, "seq_len": SEQ, "tokens_per_step": tokens, "tokens_per_step_padded": BATCH * SEQ,
+                   "length_distribution": {"kind": "uniform integer [8, 32], first text 32", "min": int(lens_h.min()),
+                                           "mean": float(lens_h.mean()), "max": int(lens_h.max())},
+                   "padding_free": bool(unpadded),
+                   "prototypes": NPROTO, "dim": DIM, "k": KNN_K, "classes": NCLASS, "parallelism": "dp1",
+                   "gemm_arith": ("bf16x3 split: fp32 operands = h+m+l exactly, 6 bf16 MFMA products, fp32 "
+                                  "accumulate (fp32-grade; tests/test_gemm_split_gpu.py)" if arith == 1
+                                  else "fp32-input MFMA"),
+                   "value_f32_mfma": BATCH * args.steps / dt32,
+                   "ms_per_step_f32_mfma": dt32 / args.steps * 1e3,
+                   "value_full_length": BATCH * args.steps / dt_full,
+                   "ms_per_step_full_length": dt_full / args.steps * 1e3,
+                   "tokens_per_step_full_length": tokens_full},
+        "stages_ms": stages,
+        "roofline_encoder": encoder_roofline(clf, stages, enc_flops, enc_peak, arith),
+        "roofline_knn_batch": {"bound": "mfma", "achieved": knn_flops / stages["knn_ms"] / 1e9,
+                               "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": knn_flops / stages["knn_ms"] / 1e9 / BF16_MFMA_PEAK_TF,
+                               "note": "the WHOLE kNN stage of the timed step (threshold stage, fp16 one-product sweep, merges / "
+                                       "exact re-rank) against the fp16 dense MFMA peak: at 256 queries x 100k rows the stage is "
+                                       "launch- and append-bound, not MFMA-bound (the sweep kernel alone reaches 0.38 of that peak "
+                                       "at 4096 x 10M: profiles/r03/knn_batch_sweep_pmc.json)"},
+    }
+    if not args.no_sweep:
+        free, _ = torch.cuda.mem_get_info(dev)
+        n_rows = args.sweep_rows
+        while n_rows * DIM * 4 > 0.8 * free and n_rows > 100_000:
+            n_rows //= 2
+        line["roofline"] = sweep_roofline(dev, n_rows, parity=not args.no_parity)
+    if not args.no_parity:
+        line["parity"] = step_parity(clf, hf, ids, types, mask)
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(hf, clf, clf.memory.index._store[:NPROTO])
+    if not args.no_extras:
+        # the other BASELINE configs, measured by the same run (outside the timed region of `value`), reduced so the whole
+        # command stays within ~90 s: `--config latency | cfg4 | add_examples` run them at full size on their own
+        torch.cuda.empty_cache()
+        line["predict_from_text"] = measure_predict_from_text(dev, clf)
+        lat = measure_latency(dev, args, reps=100, made=(clf, hf), with_cpu=not args.no_cpu_baseline, cpu_seconds=3.0)
+        line["latency_ms_b1"] = {k: lat[k] for k in ("value", "unit", "stages_ms", "cpu_baseline", "config", "reference_published")}
+        del clf
+        torch.cuda.empty_cache()
+        c4 = measure_cfg4(dev, args, steps=5, warmup=2, parity_queries=8)
+        line["cfg4"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "steps", "stages_ms", "roofline_encoder", "parity", "config")}
+        ae = measure_add_examples(dev, args, n=6000, modes=("as_wired",), with_cpu=False)
+        m = ae["modes"]["as_wired"]
+        line["add_examples"] = {"value": ae["value"], "unit": ae["unit"], "examples": m["examples"], "train_steps": m["train_steps"],
+                                "steps_per_s": m["steps_per_s"], "host_seconds_by_phase": m["host_seconds_by_phase"],
+                                "accuracy_5way": m["accuracy_5way"], "config": ae["config"]}
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """CPU suite: the multi-GPU orchestration (row shards, query all-gather, top-k all-gather + merge)
-with a world_size-2 gloo group.  The HIP kernels cannot run here, so the local search and the merge
+with world_size-2 / 4 / 8 gloo groups (uneven row shards, uneven and empty query blocks).  The HIP kernels cannot run here, so the local search and the merge
 are the ORACLE (injected) -- what is under test is the sharding / collective / offset logic of
 adaptive_classifier.sharded, which is identical under RCCL."""
 import os
@@ -16,7 +16,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, N, D, nq, k, ret):
+def _worker(rank, world, port, N, D, sizes, k, ret):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "adaptive-classifier_amd")]
@@ -25,8 +25,9 @@ def _worker(rank, world, port, N, D, nq, k, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_bounds(N, world, rank)
-    rows = torch.from_numpy(synth.synth_unit_rows(hi - lo, D, 1, row_offset=lo))   # shard generated in place
-    q_local = torch.from_numpy(synth.synth_unit_rows(nq // world, D, 2, row_offset=rank * (nq // world)))
+    rows = torch.from_numpy(synth.synth_unit_rows(hi - lo, D, 1, row_offset=lo)) if hi > lo else torch.zeros((0, D))
+    q0 = sum(sizes[:rank])
+    q_local = torch.from_numpy(synth.synth_unit_rows(sizes[rank], D, 2, row_offset=q0)) if sizes[rank] else torch.zeros((0, D))
 
     def local_search(P, n, Dd, Q, kk, off):
         d, i = knn_oracle.knn_l2_topk(P.numpy()[:n], Q.numpy(), kk, row_offset=off, return_exact=True)   # fp64 on the wire
@@ -37,30 +38,54 @@ def _worker(rank, world, port, N, D, nq, k, ret):
         return torch.from_numpy(d), torch.from_numpy(i)
 
     ss = ShardedSearch(rows, hi - lo, D, lo, local_search=local_search, merge=merge)
-    Q = ss.gather_queries(q_local)
+    Q = ss.gather_queries(q_local)                         # sizes agreed by the ranks themselves
     Dg, Ig = ss.search(Q, k)
     Db, Ib = ss.search_block(q_local, k)                   # all_to_all: this rank merges only its own query block
-    ret[rank] = (Q.numpy(), Dg.numpy(), Ig.numpy(), Db.numpy(), Ib.numpy())
+    Db2, Ib2 = ss.search_block(q_local, k, block_sizes=sizes)      # sizes known by construction: no size exchange
+    wrong = None
+    try:                                                   # a list that contradicts this rank's block: loud, before any collective
+        bad = list(sizes); bad[rank] += 1
+        ss.search_block(q_local, k, block_sizes=bad)
+    except ValueError as e:
+        wrong = str(e)
+    ret[rank] = (Q.numpy(), Dg.numpy(), Ig.numpy(), Db.numpy(), Ib.numpy(), Db2.numpy(), Ib2.numpy(), wrong)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,k", [(1001, 8), (37, 16)])
-def test_sharded_search_world2(N, k):
+def _run(world, N, k, sizes, D=64):
     from oracle import knn_oracle, synth
-    D, nq, world = 64, 6, 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), N, D, nq, k, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, D, sizes, k, ret), nprocs=world, join=True)
+    nq = sum(sizes)
     P = synth.synth_unit_rows(N, D, 1)
     Q = synth.synth_unit_rows(nq, D, 2)
     oD, oI = knn_oracle.knn_l2_topk(P, Q, k)
-    b = nq // world
     for r in range(world):
-        Qr, Dg, Ig, Db, Ib = ret[r]
-        assert np.array_equal(Qr, Q)                       # gathered query block is the global batch
+        Qr, Dg, Ig, Db, Ib, Db2, Ib2, wrong = ret[r]
+        lo = sum(sizes[:r])
+        assert np.array_equal(Qr, Q)                       # gathered query block is the global batch, rank order
         assert np.array_equal(Ig, oI) and np.array_equal(Dg, oD)
-        assert np.array_equal(Ib, oI[r * b:(r + 1) * b]) and np.array_equal(Db, oD[r * b:(r + 1) * b])
+        assert Ib.shape == (sizes[r], k)
+        assert np.array_equal(Ib, oI[lo:lo + sizes[r]]) and np.array_equal(Db, oD[lo:lo + sizes[r]])
+        assert np.array_equal(Ib2, Ib) and np.array_equal(Db2, Db)
+        assert wrong is not None and "block_sizes" in wrong
+
+
+@pytest.mark.parametrize("N,k", [(1001, 8), (37, 16)])
+def test_sharded_search_world2(N, k):
+    _run(2, N, k, [3, 3])
+
+
+@pytest.mark.parametrize("world,N,k,sizes", [
+    (4, 1003, 8, [2, 2, 2, 2]),                # equal query blocks, uneven row shards (251, 251, 251, 250)
+    (4, 1003, 8, [3, 1, 0, 2]),                # uneven last batch incl. an empty block
+    (8, 1003, 8, [2, 2, 2, 2, 2, 2, 2, 1]),    # world 8, ragged tail
+    (8, 70, 8, [1] * 8),                       # shards of 9 / 8 rows: k = 8 fills from every shard
+])
+def test_sharded_search_world_4_8_uneven(world, N, k, sizes):
+    _run(world, N, k, sizes)
 
 
 def test_shard_bounds_cover_rows():
