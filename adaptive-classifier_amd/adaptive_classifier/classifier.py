@@ -6,6 +6,7 @@ reference for the path in scope:
   add_examples :132-200 | predict :392-413 -> _predict_regular :415-480 | predict_batch :1308-1388 |
   _get_embeddings :1249-1282 | _initialize_adaptive_head :1238-1247 | _train_adaptive_head :1428-1522 |
   _train_new_classes :202-367 | get_memory_stats :1230 | get_example_statistics :1284 | clear_memory :1390 |
+  merge_classifiers :1402-1426 | _update_adaptive_head :1524-1531 |
   save / load (format of :524-628, :764-915: config.json, examples.json, model.safetensors).
 Out of scope here and rejected loudly: ONNX runtime/export (:59-81,1031-1104), strategic mode
 (:482-522,1594-1823), Hub upload / model card (:917-1183).
@@ -609,6 +610,38 @@ class AdaptiveClassifier:
                 self.memory.prototypes.pop(label, None)
                 self.memory.drop_label(label)
             self.memory._rebuild_index()
+
+    def merge_classifiers(self, other: "AdaptiveClassifier") -> "AdaptiveClassifier":
+        """classifier.py:1402-1426: fold another classifier's labels and stored examples into this one, then re-initialise
+        and retrain the head on everything stored.  Same order of effects as the reference: new labels get the next free
+        ids in `other.label_to_id` order, `other`'s examples go through the memory's add_example semantics class by class
+        (prune / prototype / rebuild counters; here one batched device pass per class, memory.add_examples_batch), the head
+        is rebuilt only if this classifier already had one.  As in the reference, training_history is not merged and the
+        index is whatever the lazy rebuild counter left (the next search brings it up to date)."""
+        if self.embedding_dim != other.embedding_dim:
+            raise ValueError("Classifiers have different embedding dimensions")
+        next_idx = max(self.id_to_label.keys()) + 1              # (raises on an empty classifier, like the reference)
+        for label in other.label_to_id:
+            if label not in self.label_to_id:
+                self.label_to_id[label] = next_idx
+                self.id_to_label[next_idx] = label
+                next_idx += 1
+        for label, examples in list(other.memory.examples.items()):
+            if examples:
+                self.memory.add_examples_batch(list(examples), [label] * len(examples))
+        if self.adaptive_head is not None:
+            self._initialize_adaptive_head()
+            self._train_adaptive_head()
+        return self
+
+    def _update_adaptive_head(self):
+        """classifier.py:1524-1531: make the head cover every known label (create it, or grow its output layer)."""
+        num_classes = len(self.label_to_id)
+        if self.adaptive_head is None:
+            self._initialize_adaptive_head()
+        elif num_classes > self.adaptive_head.model[-1].out_features:
+            self.adaptive_head.update_num_classes(num_classes)
+            self.adaptive_head = self.adaptive_head.to(self.device)
 
     def to(self, device: str) -> "AdaptiveClassifier":
         if str(device) != str(self.device):
