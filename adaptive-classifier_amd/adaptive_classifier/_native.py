@@ -163,6 +163,7 @@ _SIGNATURES = {
                                         ctypes.POINTER(c_int), c_void_p]),
     "ac_bert_one_launch_status": (c_int, [ctypes.POINTER(ac_bert_config), c_int, c_int, c_void_p, c_size_t,
                                           ctypes.POINTER(c_int), c_void_p]),
+    "ac_bert_ln_fusion_clear": (c_int, [c_void_p, c_size_t, c_void_p]),
     "ac_bert_ln_fusion_status": (c_int, [ctypes.POINTER(ac_bert_config), c_int, c_int, c_void_p, c_size_t,
                                          ctypes.POINTER(c_int), c_void_p]),
     "ac_bert_encode_cls": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p,

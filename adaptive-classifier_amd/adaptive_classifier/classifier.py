@@ -107,20 +107,47 @@ class AdaptiveClassifier:
         return self.tokenizer(texts, max_length=self.config.max_length, truncation=True, padding=True,
                               return_tensors="pt")
 
-    def _embed_device(self, texts: List[str], verify_small: bool = True, force_layered: bool = False) -> torch.Tensor:
-        """[b, D] unit-norm CLS embeddings on the device (classifier.py:1259-1275 without the D2H).
-        verify_small / force_layered: see HipBertEncoder.encode_cls -- by default a one-launch forward whose grid barrier
-        gave up (NaN rows) is detected and repeated here, for every caller."""
+    def _encoder_options(self):
+        """Which of encode_cls's keyword options the encoder object accepts (decided once per encoder object from its
+        signature, not by catching TypeError around the call: a user-supplied encoder may take none of them)."""
+        cached = getattr(self, "_enc_opts", None)
+        if cached is None or cached[0] is not self.model:
+            import inspect
+            try:
+                params = inspect.signature(self.model.encode_cls).parameters
+                anykw = any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+                opts = {name for name in ("verify", "force_layered") if anykw or name in params}
+            except (TypeError, ValueError):
+                opts = set()
+            cached = self._enc_opts = (self.model, opts)
+        return cached[1]
+
+    def _encode_tokens(self, input_ids, token_type_ids=None, attention_mask=None, verify: bool = True,
+                       force_layered: bool = False) -> torch.Tensor:
+        """[b, D] unit-norm CLS embeddings on the device from token tensors (classifier.py:1267-1275 without the D2H).
+        verify / force_layered: see HipBertEncoder.encode_cls -- by default a forward one of whose bounded waits gave up
+        (NaN rows) is detected and repeated inside the encoder, for every caller."""
+        opts = self._encoder_options()
+        kw = {}
+        if "verify" in opts:
+            kw["verify"] = verify
+        if "force_layered" in opts:
+            kw["force_layered"] = force_layered
+        return self.model.encode_cls(input_ids, token_type_ids, attention_mask, **kw)
+
+    def _embed_device(self, texts: List[str], verify: bool = True, force_layered: bool = False) -> torch.Tensor:
         inputs = self._tokenize(texts)
-        try:
-            return self.model.encode_cls(inputs["input_ids"], inputs.get("token_type_ids"), inputs.get("attention_mask"),
-                                         verify_small=verify_small, force_layered=force_layered)
-        except TypeError:            # an encoder object without the options (user-supplied)
-            return self.model.encode_cls(inputs["input_ids"], inputs.get("token_type_ids"), inputs.get("attention_mask"))
+        return self._encode_tokens(inputs["input_ids"], inputs.get("token_type_ids"), inputs.get("attention_mask"),
+                                   verify=verify, force_layered=force_layered)
 
     def _get_embeddings(self, texts: List[str]) -> List[torch.Tensor]:
-        """Reference signature: list of CPU [D] tensors (classifier.py:1282)."""
+        """Reference signature: list of CPU [D] tensors (classifier.py:1282).  The rows are checked on the host before
+        anyone can store them: the native encoders repeat a forward that gave up themselves (verify=True), so a NaN here
+        means non-finite weights or a user-supplied encoder's failure -- raised, never handed to the memory."""
         emb = self._embed_device(texts).cpu()
+        if not bool(torch.isfinite(emb).all()):
+            raise nv.NativeError("encoder returned non-finite embeddings (%d of %d rows); nothing was stored"
+                                 % (int((~torch.isfinite(emb).all(dim=1)).sum()), emb.shape[0]))
         return [e for e in emb]
 
     # ------------------------------------------------------------------------------ add_examples
@@ -129,14 +156,13 @@ class AdaptiveClassifier:
             raise ValueError("Empty input lists")
         if len(texts) != len(labels):
             raise ValueError("Mismatched text and label lists")
+        embeddings = self._get_embeddings(texts)    # (before the label maps are touched: an encoder failure leaves no trace)
         has_existing_classes = len(self.label_to_id) > 0
         new_classes = set(labels) - set(self.label_to_id.keys())
-        is_adding_new_classes = len(new_classes) > 0
         for label in sorted(new_classes):           # alphabetical ids (classifier.py:147-150)
             idx = len(self.label_to_id)
             self.label_to_id[label] = idx
             self.id_to_label[idx] = label
-        embeddings = self._get_embeddings(texts)
         self.add_embeddings(texts, embeddings, labels, _maps_done=True, _new_classes=new_classes,
                             _has_existing=has_existing_classes)
 
@@ -156,6 +182,18 @@ class AdaptiveClassifier:
                 self.label_to_id[label] = idx
                 self.id_to_label[idx] = label
         is_adding_new_classes = len(_new_classes) > 0
+        # one NaN row would poison its class's prototype and fp64 running sum for good (memory.py:149-150 averages everything
+        # stored): refuse before anything is mutated (label maps of a refused call are rolled back)
+        try:
+            bad = (~torch.isfinite(torch.stack([torch.as_tensor(e) for e in embeddings])).all(dim=1)).nonzero().flatten().tolist()
+        except (RuntimeError, TypeError, ValueError):      # ragged or missing embeddings: the memory's own validation reports those
+            bad = [i for i, e in enumerate(embeddings) if e is not None and not bool(torch.isfinite(torch.as_tensor(e)).all())]
+        if bad:
+            for label in _new_classes:                    # (the new labels took the highest ids: popping them restores the maps)
+                idx = self.label_to_id.pop(label, None)
+                if idx is not None:
+                    self.id_to_label.pop(idx, None)
+            raise ValueError("non-finite embedding for example(s) %s: nothing was added" % bad[:8])
         # memory update for the whole call: sequential add_example semantics, the per-class prune loop on the device
         self.memory.add_examples_batch([Example(t, l, e) for t, e, l in zip(texts, embeddings, labels)], list(labels))
         for label in labels:
@@ -431,13 +469,17 @@ class AdaptiveClassifier:
                                             nv.stream_ptr(out.device)), "ac_blend_topk")
         return out, (b, kk, off_cls, off_val, C)
 
-    def _unpack(self, host, layout, k: int):
-        """The packed result of _blend_device (already on the host, numpy uint8) -> list of (label, score) per query."""
+    _last_nan = False
+
+    def _unpack(self, host, layout, k: int, check: bool = True):
+        """The packed result of _blend_device (already on the host, numpy uint8) -> list of (label, score) per query.
+        NaN scores: noted in self._last_nan; check=True additionally asks the encoder whether it gave up and raises if so."""
         b, kk, off_cls, off_val, C = layout
         n = host[:off_cls].view(np.int32)
         cls = host[off_cls:off_cls + 4 * b * kk].view(np.int32)
         val = host[off_val:].view(np.float64)
-        if np.isnan(val).any():
+        self._last_nan = bool(np.isnan(val).any())
+        if self._last_nan and check:
             self._raise_if_encoder_gave_up()
         names = getattr(self, "_label_array", None)              # (kept for big label sets only: small ones are rebuilt per call)
         if C <= 64 or names is None or names[0] is not self.id_to_label or len(names[1]) != C:
@@ -450,21 +492,27 @@ class AdaptiveClassifier:
         n = n.tolist()
         return [pairs[q * kk:q * kk + min(n[q], kcap)] for q in range(b)]
 
-    def _finish(self, S, Cid, P, k: int, regular: bool, b: int = 0):
+    def _finish(self, S, Cid, P, k: int, regular: bool, b: int = 0, check: bool = True):
         """Blend + normalise + top-k of one device stage -> the reference's list of (label, score) per query.
         On the device (ac_blend_topk, one packed D2H) for up to 2048 classes; the numpy formula beyond."""
         C = len(self.id_to_label)
+        self._last_nan = False
         if S is None and P is None:
             return [[] for _ in range(b)]
         if C < 1 or C > self._BLEND_DEVICE_MAX_CLASSES:
-            return self._blend(None if S is None else S.cpu().numpy(), None if S is None else Cid.cpu().numpy(),
-                               None if P is None else P.cpu().numpy(), k, regular)
+            Sh, Ph = None if S is None else S.cpu().numpy(), None if P is None else P.cpu().numpy()
+            self._last_nan = bool((Sh is not None and np.isnan(Sh).any()) or (Ph is not None and np.isnan(Ph).any()))
+            if self._last_nan and check:
+                self._raise_if_encoder_gave_up()
+            return self._blend(Sh, None if S is None else Cid.cpu().numpy(), Ph, k, regular)
         out, layout = self._blend_device(S, Cid, P, k, regular)
-        return self._unpack(out.cpu().numpy(), layout, k)
+        return self._unpack(out.cpu().numpy(), layout, k, check)
 
     def _raise_if_encoder_gave_up(self):
-        """NaN scores: if the encoder's fused-LayerNorm GEMM epilogues timed out (a device that cannot hold one workgroup per
-        CU at once, e.g. under a CU mask; include/acamd.h ac_bert_ln_fusion_status) say so loudly and switch the fusion off."""
+        """NaN scores from embeddings this object did not compute itself (predict_embeddings): if the encoder's fused-LayerNorm
+        GEMM epilogues timed out (a device that cannot hold one workgroup per CU at once, e.g. under a CU mask; include/acamd.h
+        ac_bert_ln_fusion_status) say so loudly and switch the fusion off.  (predict / predict_batch / predict_tokens own their
+        encoder call and repeat it instead: _predict_with_retry.)"""
         gave_up = getattr(self.model, "ln_fusion_aborted", None)
         if gave_up is not None and gave_up():
             nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
@@ -476,25 +524,43 @@ class AdaptiveClassifier:
             raise ValueError("Empty input text")
         return self._predict_regular(text, k)
 
+    def _predict_with_retry(self, encode, finish):
+        """The predict paths' contract with the encoder's two bounded waits (HipBertEncoder.encode_cls): run the chain with
+        verify=False -- no host synchronisation between the encoder and the result copy, the GPU queue stays full -- and look
+        at the scores that come to the host anyway.  NaN scores are then traced to their cause and the chain is repeated
+        without the kernel that gave up; the caller never sees the NaNs and no exception is raised.
+        encode(verify, force_layered) -> embeddings; finish(emb) -> (result, has_nan)."""
+        res, nan = finish(encode(False, False))
+        if not nan:
+            return res
+        if getattr(self.model, "last_one_launch", False):
+            # NaN scores after the one-launch encoder: one of its grid barriers gave up (a device shared with another compute
+            # process poisons the embedding with NaNs rather than hanging).  Repeat through the layer-by-layer kernels.
+            logger.warning("single-query encoder returned NaN through the persistent kernel; repeating layer by layer")
+            res, nan = finish(encode(True, True))
+        else:
+            gave_up = getattr(self.model, "ln_fusion_aborted", None)
+            if gave_up is not None and gave_up():
+                logger.warning("encoder: a fused LayerNorm epilogue gave up (device shared or CU-masked?); LayerNorm fusion is "
+                               "now off for this process and the batch is encoded again")
+                nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
+                res, nan = finish(encode(True, False))
+        return res                      # (still NaN: non-finite inputs or weights -- the caller's data, returned as computed)
+
     def _predict_regular(self, text: str, k: int = 5) -> List[Tuple[str, float]]:
         """classifier.py:415-480: prototype scores over ALL classes, head probs over ALL classes,
         history-keyed weights (0.3/0.7 vs 0.7/0.3), stable sort, normalise, top-k.
         (Replaying this ~90-kernel single-query chain as one captured HIP graph was measured and dropped: 1.013 vs
         1.014 ms -- the chain is paced by the GPU's dependent-dispatch interval, not by host enqueue)"""
-        def run(force_layered=False):
-            # the result comes to the host anyway: skip the encoder's own verdict read-back (a stream sync in the middle of
-            # the chain) and look at the scores instead
-            emb = self._embed_device([text], verify_small=False, force_layered=force_layered)
+        def encode(verify, force_layered):
+            return self._embed_device([text], verify=verify, force_layered=force_layered)
+
+        def finish(emb):
             max_classes = len(self.id_to_label) if self.id_to_label else k
             S, I, P = self._device_stage(emb, max_classes)
-            return self._finish(S, I, P, k, regular=True, b=1)[0]
-        res = run()
-        if any(s != s for _, s in res) and getattr(self.model, "last_one_launch", False):
-            # NaN scores after the one-launch encoder: one of its grid barriers gave up (a device shared with another compute
-            # process poisons the embedding with NaNs rather than hanging).  Repeat through the layer-by-layer kernels.
-            logger.warning("single-query encoder returned NaN through the persistent kernel; repeating layer by layer")
-            res = run(force_layered=True)
-        return res
+            res = self._finish(S, I, P, k, regular=True, b=1, check=False)[0]
+            return res, any(s != s for _, s in res)
+        return self._predict_with_retry(encode, finish)
 
     def predict_batch(self, texts: List[str], k: int = 5, batch_size: int = 32) -> List[List[Tuple[str, float]]]:
         """classifier.py:1308-1388: top-k prototypes + top-k head classes, fixed 0.7/0.3 weights."""
@@ -502,9 +568,24 @@ class AdaptiveClassifier:
             raise ValueError("Empty input batch")
         out = []
         for i in range(0, len(texts), batch_size):
-            emb = self._embed_device(texts[i:i + batch_size])
-            out.extend(self.predict_embeddings(emb, k))
+            batch = texts[i:i + batch_size]
+            out.extend(self._predict_batch_core(lambda verify, force_layered: self._embed_device(
+                batch, verify=verify, force_layered=force_layered), k))
         return out
+
+    def predict_tokens(self, input_ids, token_type_ids=None, attention_mask=None, k: int = 5) -> List[List[Tuple[str, float]]]:
+        """One predict_batch() batch after the tokenizer (classifier.py:1267-1384): encoder -> device kNN + head -> blend
+        -> one packed D2H -> the reference's lists.  Public for pre-tokenised input (the benchmark's form).  An encoder
+        forward whose bounded wait gave up is repeated transparently (_predict_with_retry)."""
+        return self._predict_batch_core(lambda verify, force_layered: self._encode_tokens(
+            input_ids, token_type_ids, attention_mask, verify=verify, force_layered=force_layered), k)
+
+    def _predict_batch_core(self, encode, k):
+        def finish(emb):
+            S, I, P = self._device_stage(emb, k)
+            res = self._finish(S, I, P, k, regular=False, b=emb.shape[0], check=False)
+            return res, self._last_nan
+        return self._predict_with_retry(encode, finish)
 
     def predict_embeddings(self, emb: torch.Tensor, k: int = 5) -> List[List[Tuple[str, float]]]:
         """predict_batch() after the encoder: device kNN + head, then the blend of :1359-1384."""

@@ -41,7 +41,7 @@ class HipBertEncoder:
         self.unpad = bool(unpad)
         self.last_tokens = 0                  # token rows the last encode_cls call actually ran (roofline accounting)
         self.last_one_launch = False          # the last native call ran as the one persistent launch (bert_small.hip)
-        self._last_chunk = None               # (rows, S) of the last native call: where its workspace keeps the verdicts
+        self.ln_gave_up = 0                   # encode_cls calls repeated because a fused-LayerNorm exchange gave up
         cfg = hf_bert.config
         mtype = getattr(cfg, "model_type", "bert")
         if mtype not in ("bert", "distilbert"):
@@ -141,15 +141,21 @@ class HipBertEncoder:
         nv.check(nv.lib().ac_bert_workspace(ctypes.byref(self.ccfg), b, S, ctypes.byref(need)), "ac_bert_workspace")
         return need.value
 
-    def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None, verify_small=True,
-                   force_layered=False):
+    def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None, verify=True, force_layered=False,
+                   verify_small=None):
         """int64 [b, S] ids (+ optional type ids / mask) -> unit-norm CLS embeddings [b, H] on device.
 
-        <= 32 token rows run as ONE persistent launch (bert_small.hip), launched without the cooperative residency check;
-        on a device shared with another compute process one of its grid barriers can give up, and the rows are then NaN.
-        verify_small=True (default) reads that verdict after such a launch (a 4-byte D2H, i.e. a stream sync) and repeats
-        the call layer by layer -- every caller gets finite embeddings.  Latency-critical callers that look at their final
-        result anyway pass verify_small=False and, on NaN, call again with force_layered=True (classifier._predict_regular)."""
+        Two kernels of this forward wait for other workgroups with a BOUNDED wait and poison their rows with NaN when they
+        give up (a device shared with another compute process, or under a CU mask): the one persistent launch that runs
+        <= 32 token rows (bert_small.hip, launched without the cooperative residency check) and the fused-LayerNorm GEMM
+        epilogues of the layer-by-layer path (gemm_pipe.hip).  verify=True (default): their verdicts are read after the
+        call's last launch (one small D2H, i.e. ONE stream sync per call whatever the number of row chunks) and on a
+        give-up the call is repeated without the kernel that gave up (layer by layer / LayerNorm fusion switched off for
+        the process) -- every caller gets finite embeddings for finite weights.  Callers that look at their final result
+        anyway (the classifier's predict paths) pass verify=False, keep the GPU queue full, and on NaN ask
+        `ln_fusion_aborted()` / `last_one_launch` and call again.  verify_small: older name of `verify`."""
+        if verify_small is not None:
+            verify = verify_small
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         b, S = ids.shape
         if not self._has_types:
@@ -164,59 +170,84 @@ class HipBertEncoder:
         need = self.workspace_bytes(min(b, cb), S)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        self.last_tokens = 0
         with torch.cuda.device(self.device):
-            for r0 in range(0, b, cb):
-                r1 = min(b, r0 + cb)
-                nb = r1 - r0
-                self._last_chunk = (nb, S)
-                if self.unpad and mk is not None and S > 1 and nb * S > SMALL_TOKENS:
-                    # padding-free path: pack on the device, read back {rows, prefix flag, longest} (one 16-byte D2H)
-                    cu = torch.empty(nb + 1, dtype=torch.int32, device=self.device)
-                    src = torch.empty(nb * S, dtype=torch.int32, device=self.device)
-                    info = torch.empty(4, dtype=torch.int32, device=self.device)
-                    nv.check(nv.lib().ac_bert_pack(nv.ptr(mk[r0:r1]), nb, S, nv.ptr(cu), nv.ptr(src), nv.ptr(info),
-                                                   nv.stream_ptr(self.device)), "ac_bert_pack")
-                    total, not_prefix, longest, _ = info.tolist()
-                    if not not_prefix and total < nb * S:
-                        self.last_one_launch = False
-                        nv.check(nv.lib().ac_bert_encode_cls_packed(
-                            ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
-                            nv.ptr(None if tt is None else tt[r0:r1]), nb, S, nv.ptr(cu), nv.ptr(src), total, longest,
-                            nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(),
-                            nv.stream_ptr(self.device)), "ac_bert_encode_cls_packed")
-                        self.last_tokens += total
-                        continue
-                used = ctypes.c_int(0)
-
-                def call(opts):
-                    nv.check(nv.lib().ac_bert_encode_cls_opts(
-                        ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
-                        nv.ptr(None if tt is None else tt[r0:r1]), nv.ptr(None if mk is None else mk[r0:r1]), nb, S,
-                        nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(), opts, ctypes.byref(used),
-                        nv.stream_ptr(self.device)), "ac_bert_encode_cls_opts")
-                call(nv.AC_BERT_LAYERED if force_layered else 0)
-                self.last_one_launch = bool(used.value)
-                if used.value and verify_small:
-                    aborted = ctypes.c_int(0)
-                    nv.check(nv.lib().ac_bert_one_launch_status(ctypes.byref(self.ccfg), nb, S, nv.ptr(self._ws),
-                                                                self._ws.numel(), ctypes.byref(aborted),
-                                                                nv.stream_ptr(self.device)), "ac_bert_one_launch_status")
-                    if aborted.value:
-                        import logging
-                        logging.getLogger(__name__).warning(
-                            "one-launch encoder: a grid barrier gave up (device shared?); repeating layer by layer")
-                        call(nv.AC_BERT_LAYERED)
-                self.last_tokens += nb * S
+            # the fused-LayerNorm verdict of this call starts clean (sticky over the chunks below; include/acamd.h); a call
+            # that runs as the one persistent launch has no such epilogue (and is the latency path: no extra launch)
+            if b * S > SMALL_TOKENS or force_layered:
+                nv.check(nv.lib().ac_bert_ln_fusion_clear(nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
+                         "ac_bert_ln_fusion_clear")
+            layered = self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered)
+            if verify and layered and self.ln_fusion_aborted():
+                import logging
+                logging.getLogger(__name__).warning(
+                    "encoder: a fused LayerNorm epilogue gave up waiting for the tiles of a row panel (device shared or "
+                    "CU-masked?); LayerNorm fusion is now off for this process and the batch is encoded again")
+                self.ln_gave_up += 1
+                nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
+                nv.check(nv.lib().ac_bert_ln_fusion_clear(nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
+                         "ac_bert_ln_fusion_clear")
+                self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered)
         return out
 
+    def _run_chunks(self, ids, tt, mk, b, S, cb, out, verify, force_layered):
+        """The native calls of one encode_cls: row chunks of <= cb sequences.  Returns True when at least one chunk ran layer
+        by layer (the path whose GEMM epilogues may carry the fused LayerNorm)."""
+        self.last_tokens = 0
+        layered = False
+        for r0 in range(0, b, cb):
+            r1 = min(b, r0 + cb)
+            nb = r1 - r0
+            if self.unpad and mk is not None and S > 1 and nb * S > SMALL_TOKENS:
+                # padding-free path: pack on the device, read back {rows, prefix flag, longest} (one 16-byte D2H)
+                cu = torch.empty(nb + 1, dtype=torch.int32, device=self.device)
+                src = torch.empty(nb * S, dtype=torch.int32, device=self.device)
+                info = torch.empty(4, dtype=torch.int32, device=self.device)
+                nv.check(nv.lib().ac_bert_pack(nv.ptr(mk[r0:r1]), nb, S, nv.ptr(cu), nv.ptr(src), nv.ptr(info),
+                                               nv.stream_ptr(self.device)), "ac_bert_pack")
+                total, not_prefix, longest, _ = info.tolist()
+                if not not_prefix and total < nb * S:
+                    self.last_one_launch = False
+                    layered = True
+                    nv.check(nv.lib().ac_bert_encode_cls_packed(
+                        ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
+                        nv.ptr(None if tt is None else tt[r0:r1]), nb, S, nv.ptr(cu), nv.ptr(src), total, longest,
+                        nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(),
+                        nv.stream_ptr(self.device)), "ac_bert_encode_cls_packed")
+                    self.last_tokens += total
+                    continue
+            used = ctypes.c_int(0)
+
+            def call(opts):
+                nv.check(nv.lib().ac_bert_encode_cls_opts(
+                    ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
+                    nv.ptr(None if tt is None else tt[r0:r1]), nv.ptr(None if mk is None else mk[r0:r1]), nb, S,
+                    nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(), opts, ctypes.byref(used),
+                    nv.stream_ptr(self.device)), "ac_bert_encode_cls_opts")
+            call(nv.AC_BERT_LAYERED if force_layered else 0)
+            self.last_one_launch = bool(used.value)
+            if used.value and verify:
+                aborted = ctypes.c_int(0)
+                nv.check(nv.lib().ac_bert_one_launch_status(ctypes.byref(self.ccfg), nb, S, nv.ptr(self._ws),
+                                                            self._ws.numel(), ctypes.byref(aborted),
+                                                            nv.stream_ptr(self.device)), "ac_bert_one_launch_status")
+                if aborted.value:
+                    import logging
+                    logging.getLogger(__name__).warning(
+                        "one-launch encoder: a grid barrier gave up (device shared?); repeating layer by layer")
+                    call(nv.AC_BERT_LAYERED)
+                    self.last_one_launch = False
+            layered = layered or not self.last_one_launch
+            self.last_tokens += nb * S
+        return layered
+
     def ln_fusion_aborted(self) -> bool:
-        """Verdict of the fused-LayerNorm GEMM epilogues of the last encode_cls() chunk (a 4-byte D2H: stream sync)."""
-        if self._ws is None or self._last_chunk is None or self.last_one_launch:
-            return False                      # (the one-launch path has no such epilogue and does not touch the verdict word)
+        """Verdict of the fused-LayerNorm GEMM epilogues over ALL the chunks of the last encode_cls() call (sticky word at the
+        head of the workspace, cleared when a call starts; an 8-byte D2H: stream sync).  False after a call that ran as the
+        one persistent launch only (that path has no such epilogue)."""
+        if self._ws is None:
+            return False
         aborted = ctypes.c_int(0)
-        nb, S = self._last_chunk
-        nv.check(nv.lib().ac_bert_ln_fusion_status(ctypes.byref(self.ccfg), nb, S, nv.ptr(self._ws), self._ws.numel(),
+        nv.check(nv.lib().ac_bert_ln_fusion_status(ctypes.byref(self.ccfg), 1, 1, nv.ptr(self._ws), self._ws.numel(),
                                                    ctypes.byref(aborted), nv.stream_ptr(self.device)), "ac_bert_ln_fusion_status")
         return bool(aborted.value)
 
@@ -364,9 +395,11 @@ class HipModernBertEncoder:
                  "ac_modernbert_workspace")
         return need.value
 
-    def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None, verify_small=True, force_layered=False):
+    def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None, verify=True, force_layered=False,
+                   verify_small=None):
         """int64 [b, S] ids (+ optional mask; token types do not exist in ModernBERT) -> unit-norm CLS [b, H].
-        (verify_small / force_layered: interface parity with HipBertEncoder; this encoder has no one-launch path.)"""
+        (verify / force_layered: interface parity with HipBertEncoder; this encoder has neither a one-launch path nor
+        LayerNorm-fused GEMM epilogues, i.e. no kernel that can give up.)"""
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         b, S = ids.shape
         mk = None if attention_mask is None else attention_mask.to(device=self.device, dtype=torch.int64).contiguous()

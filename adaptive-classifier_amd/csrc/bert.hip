@@ -477,11 +477,21 @@ struct BertWs {
     size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
     size_t lnctl_bytes;
 };
-constexpr size_t kLnCtlHead = 256;     // the abort word of the fused-LayerNorm GEMM epilogues, then their row-panel counters
+// The verdict of the fused-LayerNorm GEMM epilogues sits at offset 0 of the workspace WHATEVER (b, S) the workspace is used
+// with: word 0 = "a panel of the CURRENT call gave up" (set by the kernels; later launches of the call stop waiting at their first
+// look at it), word 1 = the same for EARLIER calls since the last ac_bert_ln_fusion_clear.  Every call starts by rolling word 0
+// into word 1 (so a C caller that never clears still starts every call with a clean word 0, and the verdict of a multi-chunk
+// encode -- chunks of different row counts sharing one workspace -- survives the later chunks); ac_bert_ln_fusion_status
+// reports word 0 | word 1.
+constexpr size_t kLnAbortHead = 256;
+__global__ void ln_verdict_roll_kernel(unsigned* w) {
+    w[1] |= w[0];
+    w[0] = 0u;
+}
 BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     BertWs w;
     const size_t T = (size_t)b * S;
-    size_t off = 0;
+    size_t off = kLnAbortHead;
     auto take = [&](size_t n) { size_t o = off; off += ac::align_up(n * sizeof(float), 256); return o; };
     w.x = take(T * c.hidden);
     w.qkv = take(T * 3 * c.hidden);
@@ -495,9 +505,9 @@ BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     // the one-launch small-batch path (bert_small.hip) works on 32 padded rows of its own
     w.small = off;
     if (T <= 32) off += ac::bert_small_ws_bytes(c.hidden, c.intermediate);
-    // fused LayerNorm epilogues (gemm_pipe.hip): abort word + one counter per (layer, LayerNorm, 128-row panel), partials
+    // fused LayerNorm epilogues (gemm_pipe.hip): one counter per (layer, LayerNorm, 128-row panel), partials
     w.lnctl = off;
-    w.lnctl_bytes = kLnCtlHead + ac::align_up((size_t)c.layers * 2 * ac::pipe_ln_panels((int)T) * sizeof(unsigned), 256);
+    w.lnctl_bytes = ac::align_up((size_t)c.layers * 2 * ac::pipe_ln_panels((int)T) * sizeof(unsigned), 256);
     off += w.lnctl_bytes;
     w.lnpart = off;
     off += ac::align_up(ac::pipe_ln_part_bytes((int)T, c.hidden), 256);
@@ -557,10 +567,12 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
     const bool pl = wplanes && ac::linear_takes_planes(T, H, H) && ac::linear_takes_planes(T, H, I) && (H % 8) == 0;
     // bias + residual + LayerNorm in the epilogue of the attention-output and FFN2 GEMMs (one-round launches only)
     const bool fuse_ln = pl && c.layers > 1 && ac::pipe_ln_applies(T, H, H) && ac::pipe_ln_applies(T, H, I);
-    unsigned* ln_abort = (unsigned*)(base + ws.lnctl);
-    unsigned* ln_count = (unsigned*)(base + ws.lnctl + kLnCtlHead);
+    unsigned* ln_abort = (unsigned*)base;
+    hipLaunchKernelGGL(ln_verdict_roll_kernel, dim3(1), dim3(1), 0, stream, ln_abort);
+    AC_LAUNCH_CHECK();
+    unsigned* ln_count = (unsigned*)(base + ws.lnctl);
     const int ln_panels = ac::pipe_ln_panels(T);
-    AC_HIP_CHECK(hipMemsetAsync(base + ws.lnctl, 0, fuse_ln ? ws.lnctl_bytes : kLnCtlHead, stream));   // (the abort word always: ac_bert_ln_fusion_status)
+    if (fuse_ln) AC_HIP_CHECK(hipMemsetAsync(base + ws.lnctl, 0, ws.lnctl_bytes, stream));
 
     hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, T, S, H,
                        w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x,
@@ -685,13 +697,18 @@ extern "C" int ac_bert_ln_fusion_status(const ac_bert_config* cfg, int b, int S,
                                        int* aborted, ac_stream_t stream_) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
-    AC_REQUIRE(aborted && d_ws && b > 0 && S >= 1, AC_EINVAL, "bert_ln_fusion_status: bad arguments");
-    const BertWs ws = bert_ws(*cfg, b, S);
-    AC_REQUIRE(ws_bytes >= ws.total, AC_EWORKSPACE, "bert_ln_fusion_status: workspace %zu < %zu", ws_bytes, ws.total);
-    unsigned flag = 0;
-    AC_HIP_CHECK(hipMemcpyAsync(&flag, (const char*)d_ws + ws.lnctl, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    (void)b; (void)S;                                  // (kept in the signature: the word no longer depends on the chunk shape)
+    AC_REQUIRE(aborted && d_ws && ws_bytes >= kLnAbortHead, AC_EINVAL, "bert_ln_fusion_status: bad arguments");
+    unsigned flag[2] = {0, 0};
+    AC_HIP_CHECK(hipMemcpyAsync(flag, (const char*)d_ws, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     AC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
-    *aborted = flag != 0;
+    *aborted = (flag[0] | flag[1]) != 0;
+    return AC_OK;
+}
+
+extern "C" int ac_bert_ln_fusion_clear(void* d_ws, size_t ws_bytes, ac_stream_t stream_) {
+    AC_REQUIRE(d_ws && ws_bytes >= kLnAbortHead, AC_EINVAL, "bert_ln_fusion_clear: bad arguments");
+    AC_HIP_CHECK(hipMemsetAsync(d_ws, 0, 2 * sizeof(unsigned), (hipStream_t)stream_));
     return AC_OK;
 }
 

@@ -149,7 +149,8 @@ __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(ln.count + bm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // release: the workgroup's partial stores (made visible to thread 0 by the barrier) happen-before the arrival count
+    if (tid == 0) __hip_atomic_fetch_add(ln.count + bm, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     // 4. wait for the panel's other tiles (bounded: a bug or a CU mask must not hang the GPU -- the rows become NaN instead)
     if (tid < 64) {
         // (~1 us per poll: gives up after about a second; once one panel has given up -- the flag is per encoder call -- the
@@ -157,7 +158,10 @@ __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float
         unsigned ok = 1;
         for (long spins = 0;; ++spins) {
             const unsigned v = __hip_atomic_load(ln.count + bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v >= (unsigned)(ntn + ln.starve)) break;
+            if (v >= (unsigned)(ntn + ln.starve)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // acquire: pairs with the arrivals' release; the
+                break;                                                     // partial loads below cannot be served stale
+            }
             __builtin_amdgcn_s_sleep(1);
             if ((spins & 63) == 63 && (spins > (1l << 20) || __hip_atomic_load(ln.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 if (lane == 0) __hip_atomic_store(ln.abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -505,12 +505,9 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
     //  ~200 accumulator registers per iteration and a lone wave per SIMD hides nothing)
     constexpr int ns = 4, nwv = 8;
     const size_t lds = (size_t)ns * BSLOT * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // (per call, like the launch sites of knn_l2.hip: function attributes are per device, and a cached flag is neither)
+    AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     BatchParams p;
     p.Pp = Pp; p.p_rows = (N + 255) / 256 * 256; p.pnorm = pnorm;
     p.q_rows = ((int64_t)nq + 255) / 256 * 256;

@@ -96,8 +96,8 @@ def synthetic_tokens(dev, rank, full_length=False):
 
 
 def predict_step(clf, ids, types, mask):
-    emb = clf.model.encode_cls(ids, types, mask)
-    return clf.predict_embeddings(emb, k=KNN_K)
+    """predict_batch() after the tokenizer: encoder -> kNN -> head -> blend -> result lists (AdaptiveClassifier.predict_tokens)"""
+    return clf.predict_tokens(ids, types, mask, k=KNN_K)
 
 
 def time_stages(clf, ids, types, mask, reps=5):
@@ -109,7 +109,7 @@ def time_stages(clf, ids, types, mask, reps=5):
     tot = np.zeros(3)
     for _ in range(reps):
         e[0].record()
-        emb = clf.model.encode_cls(ids, types, mask)
+        emb = clf.model.encode_cls(ids, types, mask, verify=False)
         e[1].record()
         S, I, D = clf.memory.search_batch(emb, KNN_K)
         e[2].record()
@@ -399,7 +399,7 @@ def measure_cfg4(dev, args, steps=None, warmup=None, parity_queries=16):
     ids = (ids * mask).to(dev); mask = mask.to(dev); types = torch.zeros_like(ids)
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
-    step = lambda: clf.predict_embeddings(clf.model.encode_cls(ids, types, mask), k=K_)
+    step = lambda: clf.predict_tokens(ids, types, mask, k=K_)
     for _ in range(warmup):
         preds = step()
     torch.cuda.synchronize()
@@ -410,7 +410,7 @@ def measure_cfg4(dev, args, steps=None, warmup=None, parity_queries=16):
     dt = time.perf_counter() - t0
     assert len(preds) == B
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    ev[0].record(); emb = clf.model.encode_cls(ids, types, mask); ev[1].record()
+    ev[0].record(); emb = clf.model.encode_cls(ids, types, mask, verify=False); ev[1].record()
     S_, I_, D_ = clf.memory.search_batch(emb, K_); ev[2].record(); torch.cuda.synchronize()
     parity = None
     if not args.no_parity:
@@ -551,8 +551,8 @@ def measure_latency(dev, args, S=16, reps=200, made=None, with_cpu=None, cpu_sec
     ids_d = ids.to(dev)
     ncls = len(clf.id_to_label)
 
-    def one():
-        emb = clf.model.encode_cls(ids_d)
+    def one():                                       # the chain of AdaptiveClassifier._predict_regular (verify=False: no mid-chain sync)
+        emb = clf.model.encode_cls(ids_d, verify=False)
         S_, I_, P_ = clf._device_stage(emb, ncls)
         return clf._finish(S_, I_, P_, 3, True, b=1)
     for _ in range(10):
@@ -564,7 +564,7 @@ def measure_latency(dev, args, S=16, reps=200, made=None, with_cpu=None, cpu_sec
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        clf.model.encode_cls(ids_d)
+        clf.model.encode_cls(ids_d, verify=False)
     e1.record(); torch.cuda.synchronize()
     enc_ms = e0.elapsed_time(e1) / reps
     cpu = None
@@ -766,7 +766,15 @@ def launch_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=r == 0))
+
+    def pump():          # our stdout carries rank 0's JSON line and nothing else (gloo, for one, prints its connection banner on stdout)
+        for ln in procs[0].stdout:
+            (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+        sys.stdout.flush()
+    import threading
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
     rc = 0
     alive = set(range(n))
     while alive:
@@ -781,6 +789,7 @@ def launch_ranks(n):
                 for o in alive:
                     procs[o].terminate()
         time.sleep(0.05)
+    th.join(timeout=10)
     return rc
 
 

@@ -511,11 +511,19 @@ int ac_bert_encode_cls_opts(const ac_bert_config* cfg, const ac_bert_weights* w,
                             void* d_ws, size_t ws_bytes, int opts, int* used_one_launch, ac_stream_t stream);
 int ac_bert_one_launch_status(const ac_bert_config* cfg, int b, int S, const void* d_ws, size_t ws_bytes,
                               int* aborted, ac_stream_t stream);
-/* Verdict of the fused-LayerNorm GEMM epilogues (ac_gemm_set_ln_fusion) of the LAST ac_bert_encode_cls[_opts|_packed] call
- * that used this workspace (same cfg, b, S) and ran layer by layer (the one-launch path of <= 32 token rows neither has such
- * an epilogue nor resets the verdict word: do not ask after it): *aborted = 1 when the tiles of a row panel did not all arrive within the
- * bounded wait (possible only if the device cannot hold one workgroup per CU at once, e.g. under a CU mask); the output
- * rows are NaN then -- repeat after ac_gemm_set_ln_fusion(0).  Synchronises the stream (a 4-byte D2H). */
+/* Verdict of the fused-LayerNorm GEMM epilogues (ac_gemm_set_ln_fusion) of every layer-by-layer ac_bert_encode_cls[_opts|
+ * _packed] call that used this workspace SINCE THE LAST ac_bert_ln_fusion_clear.  The verdict lives at offset 0 of the
+ * workspace whatever (b, S) it is used with (so one read covers all the row chunks of a big batch): word 0 is set by the
+ * kernels of the current call (its later fused launches then stop waiting at their first look at it), every call starts by
+ * folding word 0 into the sticky word 1, _status reports word 0 | word 1.  *aborted = 1 when the tiles of a row panel did not
+ * all arrive within the bounded wait (possible only if the device cannot hold one workgroup per CU at once, e.g. under a CU
+ * mask, or shared with another compute process); the output rows of the affected call(s) are NaN then -- clear, then repeat
+ * after ac_gemm_set_ln_fusion(0).  The one-launch path of <= 32 token rows has no such epilogue and never touches the words.
+ * _status synchronises the stream (an 8-byte D2H); _clear is asynchronous.  A caller that wants verdicts clears a fresh
+ * workspace once before its first use (uninitialised memory could read as a stale verdict; the encode calls themselves are
+ * unaffected by that).  b, S of _status are unused (kept for source compatibility).
+ * Replaces nothing in the reference (classifier.py:1271 has no failure mode of this kind). */
+int ac_bert_ln_fusion_clear(void* d_ws, size_t ws_bytes, ac_stream_t stream);
 int ac_bert_ln_fusion_status(const ac_bert_config* cfg, int b, int S, const void* d_ws, size_t ws_bytes,
                              int* aborted, ac_stream_t stream);
 

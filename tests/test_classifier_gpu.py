@@ -497,3 +497,79 @@ def test_gave_up_layernorm_exchange_is_reported_loudly(clf, monkeypatch):
         assert nv.lib().ac_gemm_ln_fusion_launches() == before
     finally:
         nv.check(nv.lib().ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
+
+
+def _long_texts(n, words=14):
+    vocab = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel", "india", "juliet", "kilo", "lima"]
+    return [" ".join(vocab[(i * 7 + j * 3) % len(vocab)] for j in range(words)) for i in range(n)]
+
+
+def test_starved_layernorm_exchange_never_reaches_memory_or_caller(cuda_dev, caplog):
+    """With the fused-LayerNorm exchange starved for real (ac_gemm_set_ln_fusion(2)) on shapes where the fusion applies:
+    add_examples() stores finite prototypes (the encoder repairs its own call), predict_batch() and predict_tokens() return
+    finite scores WITHOUT raising (transparent repeat), and the results equal a run that never fused."""
+    import logging
+    from adaptive_classifier import AdaptiveClassifier, _native as nv
+    from adaptive_classifier.encoder import HipBertEncoder
+    enc = HipBertEncoder(small_bert(hidden=128, layers=3), device=cuda_dev)
+    texts = _long_texts(24)                                # 24 x 16 tokens = 384 rows: fused epilogues run
+    labels = [("a", "b", "c")[i % 3] for i in range(24)]
+    lib = nv.lib()
+
+    def build():
+        c = AdaptiveClassifier("synthetic-bert-tiny", device="cuda:0", encoder=enc, tokenizer=HashTokenizer())
+        c.add_examples(texts, labels)
+        return c
+    try:
+        nv.check(lib.ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
+        want_clf = build()
+        want = want_clf.predict_batch(texts, k=3, batch_size=24)
+        nv.check(lib.ac_gemm_set_ln_fusion(2), "ac_gemm_set_ln_fusion")
+        n0 = enc.ln_gave_up
+        with caplog.at_level(logging.WARNING):
+            got_clf = build()                              # add_examples under a starved exchange
+        assert enc.ln_gave_up == n0 + 1 and "LayerNorm" in caplog.text
+        for l, p in got_clf.memory.prototypes.items():
+            assert torch.isfinite(p).all() and torch.allclose(p, want_clf.memory.prototypes[l], atol=1e-5)
+        assert all(torch.isfinite(e.embedding).all() for exs in got_clf.memory.examples.values() for e in exs)
+        # predict paths: verify=False inside, NaN scores noticed at the result copy, batch repeated, no exception
+        for call in (lambda: got_clf.predict_batch(texts, k=3, batch_size=24),
+                     lambda: got_clf.predict_tokens(**HashTokenizer()(texts), k=3)):
+            nv.check(lib.ac_gemm_set_ln_fusion(2), "ac_gemm_set_ln_fusion")
+            caplog.clear()
+            with caplog.at_level(logging.WARNING):
+                got = call()
+            assert "encoded again" in caplog.text
+            assert all(s == s for p in got for _, s in p)
+            for g, w in zip(got, want):
+                assert [l for l, _ in g] == [l for l, _ in w] and np.allclose([s for _, s in g], [s for _, s in w], atol=1e-4)
+    finally:
+        nv.check(lib.ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
+
+
+def test_non_finite_embeddings_are_refused_before_anything_is_stored(clf):
+    """add_embeddings() with a NaN / inf row: ValueError, and neither the memory, the label maps nor the head have changed."""
+    before = (dict(clf.label_to_id), dict(clf.id_to_label), {l: len(v) for l, v in clf.memory.examples.items()},
+              {l: p.clone() for l, p in clf.memory.prototypes.items()}, clf.train_steps)
+    good = clf._get_embeddings(["fine text", "more text"])
+    for poison in (float("nan"), float("inf")):
+        bad = good[1].clone(); bad[3] = poison
+        with pytest.raises(ValueError, match="non-finite embedding"):
+            clf.add_embeddings(["fine text", "more text"], [good[0], bad], ["positive", "brand_new_label"])
+        assert (dict(clf.label_to_id), dict(clf.id_to_label)) == before[:2] and clf.train_steps == before[4]
+        assert {l: len(v) for l, v in clf.memory.examples.items()} == before[2]
+        assert all(torch.equal(p, before[3][l]) for l, p in clf.memory.prototypes.items())
+
+    class NanEncoder:                                      # a user-supplied encoder that fails: add_examples raises, stores nothing
+        config = clf.model.config
+        def encode_cls(self, ids, types=None, mask=None):
+            return torch.full((ids.shape[0], clf.embedding_dim), float("nan"), device="cuda:0")
+    real = clf.model
+    try:
+        clf.model = NanEncoder()
+        from adaptive_classifier import _native as nv
+        with pytest.raises(nv.NativeError, match="non-finite embeddings"):
+            clf.add_examples(["some text"], ["yet_another_label"])
+        assert dict(clf.label_to_id) == before[0]
+    finally:
+        clf.model = real

@@ -300,8 +300,9 @@ def test_layernorm_fused_into_the_gemm_epilogue(hidden, layers, heads, inter, b,
 
 def test_starved_layernorm_exchange_gives_up_loudly(cuda_dev):
     """The give-up path of the fused-LayerNorm epilogue for real: with the exchange starved (every tile waits for one arrival
-    more than will come) the launches must END within their bounded wait, the rows must come out NaN, the verdict must say
-    so -- and the next call with the fusion off must be right again."""
+    more than will come) the launches must END within their bounded wait; with verify=False the rows come out NaN and the
+    verdict says so; with verify=True (default) the SAME call notices, switches the fusion off and returns finite, correct
+    rows -- one place that guarantees finite embeddings."""
     import time
     from adaptive_classifier import _native as nv
     from adaptive_classifier.encoder import HipBertEncoder
@@ -314,14 +315,47 @@ def test_starved_layernorm_exchange_gives_up_loudly(cuda_dev):
     try:
         nv.check(lib.ac_gemm_set_ln_fusion(2), "ac_gemm_set_ln_fusion")
         t0 = time.time()
-        bad = enc.encode_cls(ids, types, mask).cpu()
+        bad = enc.encode_cls(ids, types, mask, verify=False).cpu()
         assert time.time() - t0 < 30.0
         assert torch.isnan(bad).all()
         assert enc.ln_fusion_aborted()
         nv.check(lib.ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
-        good = enc.encode_cls(ids, types, mask).cpu()
-        assert not enc.ln_fusion_aborted()
+        good = enc.encode_cls(ids, types, mask, verify=False).cpu()
+        assert not enc.ln_fusion_aborted()                       # the verdict of a call starts clean
         assert (good - want).abs().max().item() < 1e-4
+        # the default contract: still starved, but the call repairs itself
+        nv.check(lib.ac_gemm_set_ln_fusion(2), "ac_gemm_set_ln_fusion")
+        n_gave_up, n_fused = enc.ln_gave_up, lib.ac_gemm_ln_fusion_launches()
+        healed = enc.encode_cls(ids, types, mask).cpu()
+        assert enc.ln_gave_up == n_gave_up + 1 and lib.ac_gemm_ln_fusion_launches() > n_fused
+        assert torch.isfinite(healed).all() and (healed - want).abs().max().item() < 1e-4
+        n_fused = lib.ac_gemm_ln_fusion_launches()
+        enc.encode_cls(ids, types, mask)                         # the fusion is off for the process now
+        assert lib.ac_gemm_ln_fusion_launches() == n_fused and enc.ln_gave_up == n_gave_up + 1
     finally:
         nv.check(lib.ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
     assert (enc.encode_cls(ids, types, mask).cpu() - want).abs().max().item() < 1e-4
+
+
+def test_layernorm_verdict_is_sticky_over_the_chunks_of_a_call(cuda_dev, monkeypatch):
+    """A batch beyond MAX_TOKENS runs as several native calls sharing one workspace.  The give-up of an EARLY chunk must not be
+    erased by a later chunk (here the last chunk is too small for the fused epilogue and comes out finite): the verdict word
+    is sticky over the call, and the default verify=True repairs every chunk."""
+    from adaptive_classifier import _native as nv, encoder as encmod
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_bert(128, 3, 2, 512, vocab=2000, seed=5)
+    ids, types, mask = bert_oracle.synthetic_batch(24, 16, vocab=2000, seed=8, ragged=False)
+    want = bert_oracle.encode_cls(model, ids, types, mask)
+    enc = HipBertEncoder(model, device=cuda_dev)
+    monkeypatch.setattr(encmod, "MAX_TOKENS", 14 * 16)           # chunks of 14 sequences (224 rows: fused) and 10 (160 rows: not)
+    lib = nv.lib()
+    try:
+        nv.check(lib.ac_gemm_set_ln_fusion(2), "ac_gemm_set_ln_fusion")
+        bad = enc.encode_cls(ids, types, mask, verify=False).cpu()
+        assert torch.isnan(bad[:14]).all() and torch.isfinite(bad[14:]).all()
+        assert enc.ln_fusion_aborted()                           # although the LAST native call of the batch was clean
+        healed = enc.encode_cls(ids, types, mask).cpu()
+        assert torch.isfinite(healed).all() and (healed - want).abs().max().item() < 1e-4
+    finally:
+        nv.check(lib.ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
