@@ -23,11 +23,14 @@ def knn_workspace_bytes(N, D, nq, k):
     return b.value
 
 
-# Where the prepared-store GEMM-form path applies (library limits: N >= 65536, k <= 100) and pays: its fixed cost (sample
-# search, thresholds, query plane, a deeper merge: ~0.3 ms) beats the fp32 sweep from ~20 M query-row pairs on
-# (measured, round 3, fp32 sweep vs batched: 256 x 100k 0.56 vs 0.39 ms inside the predict step; 1024 x 2M x 1024 56 vs 6.5 ms;
-# 4096 x 10M 552 vs 78 ms)
+# Where the prepared-store paths apply (library limits: N >= 65536, k <= 100) and pay.
+#   >= 64 queries: the GEMM-form proposal sweep (knn_batch_sweep); its fixed cost (sample stages, thresholds, query plane, a deeper
+#      merge: ~0.3 ms) beats the fp32 sweep from ~20 M query-row pairs on (measured, round 3, fp32 sweep vs batched: 256 x 100k 0.56
+#      vs 0.39 ms inside the predict step; 1024 x 2M x 1024 56 vs 6.5 ms; 4096 x 10M 552 vs 78 ms)
+#   1 .. 63 queries (round 4): ONE bandwidth-bound pass over the fp16 plane with the query tile resident (knn_plane_sweep): half
+#      the bytes of the fp32 sweep; pays once the sweep, not the launch chain, is what a search costs (PLANE_MIN_ROWS)
 BATCH_MIN_QUERIES, BATCH_MIN_ROWS, BATCH_MAX_K, BATCH_MIN_PAIRS = 64, 65536, 100, 2.0e7
+PLANE_MIN_ROWS = 1 << 18
 
 
 def prepare_store(P, N, D):
@@ -45,9 +48,12 @@ def prepare_store(P, N, D):
 
 
 def batch_applies(N, nq, k, auto=False):
-    """Library limits of ac_knn_l2_topk_batch; auto=True adds the size heuristic the index uses to pick a path."""
-    ok = nq >= BATCH_MIN_QUERIES and N >= BATCH_MIN_ROWS and k <= BATCH_MAX_K
-    return ok and (not auto or float(N) * nq >= BATCH_MIN_PAIRS)
+    """Library limits of ac_knn_l2_topk_batch (any number of queries: below 64 it runs the fp16-plane sweep); auto=True adds the
+    size heuristic the index uses to pick a path."""
+    ok = nq >= 1 and N >= BATCH_MIN_ROWS and k <= BATCH_MAX_K
+    if not ok or not auto:
+        return ok
+    return float(N) * nq >= BATCH_MIN_PAIRS if nq >= BATCH_MIN_QUERIES else N >= PLANE_MIN_ROWS
 
 
 def knn_l2_topk(P, N, D, Q, k, row_offset=0, out=None, workspace=None, stats=None, exact_out=None, prepared=None):
@@ -55,8 +61,9 @@ def knn_l2_topk(P, N, D, Q, k, row_offset=0, out=None, workspace=None, stats=Non
 
     Returns (dist fp32 [nq,k], ids int64 [nq,k]) on the same device.  Asynchronous.
     exact_out: optional float64 [nq,k] cuda tensor that receives the exact fp64 distances (shard merges).
-    prepared: optional (planes, norms) from `prepare_store`: many-query searches then run the GEMM-form proposal
-              sweep on the fp16 matrix pipe (`ac_knn_l2_topk_batch`) -- same exact result, several times the throughput.
+    prepared: optional (planes, norms) from `prepare_store`: the search then proposes from the store's fp16 plane
+              (`ac_knn_l2_topk_batch`: one bandwidth-bound pass for < 64 queries, the GEMM-form sweep on the matrix pipe from 64
+              on) -- same exact result, half the bytes / several times the throughput.
     """
     if prepared is not None and batch_applies(N, Q.shape[0], k):
         return _knn_l2_topk_batch(P, N, D, Q, k, prepared, row_offset, out, workspace, stats, exact_out)
@@ -135,6 +142,12 @@ class HipFlatL2Index:
         self._ws = None
         self._stats = None
         self._prepared = None        # (planes, norms) of the resident rows for the batched search; dropped when rows change
+        self._searches_since_change = 0
+
+    def _rows_changed(self):
+        """the resident rows changed: the prepared plane / norms describe the old ones"""
+        self._prepared = None
+        self._searches_since_change = 0
 
     @property
     def device(self):
@@ -176,7 +189,7 @@ class HipFlatL2Index:
             self._reserve(self._n + m)
             self._store[self._n: self._n + m, : self.d] = rows.to(self.device, non_blocking=True)
             self._n += m
-            self._prepared = None
+            self._rows_changed()
         if self._store is None:
             self._reserve(1)
         if self._stats is None:
@@ -192,7 +205,7 @@ class HipFlatL2Index:
             self._reserve(self._n + m)
             self._store[self._n: self._n + m, : self.d] = rows.to(self.device)
             self._n += m
-            self._prepared = None
+            self._rows_changed()
         else:
             self._pending.append(rows.clone())
             self._npending += rows.shape[0]
@@ -205,7 +218,7 @@ class HipFlatL2Index:
         self._pending, self._npending = [], 0
         self._store = rows
         self._n = rows.shape[0]
-        self._prepared = None
+        self._rows_changed()
 
     def remove_ids(self, ids):
         if isinstance(ids, torch.Tensor):
@@ -220,13 +233,13 @@ class HipFlatL2Index:
         kept = self._store[: self._n][keep]             # IndexFlat compacts: later rows shift down
         self._store[: kept.shape[0]] = kept
         self._n = kept.shape[0]
-        self._prepared = None
+        self._rows_changed()
         return int(ids.size)
 
     def reset(self):
         self._n = 0
         self._pending, self._npending = [], 0
-        self._prepared = None
+        self._rows_changed()
 
     def update_rows(self, rows, values):
         """Overwrite existing rows in place (ids keep their meaning; no compaction)."""
@@ -238,7 +251,7 @@ class HipFlatL2Index:
         self._materialize()
         vals = self._as_rows(values).to(self.device)
         self._store[rows.to(self.device), : self.d] = vals
-        self._prepared = None
+        self._rows_changed()
 
     def search_device(self, q, k):
         """q: [nq, d] fp32 tensor (any device) -> (dist, ids) CUDA tensors; no host sync."""
@@ -250,7 +263,13 @@ class HipFlatL2Index:
             q = q.contiguous()
         batch = batch_applies(self._n, q.shape[0], k, auto=True)
         if batch and self._prepared is None:
-            self._prepared = prepare_store(self._store, self._n, self.d)      # once per store content
+            # preparing costs two passes over the rows (~0.14 s at 10M x 768): at once for a many-query search (it pays within
+            # the call); for a small batch only when the store has already served a search since its rows last changed
+            if q.shape[0] >= BATCH_MIN_QUERIES or self._searches_since_change >= 1:
+                self._prepared = prepare_store(self._store, self._n, self.d)      # once per store content
+            else:
+                batch = False
+        self._searches_since_change += 1
         need = knn_batch_workspace_bytes(self._n, self.d, q.shape[0], k) if batch else knn_workspace_bytes(self._n, self.d, q.shape[0], k)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)

@@ -70,15 +70,15 @@ __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict_
     }
 }
 
-// pass 2: plane[k/8][row][8] = fp16(x * 2^-e): e from the maximum row norm (store) or from the row's own norm (queries,
-// which also get their threshold and their epilogue factor here)
+// pass 2: fp16(x * 2^-e) in runs of 8 k: e from the maximum row norm (store; tile-major layout, see the store below) or from the
+// row's own norm (queries: plane[k/8][row][8]; they also get their threshold and their epilogue factor here)
 //   thr[q]  = (tau_q - |q|^2 + E_q) rounded up to fp32, tau_q = exact k'-th smallest sample distance (fp64)
 //   qfac[q] = -2 2^(e_p + e_q)
 __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int64_t rows_pad,
                                                         int D, int Kp, const uint32_t* __restrict__ maxnorm_bits, int per_row_scale,
                                                         uint16_t* __restrict__ plane, const double* __restrict__ sampleD, int kp,
                                                         double gamma, float* __restrict__ thr, float* __restrict__ qfac,
-                                                        float* __restrict__ pad_norms) {
+                                                        float* __restrict__ pad_norms, int tile_major) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows_pad) return;
@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
         }
         uint4 H;
         H.x = pack_f16(v[0], v[1]); H.y = pack_f16(v[2], v[3]); H.z = pack_f16(v[4], v[5]); H.w = pack_f16(v[6], v[7]);
-        *reinterpret_cast<uint4*>(plane + ((int64_t)q * rows_pad + row) * 8) = H;
+        // queries: plane[k-slot][row][8].  store (tile_major): plane[row / 256][k-slot][row % 256][8] -- a 256-row tile is ONE
+        // contiguous run of 256 * Kp * 2 bytes (k-slot-major inside), so a sweep streams the store front to back
+        const int64_t at = tile_major ? (((row >> 8) * nslot + q) << 8) + (row & 255) : (int64_t)q * rows_pad + row;
+        *reinterpret_cast<uint4*>(plane + at * 8) = H;
     }
 }
 
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(64) void knn_thr_kernel(const double* __restrict__ 
 }
 
 struct BatchParams {
-    const uint16_t* Pp; int64_t p_rows;      // store plane [Kp/8][p_rows][8] fp16
+    const uint16_t* Pp; int64_t p_rows;      // store plane [p_rows / 256][Kp/8][256][8] fp16 (tile-major)
     const float* pnorm;                      // [p_rows]: |p|^2, +inf past N
     const uint16_t* Qp; int64_t q_rows;      // query plane, q_rows = round_up(nq, 256)
     const float* thr;                        // [q_rows]
@@ -194,8 +197,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
 
     // ---- DMA stream.  Wave w stages store groups w + NWV t and query groups w + NWV t, both chunks.
     //      A piece = 32 rows x 2 k-slots: lane (i32, kg) copies the 16 B of row i32, k-slot 4 s + 2 c + kg.
-    const int64_t a_step = 4 * prm.p_rows * 8, w_step = 4 * prm.q_rows * 8;
-    const int64_t a_c1 = 2 * prm.p_rows * 8, w_c1 = 2 * prm.q_rows * 8;   // chunk 1 = two k-slots further
+    //      Store plane (tile-major): k-slot s of row r sits at ((r / 256 * nslot + s) * 256 + r % 256) * 16 bytes.
+    const int64_t a_step = 4 * 256 * 8, w_step = 4 * prm.q_rows * 8;
+    const int64_t a_c1 = 2 * 256 * 8, w_c1 = 2 * prm.q_rows * 8;          // chunk 1 = two k-slots further
+    const int nslot_p = prm.Kp >> 3;
     const uint16_t* pa[GPW];
     const uint16_t* pw[GPW];
     const int rs8i = 8 * (int)prm.row_stride;
@@ -204,7 +209,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
         for (int t = 0; t < GPW; ++t) {
             int row = (it * G + g) * BBM + 32 * (wave + NWV * t) + i32;
             if (row > nrows - 1) row = nrows - 1;
-            pa[t] = prm.Pp + ((int64_t)kg * prm.p_rows + (BURST ? (row >> 3) * rs8i + (row & 7) : row)) * 8;
+            const int srow = BURST ? (row >> 3) * rs8i + (row & 7) : row;     // store row (sample stages: runs of 8 rows)
+            pa[t] = prm.Pp + ((((int64_t)(srow >> 8) * nslot_p + kg) << 8) + (srow & 255)) * 8;
         }
     };
     auto w_base = [&]() {
@@ -474,7 +480,7 @@ int knn_prepare_store(const float* X, int64_t ldx, int64_t rows, int D, uint16_t
     hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, X, ldx, rows, D, norms, maxnorm_bits);
     AC_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_plane_kernel, dim3((unsigned)((rp + 3) / 4)), dim3(256), 0, stream, X, ldx, rows, rp, D, Kp, maxnorm_bits, 0,
-                       plane, (const double*)nullptr, 0, 0.0, (float*)nullptr, (float*)nullptr, norms);
+                       plane, (const double*)nullptr, 0, 0.0, (float*)nullptr, (float*)nullptr, norms, 1);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
@@ -484,7 +490,7 @@ int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t l
     const int Kp = knn_kp(D);
     const int64_t qp = ((int64_t)nq + 255) / 256 * 256;
     hipLaunchKernelGGL(knn_plane_kernel, dim3((unsigned)((qp + 3) / 4)), dim3(256), 0, stream, Q, ldQ, (int64_t)nq, qp, D, Kp,
-                       maxnorm_bits, 1, qplane, sampleD, kp, gamma, thr, qfac, (float*)nullptr);
+                       maxnorm_bits, 1, qplane, sampleD, kp, gamma, thr, qfac, (float*)nullptr, 0);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

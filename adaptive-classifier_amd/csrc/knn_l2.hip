@@ -430,7 +430,10 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep_ring(SweepParams prm) {
     int* cnt = reinterpret_cast<int*>(list_i + (size_t)TQ * prm.cap);
     float* tau_s = reinterpret_cast<float*>(cnt + TQ);
     float* wmax_s = tau_s + TQ;                       // [kWaves]
-    int* need_s = reinterpret_cast<int*>(wmax_s + kWaves);     // [2][8] per-tile verdicts of the waves
+    // [2][8] per-tile verdicts of the waves, accessed with relaxed workgroup-scope atomics (= plain ds_read / ds_write).  As
+    // `volatile int*` accesses they were FLAT loads -- address-space inference leaves volatile accesses alone -- and a flat load
+    // counts on vmcnt too: every tile waited vmcnt(0), i.e. drained the whole DMA ring, for them.
+    __shared__ int need_s[2 * 8];
     int bar_parity = 0;
     for (int t = tid; t < TQ; t += kThreads) {
         cnt[t] = 0;
@@ -532,14 +535,14 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep_ring(SweepParams prm) {
             int over = 0;
             if (tid < TQ) over = cnt[tid] > (prm.cap - prm.cap / 4);
             const int w_need = __any((int)lane_pend | over) != 0;
-            volatile int* fl = need_s + 8 * (bar_parity & 1);
-            if (lane == 0) fl[wave] = w_need;
+            const int fl = 8 * (bar_parity & 1);
+            if (lane == 0) __hip_atomic_store(&need_s[fl + wave], w_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             int need = 0;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) need |= fl[w];
+            for (int w = 0; w < kWaves; ++w) need |= __hip_atomic_load(&need_s[fl + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             ++bar_parity;
             if (!need) break;
             for (int q = wave; q < TQ; q += kWaves) {
@@ -615,6 +618,238 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep_ring(SweepParams prm) {
         float m = 0.f;
         for (int w = 0; w < kWaves; ++w) m = fmaxf(m, wmax_s[w]);
         prm.part_maxnorm[v] = m;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// knn_plane_sweep: the HBM-bound sweep over the PREPARED store's fp16 plane for 1 .. 64 resident queries.
+//   The fp32 sweeps above stream 4 B per store element; a prepared store (ac_knn_prepare_store) also holds every row as ONE
+//   fp16 plane (2 B per element) whose one-product MFMA dot differs from the exact value by a bound E the merge's certificate
+//   knows (knn_batch.hip: |v - exact| <= gamma (max|p| + |q|)^2) -- the machinery the batched search uses from 64 queries up.
+//   This kernel is its small-batch, bandwidth-bound form: ONE pass over the plane (half the bytes of the fp32 sweep), the query
+//   tile of 32 or 64 columns resident in LDS, v_mfma_f32_32x32x16_f16 at ~20 % of the matrix pipe, the candidate lists, pruning
+//   and partial results of knn_sweep (exact results come from knn_merge_rerank's fp64 re-rank + certificate, as everywhere).
+//   * The plane is tile-major: a 256-row tile is one contiguous run of 256 * Kp * 2 bytes, [k-slot][row % 256][8 fp16] inside.
+//     In that layout the MFMA A fragment of (32 rows, 16 k) is two 512-byte runs -- lane (i = lane & 31, kg = lane >> 5) loads
+//     the 16 bytes of row i, k-slot 2 s + kg -- i.e. every load instruction consumes whole 128-byte lines, which is what lets
+//     it be NON-TEMPORAL straight into registers (knn_sweep's fp32 operand layout takes half a line per instruction and loses
+//     with nt loads; knn_sweep_ring goes through LDS for that reason).  No LDS round trip for the rows, no barrier in the k-loop.
+//   * A workgroup = 8 waves x 32 rows = one 256-row tile per step, tiles interleaved over the grid (T = it * G + g), one
+//     residency round.  Per wave 16 loads (16 KB) in flight: four register buffers of four k-steps, issued unconditionally.
+//   * Query B fragments: LDS [k-step][sub-tile][lane] x 16 B, copied from the query plane knn_prepare_queries builds (same
+//     scaling and rounding as the batched path, so the same bound).  Sweep value v = |p|^2 + f_q acc; |p|^2 comes from the
+//     prepared norms through SCALAR loads (constant address space: off the vmcnt queue the prefetched rows sit in).
+//   * The block meets once per tile at a raw s_barrier to decide about pruning (as knn_sweep_ring does).
+// --------------------------------------------------------------------------------------
+struct PlaneSweepParams {
+    const uint16_t* Pp;       // store plane, tile-major (knn_batch.hip knn_plane_kernel)
+    const float* pnorm;       // [round_up(N, 256)] |p|^2, +inf past N
+    const uint16_t* Qp;       // query plane [Kp/8][q_rows][8]
+    int64_t q_rows;
+    const float* qfac;        // [q_rows] -2 2^(e_p + e_q)
+    int64_t N;
+    int64_t ntiles;           // ceil(N / 256)
+    int Kp;                   // multiple of 64
+    int q0, nq;               // this launch's query tile: queries q0 .. q0 + nq - 1 (nq <= TQ)
+    int kp, cap, G;
+    float* part_d;            // [query][G][kp]
+    int32_t* part_i;
+    int32_t* clear_ctr;       // as SweepParams (first tile's launch only; else NULL)
+    int32_t* clear_stats;
+};
+
+typedef _Float16 kf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t ku32x4 __attribute__((ext_vector_type(4)));
+// C/D layout of v_mfma_f32_32x32x16_f16: lane owns column (lane & 31) and these 16 rows
+__device__ __forceinline__ int plane_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int TQ>
+__global__ __launch_bounds__(kThreads, 2) void knn_plane_sweep(PlaneSweepParams prm) {
+    constexpr int NJ = TQ / 32;                       // 32-column sub-tiles of the query tile
+    constexpr int NB = 4, GK = 4;                     // register buffers x k-steps per buffer (16 loads in flight)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i32 = lane & 31, kg = lane >> 5;
+    const int g = xcd_remap(blockIdx.x, prm.G);
+    if (blockIdx.x == 0 && tid < 64 && prm.clear_ctr) {            // consumed by the kernels launched after this one
+        prm.clear_ctr[tid] = 0;
+        if (tid < 4 && prm.clear_stats) prm.clear_stats[tid] = tid == 1 ? 2 : 0;     // [1] = 2: the fp16-plane sweep ran
+    }
+    const int nk = prm.Kp >> 4;                       // 16-k MFMA steps per row
+    const int ngrp = nk / GK;                         // (Kp % 64 == 0)
+    // ---- LDS: query fragments [nk][NJ][64] x 16 B | lists | counters ----
+    ku32x4* Qs = reinterpret_cast<ku32x4*>(smem);
+    float* list_d = reinterpret_cast<float*>(smem + (size_t)nk * NJ * 1024);
+    int32_t* list_i = reinterpret_cast<int32_t*>(list_d + (size_t)TQ * prm.cap);
+    int* cnt = reinterpret_cast<int*>(list_i + (size_t)TQ * prm.cap);
+    float* tau_s = reinterpret_cast<float*>(cnt + TQ);
+    __shared__ int need_s[2 * 8];                                  // [2][8] per-tile verdicts of the waves (static LDS: see knn_sweep_ring)
+    for (int t = tid; t < nk * NJ * 64; t += kThreads) {
+        const int l = t & 63, jj = (t >> 6) % NJ, s = (t >> 6) / NJ;
+        const int64_t qrow = prm.q0 + 32 * jj + (l & 31);          // (< q_rows: the plane is padded to 256 queries with zeros)
+        Qs[t] = *reinterpret_cast<const ku32x4*>(prm.Qp + ((int64_t)(2 * s + (l >> 5)) * prm.q_rows + qrow) * 8);
+    }
+    for (int t = tid; t < TQ; t += kThreads) {
+        cnt[t] = 0;
+        tau_s[t] = (t < prm.nq) ? INFINITY : -INFINITY;
+    }
+    __syncthreads();
+    float tau[NJ], qf[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) { tau[jj] = tau_s[32 * jj + i32]; qf[jj] = prm.qfac[prm.q0 + 32 * jj + i32]; }
+    int bar_parity = 0;
+
+    const int64_t my_tiles = (prm.ntiles > g) ? (prm.ntiles - 1 - g) / prm.G + 1 : 0;
+    const int64_t total = my_tiles * ngrp;            // groups of GK k-steps this wave consumes
+    const size_t tile_bytes = (size_t)prm.Kp * 512;   // 256 rows x Kp x 2 B
+    const uint32_t lane_off = (uint32_t)(kg * 256 + 32 * wave + i32) * 16u;    // byte offset of this lane's piece inside a k-slot pair
+    // prefetch state: next group to load
+    int64_t pf_tile = 0;
+    int pf_grp = 0;
+    auto tile_base = [&](int64_t it) -> const char* {
+        int64_t T = it * prm.G + g;
+        if (T > prm.ntiles - 1) T = prm.ntiles - 1;    // past the end: the last tile again (never consumed)
+        return reinterpret_cast<const char*>(prm.Pp) + (size_t)T * tile_bytes;
+    };
+    const char* pf_base = tile_base(0);
+    ku32x4 buf[NB][GK];
+#define AC_PL_PREFETCH(B)                                                                                     \
+    do {                                                                                                      \
+        const char* src_ = pf_base + (size_t)pf_grp * (GK * 8192) + lane_off;                                 \
+        _Pragma("unroll") for (int u = 0; u < GK; ++u)                                                        \
+            buf[B][u] = __builtin_nontemporal_load(reinterpret_cast<const ku32x4*>(src_ + u * 8192));          \
+        if (++pf_grp == ngrp) { pf_grp = 0; ++pf_tile; pf_base = tile_base(pf_tile); }                        \
+    } while (0)
+
+    f32x16 acc[NJ];
+    int64_t cur_tile = 0;
+    int cur_grp = 0;
+
+    auto epilogue = [&]() {
+        const int row0 = (int)((cur_tile * prm.G + g) * 256) + 32 * wave;      // wave-uniform, multiple of 32 (N < 2^31)
+        // |p|^2 of the wave's 32 rows through the scalar unit: lane half kg needs rows (r & 3) + 8 (r >> 2) + 4 kg
+        typedef const float __attribute__((address_space(4)))* cfp;
+        const cfp pn = (cfp)(uintptr_t)(prm.pnorm + __builtin_amdgcn_readfirstlane(row0));
+        bool maybe = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float lo = pn[(r & 3) + 8 * (r >> 2)], hi = pn[(r & 3) + 8 * (r >> 2) + 4];
+            const float pnr = kg ? hi : lo;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                acc[jj][r] = fmaf(acc[jj][r], qf[jj], pnr);                    // the sweep value, in place
+                maybe |= acc[jj][r] < tau[jj];
+            }
+        }
+        unsigned done = 0;
+        bool pend = __any(maybe) != 0;
+        for (;;) {
+            bool lane_pend = false;
+            if (pend) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const int q = 32 * jj + i32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = acc[jj][r];
+                        const unsigned bit = 1u << (16 * jj + r);
+                        if (!(done & bit) && d < tau[jj]) {                    // (rows past N carry +inf norms: never below tau)
+                            const int slot = atomicAdd(&cnt[q], 1);
+                            if (slot < prm.cap) {
+                                list_d[q * prm.cap + slot] = d;
+                                list_i[q * prm.cap + slot] = row0 + plane_acc_row(r, lane);
+                                done |= bit;
+                            } else {
+                                lane_pend = true;
+                            }
+                        }
+                    }
+                }
+            }
+            // one RAW barrier per tile (knn_sweep_ring: __syncthreads_or would fence vmcnt(0) and drain the prefetched rows)
+            int over = 0;
+            if (tid < TQ) over = cnt[tid] > (prm.cap - prm.cap / 4);
+            const int w_need = __any((int)lane_pend | over) != 0;
+            const int fl = 8 * (bar_parity & 1);
+            if (lane == 0) __hip_atomic_store(&need_s[fl + wave], w_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int need = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) need |= __hip_atomic_load(&need_s[fl + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ++bar_parity;
+            if (!need) break;
+            for (int q = wave; q < TQ; q += kWaves) {
+                if (cnt[q] > prm.kp)
+                    prune_dispatch(list_d + q * prm.cap, list_i + q * prm.cap, &cnt[q], &tau_s[q], prm.cap, prm.kp, lane);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) tau[jj] = tau_s[32 * jj + i32];
+            pend = true;                                  // re-test un-pushed entries against the tightened tau
+        }
+    };
+
+#define AC_PL_COMPUTE(B)                                                                                      \
+    do {                                                                                                      \
+        if (cur_grp == 0) {                                                                                   \
+            _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj)                                                 \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;                              \
+        }                                                                                                     \
+        const ku32x4* qsrc_ = Qs + (size_t)cur_grp * (GK * NJ * 64) + lane;                                    \
+        ku32x4 bq_[NJ];                                                                                        \
+        _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) bq_[jj] = qsrc_[jj * 64];                           \
+        _Pragma("unroll") for (int u = 0; u < GK; ++u) {                                                      \
+            const kf16x8 a_ = __builtin_bit_cast(kf16x8, buf[B][u]);                                          \
+            kf16x8 b_[NJ];                                                                                    \
+            _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) b_[jj] = __builtin_bit_cast(kf16x8, bq_[jj]);   \
+            if (u + 1 < GK) { /* LDS reads one step ahead */                                                  \
+                _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) bq_[jj] = qsrc_[((u + 1) * NJ + jj) * 64];  \
+            }                                                                                                 \
+            _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj)                                                 \
+                acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_[jj], acc[jj], 0, 0, 0);               \
+            __builtin_amdgcn_sched_barrier(0); /* keep the per-load consume order */                          \
+        }                                                                                                     \
+        if (++cur_grp == ngrp) { epilogue(); cur_grp = 0; ++cur_tile; }                                       \
+    } while (0)
+
+    // Loads are issued unconditionally (past the end they re-read the last tile) so that every path has the same number of
+    // loads in flight: a load inside a branch makes hipcc's s_waitcnt accounting wait on the buffer it has just issued.
+    if (total > 0) {
+        AC_PL_PREFETCH(0);
+        AC_PL_PREFETCH(1);
+        AC_PL_PREFETCH(2);
+        for (int64_t gg = 0; gg < total; gg += NB) {      // (ngrp may be odd: the tile boundary falls anywhere in this body)
+            AC_PL_PREFETCH(3);
+            AC_PL_COMPUTE(0);
+            AC_PL_PREFETCH(0);
+            if (gg + 1 < total) AC_PL_COMPUTE(1);
+            AC_PL_PREFETCH(1);
+            if (gg + 2 < total) AC_PL_COMPUTE(2);
+            AC_PL_PREFETCH(2);
+            if (gg + 3 < total) AC_PL_COMPUTE(3);
+        }
+    }
+#undef AC_PL_PREFETCH
+#undef AC_PL_COMPUTE
+
+    // ---- final: sort + cut every list to kp, write the block's partial result ----
+    __syncthreads();
+    for (int q = wave; q < TQ; q += kWaves) {
+        if (q >= prm.nq) continue;
+        prune_dispatch(list_d + q * prm.cap, list_i + q * prm.cap, &cnt[q], &tau_s[q], prm.cap, prm.kp, lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int n = cnt[q];
+        const size_t base = ((size_t)(prm.q0 + q) * prm.G + g) * prm.kp;
+        for (int e = lane; e < prm.kp; e += 64) {
+            prm.part_d[base + e] = e < n ? list_d[q * prm.cap + e] : INFINITY;
+            prm.part_i[base + e] = e < n ? list_i[q * prm.cap + e] : -1;
+        }
     }
 }
 
@@ -1520,6 +1755,125 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     return AC_OK;
 }
 
+
+// ---- the fp16-plane sweep for small batches (knn_plane_sweep): 1 .. kPlaneMaxQueries queries against a prepared store ----
+constexpr int kPlaneMaxQueries = 64;
+
+struct PlanePlan {
+    int TQ, nqt, kp, cap, G, Dp, Kp;
+    int64_t ntiles, q_rows;
+    size_t sweep_lds, merge_lds, fb_lds;
+    size_t off_part_d, off_part_i, off_flags, off_qp, off_qfac, off_thr, off_fb_d, off_fb_i, off_fb_ctr, total;
+    int fb_S, fb_F;
+};
+
+// false: the shape does not fit (LDS) or the form is switched off -- the caller uses the GEMM-form path instead
+bool make_plane_plan(int64_t N, int D, int nq, int k, PlanePlan* pp) {
+    static const int plane_env = getenv("AC_KNN_PLANE") ? atoi(getenv("AC_KNN_PLANE")) : -1;       // 0 = never (A/B)
+    if (plane_env == 0 || nq < 1 || nq > kPlaneMaxQueries || N < 1 || N >= 2147483647LL - 512 || k < 1 || k > kBatchMaxK) return false;
+    pp->kp = k + kBatchPad;
+    pp->Dp = (D + 3) / 4 * 4;
+    pp->Kp = (D + 63) / 64 * 64;
+    const int nk = pp->Kp / 16;
+    auto lds_for = [&](int TQ, int cap) {
+        return (size_t)nk * (TQ / 32) * 1024 + (size_t)TQ * cap * 8 + (size_t)TQ * 8 + 2 * 8 * 4 + 64;
+    };
+    const int cap_full = (2 * pp->kp + 15) / 16 * 16, cap_min = (pp->kp + 32 + 15) / 16 * 16;
+    const int tq_first = nq > 32 ? 64 : 32;
+    pp->TQ = 0;
+    for (int TQ = tq_first; TQ >= 32 && !pp->TQ; TQ -= 32)
+        for (int cap = cap_full; cap >= cap_min; cap -= 16)
+            if (lds_for(TQ, cap) <= (size_t)kLdsLimit) { pp->TQ = TQ; pp->cap = cap; break; }
+    if (!pp->TQ || pp->cap > 512) return false;
+    pp->sweep_lds = lds_for(pp->TQ, pp->cap);
+    pp->nqt = (nq + pp->TQ - 1) / pp->TQ;
+    pp->ntiles = (N + 255) / 256;
+    int64_t G = ac::dev_info().cus;                       // one 8-wave workgroup per CU: exactly one residency round
+    if (G > pp->ntiles) G = pp->ntiles;
+    if (G > kMergeMaxCand / pp->kp) G = kMergeMaxCand / pp->kp;
+    if (const char* e = getenv("AC_KNN_G")) { int64_t v = atoll(e); if (v >= 1 && v <= G) G = v; }   // tuning experiments
+    pp->G = (int)G;
+    pp->q_rows = 256;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += ac::align_up(n, 256); return o; };
+    const size_t ncand = (size_t)pp->nqt * pp->TQ * pp->G * pp->kp;
+    pp->off_part_d = take(ncand * 4);
+    pp->off_part_i = take(ncand * 4);
+    pp->off_flags = take((size_t)nq * 4);
+    pp->off_qp = take(ac::knn_planes_bytes(nq, D));
+    pp->off_qfac = take((size_t)pp->q_rows * 4);
+    pp->off_thr = take((size_t)pp->q_rows * 4);
+    pp->fb_S = 4096 / next_pow2(k);
+    if (pp->fb_S > 64) pp->fb_S = 64;
+    if (pp->fb_S < 1) pp->fb_S = 1;
+    pp->fb_F = nq;
+    pp->off_fb_d = take((size_t)pp->fb_F * pp->fb_S * k * 8);
+    pp->off_fb_i = take((size_t)pp->fb_F * pp->fb_S * k * 4);
+    pp->off_fb_ctr = take(256);
+    pp->total = off;
+    pp->merge_lds = ac::align_up((size_t)pp->G * pp->kp * 4, 16) + ac::align_up((size_t)pp->Dp * 4, 16) + (size_t)pp->kp * 16 + 256 * 4 + 64;
+    pp->fb_lds = (size_t)kFbCap * 12 + ac::align_up((size_t)pp->Dp, 4) * 4 + 64;
+    return true;
+}
+
+int plane_search(const PlanePlan& pp, const float* d_P, int64_t N, int64_t ldP, int D, const uint16_t* d_planes, const float* d_norms,
+                 const float* d_Q, int nq, int64_t ldQ, int k, int64_t row_offset, float* d_outD, double* d_outD64, int64_t* d_outI,
+                 char* ws, int32_t* d_stats, hipStream_t stream) {
+    const int64_t np = (N + 255) / 256 * 256;
+    const uint32_t* d_maxnorm = reinterpret_cast<const uint32_t*>(d_norms + np);
+    const double gamma = ac::knn_batch_gamma(D);
+    // 1. the queries' fp16 plane (each scaled by its own power of two) and epilogue factors -2 2^(e_p + e_q): the same kernel,
+    //    scaling and rounding as the GEMM-form path, hence the same error bound
+    int rc = ac::knn_prepare_queries(nullptr, pp.kp, d_Q, ldQ, D, nq, d_maxnorm, gamma, (uint16_t*)(ws + pp.off_qp),
+                                     (float*)(ws + pp.off_thr), (float*)(ws + pp.off_qfac), stream);
+    if (rc != AC_OK) return rc;
+    // 2. one pass over the plane per query tile
+    PlaneSweepParams sp;
+    sp.Pp = d_planes; sp.pnorm = d_norms; sp.Qp = (const uint16_t*)(ws + pp.off_qp); sp.q_rows = pp.q_rows;
+    sp.qfac = (const float*)(ws + pp.off_qfac); sp.N = N; sp.ntiles = pp.ntiles; sp.Kp = pp.Kp;
+    sp.kp = pp.kp; sp.cap = pp.cap; sp.G = pp.G;
+    sp.part_d = (float*)(ws + pp.off_part_d); sp.part_i = (int32_t*)(ws + pp.off_part_i);
+    if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
+    for (int qt = 0; qt < pp.nqt; ++qt) {
+        sp.q0 = qt * pp.TQ; sp.nq = nq - sp.q0 < pp.TQ ? nq - sp.q0 : pp.TQ;
+        sp.clear_ctr = qt == 0 ? (int32_t*)(ws + pp.off_fb_ctr) : nullptr;
+        sp.clear_stats = qt == 0 ? d_stats : nullptr;
+        if (pp.TQ == 64) {
+            AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_plane_sweep<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.sweep_lds));
+            hipLaunchKernelGGL(knn_plane_sweep<64>, dim3(pp.G), dim3(kThreads), pp.sweep_lds, stream, sp);
+        } else {
+            AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_plane_sweep<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.sweep_lds));
+            hipLaunchKernelGGL(knn_plane_sweep<32>, dim3(pp.G), dim3(kThreads), pp.sweep_lds, stream, sp);
+        }
+        AC_LAUNCH_CHECK();
+    }
+    if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_stop, stream));
+    // 3. merge of the G per-workgroup lists + exact fp64 re-rank + certificate with the fp16 bound, then the exact fallback
+    MergeParams mp;
+    mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = pp.Dp;
+    mp.k = k; mp.kp = pp.kp; mp.G = pp.G; mp.nblk = 1; mp.gamma = gamma;
+    mp.cand_cnt = nullptr; mp.cand_cap = 0; mp.cand_segs = 1; mp.run_stride = 0;
+    mp.row_offset = row_offset;
+    mp.part_d = (const float*)(ws + pp.off_part_d); mp.part_i = (const int32_t*)(ws + pp.off_part_i);
+    mp.part_maxnorm = reinterpret_cast<const float*>(d_maxnorm);
+    mp.outD = d_outD; mp.outD64 = d_outD64; mp.outI = d_outI;
+    mp.flags = (int32_t*)(ws + pp.off_flags);
+    mp.stats = d_stats;
+    mp.fb_S = pp.fb_S; mp.fb_F = pp.fb_F;
+    mp.fb_d = (double*)(ws + pp.off_fb_d); mp.fb_i = (int32_t*)(ws + pp.off_fb_i); mp.fb_slotctr = (int32_t*)(ws + pp.off_fb_ctr);
+    AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.merge_lds));
+    hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), pp.merge_lds, stream, mp);
+    AC_LAUNCH_CHECK();
+    (void)hipFuncSetAttribute((const void*)knn_exact_fallback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.fb_lds);
+    hipLaunchKernelGGL(knn_exact_fallback, dim3(pp.fb_S, nq), dim3(kFbThreads), pp.fb_lds, stream, mp);
+    AC_LAUNCH_CHECK();
+    const int np2 = next_pow2(pp.fb_S * k > 2 ? pp.fb_S * k : 2);
+    (void)hipFuncSetAttribute((const void*)knn_exact_fb_merge, hipFuncAttributeMaxDynamicSharedMemorySize, np2 * 12);
+    hipLaunchKernelGGL(knn_exact_fb_merge, dim3(nq), dim3(256), (size_t)np2 * 12, stream, mp, np2);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
 }  // namespace
 
 extern "C" int ac_knn_store_bytes(int64_t N, int D, size_t* planes_bytes, size_t* norms_bytes) {
@@ -1546,6 +1900,8 @@ extern "C" int ac_knn_l2_topk_batch_workspace(int64_t N, int D, int nq, int k, s
     int rc = make_batch_plan(N, D, nq, k, &bp);
     if (rc != AC_OK) return rc;
     *bytes = bp.total;
+    PlanePlan pp;                                       // small batches take the fp16-plane sweep (knn_plane_sweep)
+    if (make_plane_plan(N, D, nq, k, &pp) && pp.total > *bytes) *bytes = pp.total;
     return AC_OK;
 }
 
@@ -1568,6 +1924,14 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     AC_REQUIRE(ldQ >= D && ldP >= bp.Dp && (ldP % 4) == 0 && (((uintptr_t)d_P) & 15) == 0, AC_EINVAL, "knn batch: bad leading dimension / alignment");
     AC_REQUIRE(d_ws && ws_bytes >= bp.total, AC_EWORKSPACE, "knn batch: workspace %zu < required %zu", ws_bytes, bp.total);
     char* ws = (char*)d_ws;
+    {   // <= 64 queries: bandwidth-bound, ONE pass over the fp16 plane with the query tile resident (knn_plane_sweep)
+        PlanePlan pp;
+        if (make_plane_plan(N, D, nq, k, &pp)) {
+            AC_REQUIRE(ws_bytes >= pp.total, AC_EWORKSPACE, "knn batch: workspace %zu < required %zu", ws_bytes, pp.total);
+            return plane_search(pp, d_P, N, ldP, D, d_planes, d_norms, d_Q, nq, ldQ, k, row_offset, d_outD, d_outD64, d_outI, ws,
+                                d_stats, stream);
+        }
+    }
     const int64_t np = (N + 255) / 256 * 256;
     const uint32_t* d_maxnorm = reinterpret_cast<const uint32_t*>(d_norms + np);
     // |v - exact| <= gamma (max|p| + |q|)^2 for the one-product fp16 sweep (knn_batch.hip; derivation at the declaration of

@@ -31,10 +31,28 @@ def kernel_resources(src):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("src,pattern", [("knn_batch.hip", "knn_batch_sweep"), ("gemm_pipe.hip", "gemm_pipe_nt"),
-                                         ("knn_l2.hip", "knn_sweep_ring")])
+                                         ("knn_l2.hip", "knn_sweep_ring"), ("knn_l2.hip", "knn_plane_sweep")])
 def test_ring_staged_kernels_do_not_spill(src, pattern):
     res = {k: v for k, v in kernel_resources(src).items() if pattern in k}
     assert res, "no %s kernels found in the listing" % pattern
     spilled = {k: v for k, v in res.items() if v[0] != 0}
     assert not spilled, "kernels with scratch (scratch bytes, vgprs): %r" % spilled
     assert all(v[1] <= 512 for v in res.values())
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_streaming_sweeps_keep_their_prefetch_queue():
+    """The two bandwidth-bound sweeps wait on COUNTED vmcnt values in their k-loops.  A flat load there (a volatile access to
+    LDS through a generic pointer compiles to one) counts on vmcnt as well and forces s_waitcnt vmcnt(0) -- the whole prefetch
+    queue -- once per row tile: the listing of these kernels must hold no flat memory instruction at all."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-S",
+                               "--cuda-device-only", os.path.join(CSRC, "knn_l2.hip"), "-o", out], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    seen = 0
+    for m in re.finditer(r"^(_ZN\S*(knn_sweep_ring|knn_plane_sweep)\S*):[^\n]*\n(.*?)\.Lfunc_end", text, re.S | re.M):
+        seen += 1
+        body = m.group(3)
+        assert "flat_load" not in body and "flat_store" not in body and "flat_atomic" not in body, m.group(1)
+    assert seen >= 4

@@ -1,6 +1,7 @@
-"""The batched (prepared-store, GEMM-form bf16x2 proposal) kNN path -- ac_knn_prepare_store + ac_knn_l2_topk_batch --
-against the exact oracle and against the fp32 sweep path: same contract, ids bit-exact, distances = exact fp64 rounded
-once (1 ulp across summation orders).  The proposal arithmetic differs (bf16 split products), the answer may not."""
+"""The prepared-store kNN paths -- ac_knn_prepare_store + ac_knn_l2_topk_batch: the GEMM-form fp16 proposal sweep (>= 64
+queries) and the bandwidth-bound fp16-plane sweep (knn_plane_sweep, 1 .. 63 queries) -- against the exact oracle and against
+the fp32 sweep path: same contract, ids bit-exact, distances = exact fp64 rounded once (1 ulp across summation orders).
+The proposal arithmetic differs (one fp16 product), the answer may not."""
 import numpy as np
 import pytest
 import torch
@@ -37,6 +38,7 @@ def _run(Ph, Qh, k, dev, row_offset=0):
     torch.cuda.synchronize()
     assert torch.equal(Ib, Is) and torch.equal(Db, Ds)
     assert torch.equal(ex.float(), Db)
+    _run.form = int(st[1].item())                  # 2 = the fp16-plane sweep (knn_plane_sweep) ran
     return Db.cpu().numpy(), Ib.cpu().numpy(), int(st[0].item())
 
 
@@ -121,3 +123,91 @@ def test_index_uses_the_batched_path_and_invalidates_on_change(cuda_dev, request
     assert np.array_equal(i, c_oracle.knn_l2_topk_batch(X2, Q, 5)[1])
     d1, i1 = idx.search(Q[:8], 5)                                      # few queries: the fp32 sweep path, same answer
     assert np.array_equal(i1, i[:8]) and np.array_equal(d1, d[:8])
+
+
+# ---------------------------------------------------------------------------------------------- knn_plane_sweep (1 .. 63 queries)
+@pytest.mark.parametrize("N,D,nq,k", [
+    (70_001, 768, 1, 16),          # one query, ragged last row tile
+    (70_001, 768, 16, 32),
+    (131_072, 768, 32, 32),        # a full 32-column tile, exact tile multiples
+    (100_003, 768, 33, 32),        # 64-column tile, one column past the first sub-tile
+    (90_000, 768, 48, 32),
+    (65_536, 768, 63, 8),          # the smallest store, the most queries
+    (70_001, 1024, 40, 32),        # e5-large width: the query tile fits LDS only 32 columns at a time -> two passes
+    (70_001, 100, 17, 8),          # D % 16 != 0 (zero-padded k-slots)
+    (80_000, 64, 63, 100),         # the largest k (k' = 124 candidates per list)
+    (66_000, 770, 5, 1),           # D % 4 != 0, k = 1
+])
+def test_plane_sweep_matches_oracle(N, D, nq, k, cuda_dev):
+    from oracle import c_oracle, synth
+    Ph = synth.synth_unit_rows(N, D, 1)
+    Qh = synth.synth_unit_rows(nq, D, 2)
+    d, i, nfb = _run(Ph, Qh, k, cuda_dev, row_offset=11)
+    assert _run.form == 2, "the fp16-plane sweep did not run"
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, k, row_offset=11)
+    assert np.array_equal(i, oI), f"{(i != oI).sum()} id mismatches"
+    assert _ulp_close(d, oD)
+    assert nfb <= 1                                                   # uniform synthetic rows: the certificate holds
+
+
+def test_plane_sweep_unnormalised_near_ties_duplicates_and_clusters(cuda_dev):
+    """The hard stores of the batched path's tests, with few queries: rows far from unit norm; a store full of fp32-
+    unresolvable near-ties and exact duplicates; one tight cluster (every row is a candidate: the lists are pruned over and
+    over, the certificate fails, the exact fallback answers)."""
+    from oracle import c_oracle, synth
+    rng = np.random.default_rng(5)
+    Ph = (rng.standard_normal((80_000, 256)) * 3 + 0.5).astype(np.float32)
+    Qh = (rng.standard_normal((20, 256)) * 0.3).astype(np.float32)
+    d, i, _ = _run(Ph, Qh, 10, cuda_dev)
+    assert _run.form == 2
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, 10)
+    assert np.array_equal(i, oI) and _ulp_close(d, oD)
+
+    D, k = 768, 16
+    Ph, centres = near_tie_store(90_000, D, 7)
+    Ph[50_000:50_300] = Ph[100:400]                                    # exact duplicates of earlier rows
+    Qh = np.concatenate([(centres[:30] + synth.synth_unit_rows(30, D, 8) * 1e-3), Ph[100:124]]).astype(np.float32)
+    d, i, nfb = _run(Ph, Qh, k, cuda_dev)
+    assert _run.form == 2
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, k)
+    assert np.array_equal(i, oI) and _ulp_close(d, oD)
+    print("near-tie store, fp16-plane sweep: exact-fallback queries =", nfb)
+
+    D, k, N = 128, 8, 70_000
+    c = synth.synth_unit_rows(1, D, 3)
+    rng = np.random.default_rng(1)
+    Ph = (c + rng.standard_normal((N, D)).astype(np.float32) * 1e-4).astype(np.float32)
+    Qh = (c + rng.standard_normal((40, D)).astype(np.float32) * 1e-4).astype(np.float32)
+    d, i, nfb = _run(Ph, Qh, k, cuda_dev)
+    assert _run.form == 2
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, k)
+    assert np.array_equal(i, oI) and _ulp_close(d, oD)
+    assert nfb == 40
+
+
+def test_index_prepares_for_small_batches_from_the_second_search_on(cuda_dev, request):
+    """HipFlatL2Index: a big store's first few-query search runs the fp32 sweep (no preparation cost), the following ones the
+    fp16-plane sweep; a row change drops the plane again.  Same answers throughout."""
+    from adaptive_classifier import index as ixm
+    from adaptive_classifier.index import HipFlatL2Index
+    from oracle import c_oracle, synth
+    D = 64
+    X = synth.synth_unit_rows(70_000, D, 11)
+    Q = synth.synth_unit_rows(9, D, 12)
+    old = ixm.PLANE_MIN_ROWS
+    ixm.PLANE_MIN_ROWS = 65_536                                        # (the auto heuristic keeps stores this small on the fp32 sweep)
+    request.addfinalizer(lambda: setattr(ixm, "PLANE_MIN_ROWS", old))
+    idx = HipFlatL2Index(D, device=cuda_dev)
+    idx.add(X)
+    want = c_oracle.knn_l2_topk_batch(X, Q, 5)[1]
+    d0, i0 = idx.search(Q, 5)
+    assert idx._prepared is None and np.array_equal(i0, want)
+    d1, i1 = idx.search(Q, 5)
+    assert idx._prepared is not None and int(idx._stats[1].item()) == 2
+    assert np.array_equal(i1, want) and np.array_equal(d1, d0)
+    idx.update_rows([3], Q[:1])
+    assert idx._prepared is None
+    d2, i2 = idx.search(Q, 5)
+    assert idx._prepared is None and i2[0, 0] == 3 and d2[0, 0] == 0.0
+    d3, i3 = idx.search(Q, 5)
+    assert idx._prepared is not None and np.array_equal(i3, i2) and np.array_equal(d3, d2)
