@@ -103,43 +103,73 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
     return base + s;
 }
 
-// Wave-level prune of one candidate list: keep the kp smallest by (d, id), written back in
-// ascending order; update cnt and tau.  n <= cap <= 512.
+// Wave-level prune of one candidate list: keep the kp smallest by (d, id), compacted to the front (in no particular order --
+// nothing downstream reads the lists as sorted: the merge radix-selects over all of them); update cnt and tau.  n <= cap <= 512.
+// Round 4: a radix SELECT over the monotone keys (32 ballots per register slot) instead of rank-by-counting (n dependent
+// LDS broadcast reads: ~3 us for a 112-entry list, most of what a sweep with many resident queries spent outside its k-loop).
 template <int MAXPER>
 __device__ __forceinline__ void prune_list(float* ld, int32_t* li, int* cnt_p, float* tau_p,
                                            int cap, int kp, int lane) {
     int n = *cnt_p;
     if (n > cap) n = cap;
-    float myd[MAXPER];
+    if (n <= kp) {                                    // nothing to drop (final prune of a short list)
+        if (lane == 0) *cnt_p = n;
+        return;
+    }
+    uint32_t key[MAXPER];
     int32_t myi[MAXPER];
-    int rank[MAXPER];
 #pragma unroll
     for (int e = 0; e < MAXPER; ++e) {
         const int s = lane + 64 * e;
         const bool v = s < n;
-        myd[e] = v ? ld[s] : INFINITY;
+        key[e] = v ? fkey(ld[s]) : 0xffffffffu;       // (a real key is never 0xffffffff: that would be a NaN)
         myi[e] = v ? li[s] : 0x7fffffff;
-        rank[e] = 0;
     }
-    for (int s = 0; s < n; ++s) {
-        const float d = ld[s];        // wave-uniform address: LDS broadcast
-        const int32_t i = li[s];
+    // T = the kp-th smallest key: fix its bits from the top; `want` = its rank among the entries that share the bits fixed so far
+    uint32_t T = 0;
+    int want = kp;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t hi = bit == 31 ? 0u : ~((2u << bit) - 1u);
+        int c0 = 0;
 #pragma unroll
         for (int e = 0; e < MAXPER; ++e)
-            rank[e] += (d < myd[e] || (d == myd[e] && i < myi[e])) ? 1 : 0;
+            c0 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[e] != 0xffffffffu && (key[e] & hi) == T && !((key[e] >> bit) & 1u)));
+        if (want > c0) { want -= c0; T |= 1u << bit; }
     }
-    // all reads above are complete for the whole wave before any lane writes (lockstep)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // entries below T stay, entries equal to T: the `want` lowest ids of them (ids are unique)
+    int c_eq = 0;
 #pragma unroll
-    for (int e = 0; e < MAXPER; ++e) {
-        const int s = lane + 64 * e;
-        if (s < n && rank[e] < kp) {
-            ld[rank[e]] = myd[e];
-            li[rank[e]] = myi[e];
-            if (rank[e] == kp - 1) *tau_p = myd[e];
+    for (int e = 0; e < MAXPER; ++e) c_eq += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[e] == T));
+    uint32_t idT = 0xffffffffu;
+    if (c_eq > want) {                                // (wave-uniform, rare: several candidates share the boundary value)
+        idT = 0;
+        int w2 = want;
+#pragma unroll 1
+        for (int bit = 30; bit >= 0; --bit) {         // ids are non-negative 31-bit numbers
+            const uint32_t hi = ~((2u << bit) - 1u);
+            int c0 = 0;
+#pragma unroll
+            for (int e = 0; e < MAXPER; ++e)
+                c0 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[e] == T && ((uint32_t)myi[e] & hi) == idT && !(((uint32_t)myi[e] >> bit) & 1u)));
+            if (w2 > c0) { w2 -= c0; idT |= 1u << bit; }
         }
     }
-    if (lane == 0) *cnt_p = n < kp ? n : kp;
+    // all reads above are complete for the whole wave before any lane writes (the entries sit in registers)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < MAXPER; ++e) {
+        const bool keep = key[e] < T || (key[e] == T && (uint32_t)myi[e] <= idT);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) {
+            const int pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            ld[pos] = fkey_inv(key[e]);
+            li[pos] = myi[e];
+        }
+        base += __builtin_popcountll(m);
+    }
+    if (lane == 0) { *cnt_p = kp; *tau_p = fkey_inv(T); }
 }
 
 __device__ __forceinline__ void prune_dispatch(float* ld, int32_t* li, int* cnt_p, float* tau_p,
