@@ -175,13 +175,14 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); e1.record(); torch.cuda.synchronize()          # materialise the hipEvent handles
 
-    def measure(nq, reps):
+    def measure(nq, reps, prepared=None):
         Q = ix.synth_unit_rows(nq, DIM, 2, device=dev)
-        ws = torch.empty(ix.knn_workspace_bytes(n_rows, DIM, nq, k), dtype=torch.uint8, device=dev)
+        ws = torch.empty(max(ix.knn_workspace_bytes(n_rows, DIM, nq, k), 0 if prepared is None else ix.knn_batch_workspace_bytes(n_rows, DIM, nq, k)),
+                         dtype=torch.uint8, device=dev)
         stats = torch.zeros(4, dtype=torch.int32, device=dev)
         out = (torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev))
         for _ in range(2):
-            ix.knn_l2_topk(P, n_rows, DIM, Q, k, out=out, workspace=ws, stats=stats)
+            ix.knn_l2_topk(P, n_rows, DIM, Q, k, out=out, workspace=ws, stats=stats, prepared=prepared)
         torch.cuda.synchronize()
         times, calls = [], []
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -189,21 +190,24 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
         try:
             for _ in range(reps):
                 c0.record()
-                ix.knn_l2_topk(P, n_rows, DIM, Q, k, out=out, workspace=ws, stats=stats)
+                ix.knn_l2_topk(P, n_rows, DIM, Q, k, out=out, workspace=ws, stats=stats, prepared=prepared)
                 c1.record()
                 torch.cuda.synchronize()
                 times.append(e0.elapsed_time(e1))
                 calls.append(c0.elapsed_time(c1))
         finally:
             nv.lib().ac_knn_set_profile_events(None, None)
-        if nq == 16:
-            keep["ids16"] = out[1].clone()
-        if nq == 16 and parity:
+        if prepared is not None:
+            keep["plane_ids"] = out[1].clone()
+            keep["plane_form"] = int(stats[1].item())
+        elif nq in (16, 32):
+            keep["ids%d" % nq] = out[1].clone()
+        if nq == 16 and parity and prepared is None:
             par["v"] = sweep_parity(P, n_rows, Q, out[1], k)
         return float(np.mean(times)), float(np.min(times)), float(np.mean(calls)), int(stats[0].item())
 
     par = {"v": None}
-    keep = {"ids16": None}
+    keep = {"ids16": None, "ids32": None}
     ms, ms_min, call_ms, nfb = measure(16, 8)
     table = {}
     for nq in ((1, 8, 16, 32) if full else (16,)):
@@ -211,7 +215,8 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
         table[str(nq)] = {"kernel_ms": t, "GBps": bytes_alg / t / 1e6, "frac": bytes_alg / t / 1e6 / HBM_PEAK_GBS,
                           "whole_call_ms": c}
     # BASELINE configs[2] on this one GPU: 4096 queries x the whole store, k = 32 (compute-bound regime, whole call)
-    batch = None
+    import glob
+    batch = plane = None
     out16_ids = keep["ids16"]           # ids of the 16 roofline queries (= the first 16 of the 4096-query batch, same seed)
     if full:
         nqb = 4096
@@ -233,11 +238,35 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
                  "ms_per_batch": bms, "queries_per_s": nqb / bms * 1e3, "TFLOPs_fp32_equiv": 2.0 * nqb * n_rows * DIM / bms / 1e9,
                  "exact_fallback_queries": int(stb[0].item()),
                  "ids_equal_fp32_sweep_subset": bool(torch.equal(outb[1][:16], out16_ids)) if out16_ids is not None else None}
-        del Qb, wsb, outb, prep
+        del Qb, wsb, outb
+        # the same store's fp16 plane swept ONCE for 1 .. 64 resident queries (knn_plane_sweep, round 4): its own entry, priced on
+        # ITS algorithmic bytes N * D * 2 -- never against the fp32 sweep's N * D * 4
+        plane_bytes = n_rows * DIM * 2
+        ptab, ids_ok = {}, None
+        for nq in (1, 16, 32, 48, 64):
+            t, tmin, c, fb = measure(nq, 4, prepared=prep)
+            ptab[str(nq)] = {"kernel_ms": t, "GBps": plane_bytes / t / 1e6, "frac": plane_bytes / t / 1e6 / HBM_PEAK_GBS, "whole_call_ms": c,
+                             "exact_fallback_queries": fb, "form": keep["plane_form"]}
+            if nq in (16, 32) and keep["ids%d" % nq] is not None:
+                same = bool(torch.equal(keep["plane_ids"], keep["ids%d" % nq]))
+                ids_ok = same if ids_ok is None else (ids_ok and same)
+        t16 = ptab["16"]["kernel_ms"]
+        plane = {"bound": "hbm", "achieved": plane_bytes / t16 / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": plane_bytes / t16 / 1e6 / HBM_PEAK_GBS,
+                 "traffic": None, "kernel": "knn_plane_sweep (prepared store: tile-major fp16 plane by non-temporal whole-line loads straight into "
+                                            "MFMA fragments, query tile resident in LDS; exact result through the fp64 re-rank + certificate)",
+                 "rows": n_rows, "dim": DIM, "resident_queries": 16, "algorithmic_bytes_per_launch": plane_bytes,
+                 "note": "bytes = N * D * 2 (the fp16 plane; + 4 B of |p|^2 per row = 0.26 %%); the fp32 rows are read only for the k' re-ranked "
+                         "candidates per query.  Speed-up of the sweep over the fp32 form at 16 queries: %.2fx" % (ms / t16),
+                 "avg_kernel_ms": t16, "by_resident_queries": ptab, "ids_equal_fp32_sweep": ids_ok}
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "knn_plane_sweep_pmc.json"))):
+            pj = json.load(open(f))
+            if pj.get("rows") == n_rows and pj.get("dim") == DIM:
+                plane["traffic"] = pj["hbm_read_bytes_per_launch_corrected"] + pj["hbm_write_bytes_per_launch"]
+                plane["traffic_source"] = os.path.relpath(f, ROOT)
+        del prep
     # HBM traffic per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 gfx950 correction,
     # profiles/<round>/knn_sweep_pmc.json); null when no pass exists for this problem size.
     traffic, traffic_src = None, None
-    import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "knn_sweep_pmc.json"))):
         pj = json.load(open(f))
         if pj.get("rows") == n_rows and pj.get("dim") == DIM:
@@ -251,7 +280,7 @@ def sweep_roofline(dev, n_rows, full=True, parity=False):
                       "fragments in registers; knn_sweep<1> with AC_KNN_RING=0)", "rows": n_rows, "dim": DIM, "resident_queries": 16,
             "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": ms, "min_kernel_ms": ms_min,
             "whole_call_ms": call_ms, "exact_fallback_queries": nfb, "parity": par["v"], "by_resident_queries": table,
-            "batch4096": batch}
+            "batch4096": batch, "fp16_plane": plane}
 
 
 def cpu_baseline(hf, clf, rows_dev, sample=2048, chunk=64):
@@ -911,6 +940,7 @@ def main():
         while n_rows * DIM * 4 > 0.8 * free and n_rows > 100_000:
             n_rows //= 2
         line["roofline"] = sweep_roofline(dev, n_rows, parity=not args.no_parity)
+        line["roofline_fp16_plane"] = line["roofline"].pop("fp16_plane")
     if not args.no_parity:
         line["parity"] = step_parity(clf, hf, ids, types, mask)
     if not args.no_cpu_baseline:

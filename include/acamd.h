@@ -100,14 +100,18 @@ int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
                      ac_stream_t stream);
 
 /*
- * Batched search over a PREPARED store (many queries: predict_batch, BASELINE configs[2] / [4]).  Same result
- * contract as ac_knn_l2_topk_x -- the ids are the exact top-k, bit for bit -- but the proposal sweep runs as a
- * GEMM on the matrix pipe over ONE fp16 plane per operand (one v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block;
- * knn_batch.hip) and only the re-rank / certificate / fallback stay in fp64.
+ * Search over a PREPARED store (BASELINE configs[2] / [4], predict_batch; replaces the same faiss call, memory.py:114).  Same
+ * result contract as ac_knn_l2_topk_x -- the ids are the exact top-k, bit for bit -- but candidates are PROPOSED from ONE fp16
+ * plane per operand (one v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block) and only the re-rank / certificate / fallback stay in
+ * fp64:
+ *   nq <= 64   knn_plane_sweep (knn_l2.hip): ONE bandwidth-bound pass over the store's plane (2 B per element: half the bytes of
+ *              the fp32 sweep) with the query tile resident in LDS; d_stats[1] = 2 reports that it ran;
+ *   nq  > 64   knn_batch_sweep (knn_batch.hip): a GEMM on the matrix pipe, thresholds from strided samples.
  *   ac_knn_store_bytes       sizes of the two auxiliary buffers of a store of N rows
- *   ac_knn_prepare_store     fills them from the fp32 rows: d_planes = fp16(p 2^-e_p), k-slot-major [K/8][rows][8] with
- *                            rows padded to 256 and K to 64, 2^e_p > max |p|; d_norms = |p|^2 per row, +inf on the
- *                            padding rows, the maximum at [round_up(N, 256)].  Redo after any row changes.
+ *   ac_knn_prepare_store     fills them from the fp32 rows: d_planes = fp16(p 2^-e_p), 2^e_p > max |p|, TILE-MAJOR
+ *                            [rows / 256][K / 8][256][8] (rows padded to 256, K to 64: a 256-row tile is one contiguous run,
+ *                            k-slot-major inside; an opaque layout -- only these entry points read it); d_norms = |p|^2 per
+ *                            row, +inf on the padding rows, the maximum at [round_up(N, 256)].  Redo after any row changes.
  *   ac_knn_l2_topk_batch     N >= 65536, k <= 100 (AC_EUNSUPPORTED otherwise: use ac_knn_l2_topk_x); d_stats as above
  * Error bound of the proposal value v = |p|^2 - 2 p.q used by the filter and the certificate (unit = (max|p| + |q|)^2):
  *   operands scaled into the unit ball (p^ = p 2^-e_p, q^ = q 2^-e_q, per-query e_q) and rounded to nearest fp16:

@@ -117,8 +117,9 @@ def test_cfg2_10M_k32_nq4096_subset_and_properties(cuda_dev):
     Dm, Im = ix.topk_merge(torch.stack([D0, D1]), torch.stack([I0, I1]))
     assert torch.equal(Im, Id) and torch.equal(Dm, Dd)
     del D0, I0, D1, I1, Dm, Im
-    # 64-query subset (every 64th query: one per pair of 32-query tiles) vs the chunked exact oracle
-    sel = np.arange(0, nq, 64)
+    # 64-query subset (every 64th query: one per pair of 32-query tiles) + the first 48 queries (what the small-batch forms
+    # below answer) vs the chunked exact oracle
+    sel = np.unique(np.concatenate([np.arange(0, nq, 64), np.arange(48)]))
     Qh = Q[:, :D].cpu().numpy()[sel]
     oD, oI = c_oracle.knn_l2_topk_chunked(_device_chunks(P, N, D), Qh, k)
     assert np.array_equal(i[sel], oI), f"{(i[sel] != oI).sum()} id mismatches"
@@ -132,6 +133,14 @@ def test_cfg2_10M_k32_nq4096_subset_and_properties(cuda_dev):
     Db, Ib = ix.knn_l2_topk(P, N, D, Q, k, stats=stb, prepared=prep)
     assert torch.equal(Ib, Id) and torch.equal(Db, Dd)
     print("cfg2 batched path: exact-fallback queries =", int(stb[0].item()))
+    # ... and the bandwidth-bound fp16-plane sweep (knn_plane_sweep) for 1 / 16 / 32 / 48 resident queries: the oracle's ids,
+    # no fallback query on the benchmark data
+    for m in (1, 16, 32, 48):
+        stp = torch.zeros(4, dtype=torch.int32, device=cuda_dev)
+        Dp, Ip = ix.knn_l2_topk(P, N, D, Q[:m], k, stats=stp, prepared=prep)
+        assert stp.tolist()[:2] == [0, 2], stp.tolist()                  # [fallback queries, form = 2: the plane sweep ran]
+        assert torch.equal(Ip, Id[:m]) and torch.equal(Dp, Dd[:m])
+        assert np.array_equal(Ip.cpu().numpy(), oI[np.searchsorted(sel, np.arange(m))])
 
 
 def test_cfg4_2M_x1024_k32_nq1024_subset(cuda_dev):
@@ -149,5 +158,11 @@ def test_cfg4_2M_x1024_k32_nq1024_subset(cuda_dev):
     oD, oI = c_oracle.knn_l2_topk_chunked(_device_chunks(P, N, D, rows=500_000), Qh, k)
     assert np.array_equal(i[sel], oI), f"{(i[sel] != oI).sum()} id mismatches"
     assert _ulp_close(d[sel], oD)
-    Db, Ib = ix.knn_l2_topk(P, N, D, Q, k, prepared=ix.prepare_store(P, N, D))          # the batched path: identical
+    prep = ix.prepare_store(P, N, D)
+    Db, Ib = ix.knn_l2_topk(P, N, D, Q, k, prepared=prep)          # the batched path: identical
     assert torch.equal(Ib, Id) and torch.equal(Db, Dd)
+    for m in (1, 16, 40):                                          # the fp16-plane sweep (40 queries: two 32-column passes at D = 1024)
+        stp = torch.zeros(4, dtype=torch.int32, device=cuda_dev)
+        Dp, Ip = ix.knn_l2_topk(P, N, D, Q[:m], k, stats=stp, prepared=prep)
+        assert stp.tolist()[:2] == [0, 2], stp.tolist()
+        assert torch.equal(Ip, Id[:m]) and torch.equal(Dp, Dd[:m])
