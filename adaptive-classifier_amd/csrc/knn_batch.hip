@@ -138,7 +138,9 @@ __global__ __launch_bounds__(64) void knn_thr_kernel(const double* __restrict__ 
         const double tau = tauD[(size_t)q * kp + kp - 1];
         float t = (float)(tau - a + E);
         if ((double)t < tau - a + E) t = nextafterf(t, INFINITY);
-        thr[q] = isfinite(tau) ? t : INFINITY;
+        // a stage that kept fewer than k' rows for this query has no k'-th distance to offer: the threshold of the stage
+        // before it (still a valid bound) stays; a valid new bound only ever tightens it
+        if (isfinite(tau) && t < thr[q]) thr[q] = t;
     }
 }
 

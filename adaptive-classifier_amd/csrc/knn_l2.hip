@@ -1738,7 +1738,16 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     // are, up to rare collisions, the sample's k' best, so tau_A is as tight as an exact search of the sample would make it
     const int64_t rows_a = 128 * (int64_t)bp->kp > 4096 ? 128 * (int64_t)bp->kp : 4096;
     int64_t stride_a = (N + rows_a - 1) / rows_a, stride = stride_a;
-    if (stride > smax) stride = smax;                  // stage B's (or, for small stores, stage A's own) stride
+    if (stride > smax) {                               // stage B's (or, for small stores, stage A's own) stride
+        // Stage B keeps the sample rows within tau_A and needs k' of them: k' S_B / S_A are expected, so its sample must be a few
+        // times stage A's.  (Round 3 used smax whatever stride_a was: at 0.92 - 1.5 M rows -- stride_a just above smax, e.g. a
+        // 10M-row store sharded 8 ways -- that is k' x 1.1 .. 1.4 expected candidates, a good share of the queries came out of
+        // stage B with fewer than k', lost their threshold, overflowed their candidate buffer in the main sweep and took the
+        // exact fallback: 1.3 s instead of 8 ms per 4096-query batch at 1M rows.)
+        stride = smax;
+        if (stride > stride_a / 3) stride = stride_a / 3;
+        if (stride < 1) stride = 1;
+    }
     bp->stride_a = stride_a;
     bp->stride = stride;
     bp->S = ac::knn_sample_rows(N, stride_a);            // rows of the stage-A sample

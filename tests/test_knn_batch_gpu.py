@@ -125,6 +125,22 @@ def test_index_uses_the_batched_path_and_invalidates_on_change(cuda_dev, request
     assert np.array_equal(i1, i[:8]) and np.array_equal(d1, d[:8])
 
 
+def test_batched_path_two_threshold_stages_of_similar_size(cuda_dev):
+    """Stores of ~0.92 - 1.5 M rows (a 10M-row store sharded 8 ways) are where the second threshold stage starts: its sample
+    must be a few times the first stage's, or a share of the queries leaves it with fewer than k' rows, loses its threshold,
+    overflows its candidate buffer and takes the exact fallback (round 3: 211 of 4096 queries at 1M rows, 1.3 s per batch)."""
+    from adaptive_classifier import index as ix
+    N, D, nq, k = 1_000_000, 64, 768, 32
+    P = ix.synth_unit_rows(N, D, 1, device=cuda_dev)
+    Q = ix.synth_unit_rows(nq, D, 2, device=cuda_dev)
+    prep = ix.prepare_store(P, N, D)
+    st = torch.zeros(4, dtype=torch.int32, device=cuda_dev)
+    Db, Ib = ix.knn_l2_topk(P, N, D, Q, k, stats=st, prepared=prep)
+    Ds, Is = ix.knn_l2_topk(P, N, D, Q, k)                                 # the fp32 sweep path (oracle-checked elsewhere)
+    assert torch.equal(Ib, Is) and torch.equal(Db, Ds)
+    assert int(st[0].item()) <= 1, "exact-fallback queries: %d" % int(st[0].item())
+
+
 # ---------------------------------------------------------------------------------------------- knn_plane_sweep (1 .. 63 queries)
 @pytest.mark.parametrize("N,D,nq,k", [
     (70_001, 768, 1, 16),          # one query, ragged last row tile
