@@ -418,8 +418,12 @@ class PrototypeMemory:
                 self.index.update_rows(rows, vals)
             self._dirty.clear()
 
-    def load_rows(self, rows: torch.Tensor, row_labels: torch.Tensor, label_names: List[str], sharded=None):
+    def load_rows(self, rows: torch.Tensor, row_labels: torch.Tensor, label_names: List[str], sharded=None,
+                  prepare: bool = False):
         """Generalised store: arbitrary device rows + int32 row->class map behind the same search.
+        prepare=True builds the store's fp16 plane + row norms now (`index.prepare_store`: two passes over the rows, 2 B per
+        element) instead of at the first many-query / second few-query search, so that every search of a static store --
+        the first included -- proposes from the plane (half the bytes of the fp32 sweep).
 
         With `sharded` (adaptive_classifier.sharded.ShardedSearch) `rows` is this rank's row shard and
         `row_labels` the GLOBAL (replicated) row->class map; search_batch() then all-gathers the ranks'
@@ -432,6 +436,11 @@ class PrototypeMemory:
         self._row_class_cache = None
         self.updates_since_rebuild = 0
         self._dirty.clear()
+        if prepare and sharded is None:
+            from .index import BATCH_MIN_ROWS, prepare_store
+            if self.index.ntotal >= BATCH_MIN_ROWS:
+                self.index._prepared = prepare_store(self.index._store, self.index.ntotal, self.index.d)
+                self.index._searches_since_change = 1
 
     # ------------------------------------------------------------------ search
     def get_nearest_prototypes(self, query_embedding: torch.Tensor, k: int = 5,

@@ -227,3 +227,21 @@ def test_index_prepares_for_small_batches_from_the_second_search_on(cuda_dev, re
     assert idx._prepared is None and i2[0, 0] == 3 and d2[0, 0] == 0.0
     d3, i3 = idx.search(Q, 5)
     assert idx._prepared is not None and np.array_equal(i3, i2) and np.array_equal(d3, d2)
+
+
+def test_load_rows_prepare_makes_the_first_small_search_use_the_plane(cuda_dev, request):
+    from adaptive_classifier import PrototypeMemory, index as ixm
+    from oracle import c_oracle, synth
+    old = ixm.PLANE_MIN_ROWS
+    ixm.PLANE_MIN_ROWS = 65_536
+    request.addfinalizer(lambda: setattr(ixm, "PLANE_MIN_ROWS", old))
+    D, N = 64, 70_000
+    X = synth.synth_unit_rows(N, D, 21)
+    Q = synth.synth_unit_rows(5, D, 22)
+    mem = PrototypeMemory(D, device=cuda_dev)
+    mem.load_rows(ixm.synth_unit_rows(N, D, 21, device=cuda_dev), torch.arange(N, dtype=torch.int32) % 3, ["a", "b", "c"], prepare=True)
+    assert mem.index._prepared is not None
+    S, I, Dd = mem.search_batch(torch.from_numpy(Q).to(cuda_dev), 7)
+    assert int(mem.index._stats[1].item()) == 2                        # the very first search ran the fp16-plane sweep
+    assert np.array_equal(I.cpu().numpy(), c_oracle.knn_l2_topk_batch(X, Q, 7)[1])
+    assert abs(float(S.sum(dim=1).mean()) - 1.0) < 1e-5
