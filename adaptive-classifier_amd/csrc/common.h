@@ -122,13 +122,12 @@ double knn_batch_gamma(int D);                     // |sweep value - exact| <= g
 int knn_prepare_store(const float* X, int64_t ldx, int64_t rows, int D, uint16_t* plane, float* norms, uint32_t* maxnorm_bits,
                       hipStream_t stream);
 int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t ldQ, int D, int nq, const uint32_t* maxnorm_bits,
-                        double gamma, uint16_t* qplane, float* thr, float* qfac, hipStream_t stream);
-int knn_thresholds(const double* tauD, int kp, const float* Q, int64_t ldQ, int D, int nq, const uint32_t* maxnorm_bits, double gamma,
-                   float* thr, hipStream_t stream);
+                        double gamma, uint16_t* qplane, float* thr, float* qfac, hipStream_t stream, int32_t* zero_ints = nullptr,
+                        int64_t zero_count = 0);             // zero_ints: device ints the same launch clears (the candidate counters)
 int64_t knn_sample_rows(int64_t N, int64_t stride);
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
                      const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int segs, int64_t row_stride,
-                     int best_only, hipStream_t stream);
+                     int best_only, hipStream_t stream, int32_t* clear_ctr = nullptr, int32_t* clear_stats = nullptr);
 
 // arithmetic of the LDS-tiled GEMMs (ac_gemm_set_arith / env AC_GEMM_ARITH = f32 | bf16x3)
 int gemm_arith();

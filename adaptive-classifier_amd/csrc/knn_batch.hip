@@ -78,7 +78,10 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
                                                         int D, int Kp, const uint32_t* __restrict__ maxnorm_bits, int per_row_scale,
                                                         uint16_t* __restrict__ plane, const double* __restrict__ sampleD, int kp,
                                                         double gamma, float* __restrict__ thr, float* __restrict__ qfac,
-                                                        float* __restrict__ pad_norms, int tile_major) {
+                                                        float* __restrict__ pad_norms, int tile_major,
+                                                        int32_t* __restrict__ zero_a, int64_t zero_na) {
+    // (query form) the counters the following launches append to start at zero: done here instead of by a memset launch
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < zero_na; i += (int64_t)gridDim.x * 256) zero_a[i] = 0;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows_pad) return;
@@ -122,28 +125,6 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
     }
 }
 
-// thr[q] from a new tau_q = tauD[q][kp - 1] (an exact distance that at least kp store rows do not exceed)
-__global__ __launch_bounds__(64) void knn_thr_kernel(const double* __restrict__ tauD, int kp, const float* __restrict__ Q, int64_t ldQ,
-                                                     int D, int nq, const uint32_t* __restrict__ maxnorm_bits, double gamma,
-                                                     float* __restrict__ thr) {
-    const int q = blockIdx.x, lane = threadIdx.x;
-    if (q >= nq) return;
-    double a = 0.0;
-    for (int c = lane; c < D; c += 64) { const double x = Q[(size_t)q * ldQ + c]; a = fma(x, x, a); }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o);
-    if (lane == 0) {
-        const double pmax = sqrt((double)__uint_as_float(*maxnorm_bits) * 1.001), qn = sqrt(a);
-        const double E = gamma * (pmax + qn) * (pmax + qn) + 1e-30;
-        const double tau = tauD[(size_t)q * kp + kp - 1];
-        float t = (float)(tau - a + E);
-        if ((double)t < tau - a + E) t = nextafterf(t, INFINITY);
-        // a stage that kept fewer than k' rows for this query has no k'-th distance to offer: the threshold of the stage
-        // before it (still a valid bound) stays; a valid new bound only ever tightens it
-        if (isfinite(tau) && t < thr[q]) thr[q] = t;
-    }
-}
-
 struct BatchParams {
     const uint16_t* Pp; int64_t p_rows;      // store plane [p_rows / 256][Kp/8][256][8] fp16 (tile-major)
     const float* pnorm;                      // [p_rows]: |p|^2, +inf past N
@@ -161,6 +142,8 @@ struct BatchParams {
     int64_t ntiles;                          // row tiles of 256
     float* cand_d; int32_t* cand_i; int32_t* cand_cnt; int cap;
     int segs, segcap;                        // a query's list = segs segments of segcap = cap / segs entries, one counter each
+    int32_t* clear_ctr;                      // (main sweep) [64] fallback slot counter and [4] caller's d_stats, zeroed by workgroup 0 here
+    int32_t* clear_stats;                    //   instead of by two memset launches in front of the merge; NULL = leave alone
 };
 
 typedef const BatchParams __attribute__((address_space(4)))* KArgs;
@@ -185,6 +168,12 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int i32 = lane & 31, kg = lane >> 5;
+    if (blockIdx.x == 0 && tid < 64) {                              // consumed by the merge / fallback kernels launched after this one
+        KArgs ka0 = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        int32_t* const cc = ka0->clear_ctr; int32_t* const cs = ka0->clear_stats;
+        if (cc) cc[tid] = 0;
+        if (cs && tid < 4) cs[tid] = 0;
+    }
     // ---- workgroup -> (query tile, row group) ----
     const int per_xcd = (int)(gridDim.x >> 3), xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int xs = 8 / prm.sets, set = xcd % prm.sets, xr = xcd / prm.sets;
@@ -482,24 +471,18 @@ int knn_prepare_store(const float* X, int64_t ldx, int64_t rows, int D, uint16_t
     hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, X, ldx, rows, D, norms, maxnorm_bits);
     AC_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_plane_kernel, dim3((unsigned)((rp + 3) / 4)), dim3(256), 0, stream, X, ldx, rows, rp, D, Kp, maxnorm_bits, 0,
-                       plane, (const double*)nullptr, 0, 0.0, (float*)nullptr, (float*)nullptr, norms, 1);
+                       plane, (const double*)nullptr, 0, 0.0, (float*)nullptr, (float*)nullptr, norms, 1, (int32_t*)nullptr, (int64_t)0);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
 
 int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t ldQ, int D, int nq, const uint32_t* maxnorm_bits,
-                        double gamma, uint16_t* qplane, float* thr, float* qfac, hipStream_t stream) {
+                        double gamma, uint16_t* qplane, float* thr, float* qfac, hipStream_t stream, int32_t* zero_ints,
+                        int64_t zero_count) {
     const int Kp = knn_kp(D);
     const int64_t qp = ((int64_t)nq + 255) / 256 * 256;
     hipLaunchKernelGGL(knn_plane_kernel, dim3((unsigned)((qp + 3) / 4)), dim3(256), 0, stream, Q, ldQ, (int64_t)nq, qp, D, Kp,
-                       maxnorm_bits, 1, qplane, sampleD, kp, gamma, thr, qfac, (float*)nullptr, 0);
-    AC_LAUNCH_CHECK();
-    return AC_OK;
-}
-
-int knn_thresholds(const double* tauD, int kp, const float* Q, int64_t ldQ, int D, int nq, const uint32_t* maxnorm_bits, double gamma,
-                   float* thr, hipStream_t stream) {
-    hipLaunchKernelGGL(knn_thr_kernel, dim3(nq), dim3(64), 0, stream, tauD, kp, Q, ldQ, D, nq, maxnorm_bits, gamma, thr);
+                       maxnorm_bits, 1, qplane, sampleD, kp, gamma, thr, qfac, (float*)nullptr, 0, zero_ints, zero_count);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
@@ -507,7 +490,7 @@ int knn_thresholds(const double* tauD, int kp, const float* Q, int64_t ldQ, int 
 // N = rows of the prepared store, row_stride >= 1: sweep the knn_sample_rows(N, row_stride) logical rows (BatchParams::row_stride)
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
                      const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int segs, int64_t row_stride,
-                     int best_only, hipStream_t stream) {
+                     int best_only, hipStream_t stream, int32_t* clear_ctr, int32_t* clear_stats) {
     // (measured and dropped, profiles/r03/knn_batch_probe*.txt: a ring of 5 slots -- no change, the DMA depth is not the limit;
     //  2 x 2 waves of 128 x 128 with the 512-register budget, one wave per SIMD -- 120 vs 80 ms at 4096 x 10M: hipcc shuffles
     //  ~200 accumulator registers per iteration and a lone wave per SIMD hides nothing)
@@ -543,6 +526,7 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
         p.Qp = Qp + qoff * 8;                                       // plane[k/8][q_rows][8]: tile t0 starts at row t0 * 256 of every k-slot
         p.thr = thr + qoff; p.qfac = qfac + qoff;
         p.cand_d = cand_d + qoff * cap; p.cand_i = cand_i + qoff * cap; p.cand_cnt = cand_cnt + qoff * segs;
+        p.clear_ctr = t0 == 0 ? clear_ctr : nullptr; p.clear_stats = t0 == 0 ? clear_stats : nullptr;
         const dim3 grid((unsigned)nblk), block(64 * nwv);
         if (segs > 1 || p.row_stride > 1 || best_only) hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, false>), grid, block, lds, stream, p);

@@ -914,6 +914,9 @@ struct MergeParams {
     // (may exceed the segment: overflow -> exact fallback)
     const int32_t* cand_cnt;
     int cand_cap, cand_segs;
+    int32_t* cand_cnt_clear;   // (threshold stages) = cand_cnt: this query's counters are zeroed once read, for the next sweep's appends
+    float* thr_out;            // (threshold stages) thr_out[q] = min(thr_out[q], tau_q - |q|^2 + E rounded up), tau_q = the k-th (= k'-th)
+                               // exact distance of this stage -- what knn_thr_kernel computed in a launch of its own (round 3)
     int64_t run_stride;      // 0, or 8 * stride of a threshold stage's sample: candidate id i is store row (i >> 3) * run_stride + (i & 7)
     int64_t row_offset;
     const float* part_d;
@@ -1041,6 +1044,7 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
             cid[j] = pi[t];
         }
         if (tid == 0) misc[5] = nkeys;
+        if (prm.cand_cnt_clear && tid < segs) prm.cand_cnt_clear[(size_t)q * segs + tid] = 0;       // (read above, before the barriers)
     } else {
         // monotone 32-bit key of the sweep value; padding (id < 0) and slots past the count sort last
         const int raw = prm.cand_cnt ? prm.cand_cnt[q] : n;
@@ -1055,6 +1059,7 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
         }
         __syncthreads();
         atomicAdd(&misc[5], nreal_local);
+        if (prm.cand_cnt_clear && tid == 0) prm.cand_cnt_clear[q] = 0;
     }
     __syncthreads();
     const bool overflow = misc[6] != 0;
@@ -1093,24 +1098,45 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
     const unsigned long long T64 = (unsigned long long)T << 32;
 
     // ---- exact fp64 distances of the selected rows; |q|^2 ----
+    // Four rows per wave at a time: their loads are issued together, so a wave pays the (random-row, HBM) latency once per
+    // group instead of once per row -- the per-row arithmetic (four accumulators over c4 = lane, lane + 64, ..., the
+    // (a0 + a1) + (a2 + a3) fold, the xor-shuffle tree) is unchanged, hence the same bits.  (One row at a time this loop was
+    // most of the kernel: ~20 of its 27 - 32 us.)
     const int nc4 = prm.Dp >> 2;
-    for (int s = wave; s < ns; s += kMergeThreads / 64) {
-        const int32_t id = (int32_t)(uint32_t)(sel[s] & 0xffffffffull);
-        const int64_t prow_i = prm.run_stride ? (int64_t)(id >> 3) * prm.run_stride + (id & 7) : (int64_t)id;     // (threshold stages: sample row -> store row)
-        const f32x4* prow = reinterpret_cast<const f32x4*>(prm.P + (size_t)prow_i * prm.ldP);
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll 4
-        for (int c4 = lane; c4 < nc4; c4 += 64) {
-            const f32x4 p = prow[c4];
-            const f32x4 qq = *reinterpret_cast<const f32x4*>(qrow + 4 * c4);
-            const double e0 = (double)p.x - (double)qq.x, e1 = (double)p.y - (double)qq.y;
-            const double e2 = (double)p.z - (double)qq.z, e3 = (double)p.w - (double)qq.w;
-            a0 = fma(e0, e0, a0); a1 = fma(e1, e1, a1); a2 = fma(e2, e2, a2); a3 = fma(e3, e3, a3);
-        }
-        double a = (a0 + a1) + (a2 + a3);
+    constexpr int RU = 4;
+    for (int s0 = wave * RU; s0 < ns; s0 += (kMergeThreads / 64) * RU) {
+        const f32x4* prow[RU];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o);
-        if (lane == 0) exact[s] = a;
+        for (int u = 0; u < RU; ++u) {
+            const int s = s0 + u < ns ? s0 + u : s0;                  // (a short last group re-reads its first row)
+            const int32_t id = (int32_t)(uint32_t)(sel[s] & 0xffffffffull);
+            const int64_t prow_i = prm.run_stride ? (int64_t)(id >> 3) * prm.run_stride + (id & 7) : (int64_t)id;     // (threshold stages: sample row -> store row)
+            prow[u] = reinterpret_cast<const f32x4*>(prm.P + (size_t)prow_i * prm.ldP);
+        }
+        double acc[RU][4];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) { acc[u][0] = 0; acc[u][1] = 0; acc[u][2] = 0; acc[u][3] = 0; }
+#pragma unroll 2
+        for (int c4 = lane; c4 < nc4; c4 += 64) {
+            f32x4 p[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) p[u] = prow[u][c4];
+            const f32x4 qq = *reinterpret_cast<const f32x4*>(qrow + 4 * c4);
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const double e0 = (double)p[u].x - (double)qq.x, e1 = (double)p[u].y - (double)qq.y;
+                const double e2 = (double)p[u].z - (double)qq.z, e3 = (double)p[u].w - (double)qq.w;
+                acc[u][0] = fma(e0, e0, acc[u][0]); acc[u][1] = fma(e1, e1, acc[u][1]);
+                acc[u][2] = fma(e2, e2, acc[u][2]); acc[u][3] = fma(e3, e3, acc[u][3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            double a = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o);
+            if (lane == 0 && s0 + u < ns) exact[s0 + u] = a;
+        }
     }
     if (wave == 0) {
         double a = 0;
@@ -1155,6 +1181,19 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_rerank(MergeParams pr
     for (int o = 1; o < 64; o <<= 1) mx_all = fmaxf(mx_all, __shfl_xor(mx_all, o));
     if (lane == 0) hist[wave] = (int)__float_as_uint(mx_all);           // (norms are non-negative: their bits order like the values)
     __syncthreads();
+    if (tid == 0 && prm.thr_out) {
+        // threshold stage: the k-th (= k'-th) exact distance of this sample bounds the store's k'-th smallest distance
+        float mx = 0.f;
+        for (int w = 0; w < kMergeThreads / 64; ++w) mx = fmaxf(mx, __uint_as_float((uint32_t)hist[w]));
+        const double qn2 = dmisc[0], tau = dmisc[1];
+        const double pn = sqrt((double)mx * 1.001), qn = sqrt(qn2);
+        const double E = prm.gamma * (pn + qn) * (pn + qn) + 1e-30;
+        float t = (float)(tau - qn2 + E);
+        if ((double)t < tau - qn2 + E) t = nextafterf(t, INFINITY);
+        // a stage that kept fewer than k' rows for this query has no k'-th distance to offer: the threshold of the stage before it
+        // (still a valid bound) stays; a valid new bound only ever tightens it
+        if (isfinite(tau) && ns >= kout && t < prm.thr_out[q]) prm.thr_out[q] = t;
+    }
     if (tid == 0) {
         int ok = 1;
         if (prm.N > (int64_t)kp) {
@@ -1628,7 +1667,7 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
     mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = pl.Dp;
     mp.k = k; mp.kp = pl.kp; mp.G = pl.G; mp.nblk = pl.G * pl.nqt;
     mp.gamma = 1.01 * (double)(pl.ng * kGroup * 16 + 16) * 5.9604644775390625e-08;    // n * 2^-24, n roundings per term
-    mp.cand_cnt = nullptr; mp.cand_cap = 0; mp.cand_segs = 1; mp.run_stride = 0;
+    mp.cand_cnt = nullptr; mp.cand_cap = 0; mp.cand_segs = 1; mp.run_stride = 0; mp.cand_cnt_clear = nullptr; mp.thr_out = nullptr;
     mp.row_offset = row_offset;
     mp.part_d = (const float*)(ws + pl.off_part_d);
     mp.part_i = (const int32_t*)(ws + pl.off_part_i);
@@ -1891,7 +1930,7 @@ int plane_search(const PlanePlan& pp, const float* d_P, int64_t N, int64_t ldP, 
     MergeParams mp;
     mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = pp.Dp;
     mp.k = k; mp.kp = pp.kp; mp.G = pp.G; mp.nblk = 1; mp.gamma = gamma;
-    mp.cand_cnt = nullptr; mp.cand_cap = 0; mp.cand_segs = 1; mp.run_stride = 0;
+    mp.cand_cnt = nullptr; mp.cand_cap = 0; mp.cand_segs = 1; mp.run_stride = 0; mp.cand_cnt_clear = nullptr; mp.thr_out = nullptr;
     mp.row_offset = row_offset;
     mp.part_d = (const float*)(ws + pp.off_part_d); mp.part_i = (const int32_t*)(ws + pp.off_part_i);
     mp.part_maxnorm = reinterpret_cast<const float*>(d_maxnorm);
@@ -1978,8 +2017,10 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     const double gamma = ac::knn_batch_gamma(D);
 
     // 1. per query: epilogue factor -2 2^(e_p + e_q), fp16 plane of q 2^-e_q, threshold +inf (keep everything)
+    //    (the same launch zeroes the candidate counters of every segmentation this call uses: no memset launches below)
     rc = ac::knn_prepare_queries(nullptr, bp.kp, d_Q, ldQ, D, nq, d_maxnorm, gamma,
-                                 (uint16_t*)(ws + bp.off_qp), (float*)(ws + bp.off_thr), (float*)(ws + bp.off_qfac), stream);
+                                 (uint16_t*)(ws + bp.off_qp), (float*)(ws + bp.off_thr), (float*)(ws + bp.off_qfac), stream,
+                                 (int32_t*)(ws + bp.off_cnt), (int64_t)bp.q_rows * bp.segs);
     if (rc != AC_OK) return rc;
     // 2. threshold stages: sweep a strided sample, re-rank its k' best exactly (knn_merge_rerank in candidate mode, asked for
     //    k' results; its certificate is irrelevant here -- ANY k' rows bound the k'-th smallest distance from above)
@@ -1987,6 +2028,9 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     sp.P = d_P; sp.Q = d_Q; sp.ldQ = ldQ; sp.D = D; sp.Dp = bp.Dp;
     sp.k = bp.kp; sp.kp = bp.kp; sp.G = 1; sp.nblk = 1; sp.gamma = gamma;
     sp.cand_cnt = (const int32_t*)(ws + bp.off_cnt); sp.cand_cap = bp.cap; sp.cand_segs = bp.segs; sp.row_offset = 0;
+    // a threshold stage's merge writes the new threshold itself and zeroes the counters it has read (the next sweep appends
+    // into them): round 3 spent a knn_thr_kernel launch and a memset launch per stage on that
+    sp.cand_cnt_clear = (int32_t*)(ws + bp.off_cnt); sp.thr_out = (float*)(ws + bp.off_thr);
     sp.part_d = (const float*)(ws + bp.off_cd); sp.part_i = (const int32_t*)(ws + bp.off_ci);
     sp.part_maxnorm = reinterpret_cast<const float*>(d_maxnorm);
     sp.outD = (float*)(ws + bp.off_sD32); sp.outD64 = (double*)(ws + bp.off_sD64); sp.outI = (int64_t*)(ws + bp.off_sI);
@@ -2001,7 +2045,6 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
         const int segs = batch_segs(bp, ac::knn_sample_rows(N, sst), nq);
         const size_t mlds = bp.merge_lds - (segs > 1 ? 0 : ac::align_up((size_t)bp.cap * 4, 16));
         sp.cand_segs = segs;
-        AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4 * segs, stream));
         rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
                                   (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci),
                                   (int32_t*)(ws + bp.off_cnt), bp.cap, segs, sst, st == 0 ? 1 : 0, stream);
@@ -2009,8 +2052,6 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
         sp.N = ac::knn_sample_rows(N, sst); sp.ldP = ldP; sp.run_stride = sst > 1 ? 8 * sst : 0;   // sample row i = store row (i >> 3) * 8 sst + (i & 7)
         hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), mlds, stream, sp);
         AC_LAUNCH_CHECK();
-        rc = ac::knn_thresholds((const double*)(ws + bp.off_sD64), bp.kp, d_Q, ldQ, D, nq, d_maxnorm, gamma, (float*)(ws + bp.off_thr), stream);
-        if (rc != AC_OK) return rc;
         if (dbg) {
             AC_HIP_CHECK(hipStreamSynchronize(stream));
             int32_t cnt[4]; float thr[4]; double tau[4];
@@ -2024,19 +2065,20 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     }
     const int msegs = batch_segs(bp, N, nq);
     const size_t mlds = bp.merge_lds - (msegs > 1 ? 0 : ac::align_up((size_t)bp.cap * 4, 16));
-    AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_cnt, 0, (size_t)bp.q_rows * 4 * msegs, stream));
-    // 3. the GEMM-form sweep: candidates (row, v) with v below the query's threshold
+    // 3. the GEMM-form sweep: candidates (row, v) with v below the query's threshold (its workgroup 0 also zeroes the caller's
+    //    d_stats and the fallback's slot counter, which the merge after it increments)
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
     rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
-                              (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, msegs, 1, 0, stream);
+                              (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, msegs, 1, 0, stream,
+                              (int32_t*)(ws + bp.off_fb_ctr), d_stats);
     if (rc != AC_OK) return rc;
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_stop, stream));
     // 4. merge + exact re-rank + certificate, then the exact fallback for uncertified queries
-    if (d_stats) AC_HIP_CHECK(hipMemsetAsync(d_stats, 0, 4 * sizeof(int32_t), stream));
     MergeParams mp;
     mp.P = d_P; mp.N = N; mp.ldP = ldP; mp.Q = d_Q; mp.ldQ = ldQ; mp.D = D; mp.Dp = bp.Dp;
     mp.k = k; mp.kp = bp.kp; mp.G = 1; mp.nblk = 1; mp.gamma = gamma;
     mp.cand_cnt = (const int32_t*)(ws + bp.off_cnt); mp.cand_cap = bp.cap; mp.cand_segs = msegs; mp.run_stride = 0;
+    mp.cand_cnt_clear = nullptr; mp.thr_out = nullptr;
     mp.row_offset = row_offset;
     mp.part_d = (const float*)(ws + bp.off_cd); mp.part_i = (const int32_t*)(ws + bp.off_ci);
     mp.part_maxnorm = reinterpret_cast<const float*>(d_maxnorm);
@@ -2045,7 +2087,6 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     mp.stats = d_stats;
     mp.fb_S = bp.fb_S; mp.fb_F = bp.fb_F;
     mp.fb_d = (double*)(ws + bp.off_fb_d); mp.fb_i = (int32_t*)(ws + bp.off_fb_i); mp.fb_slotctr = (int32_t*)(ws + bp.off_fb_ctr);
-    AC_HIP_CHECK(hipMemsetAsync(ws + bp.off_fb_ctr, 0, 256, stream));
     AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.merge_lds));
     hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), mlds, stream, mp);
     AC_LAUNCH_CHECK();
