@@ -245,3 +245,22 @@ def test_load_rows_prepare_makes_the_first_small_search_use_the_plane(cuda_dev, 
     assert int(mem.index._stats[1].item()) == 2                        # the very first search ran the fp16-plane sweep
     assert np.array_equal(I.cpu().numpy(), c_oracle.knn_l2_topk_batch(X, Q, 7)[1])
     assert abs(float(S.sum(dim=1).mean()) - 1.0) < 1e-5
+
+
+def test_sweeps_under_maximal_push_pressure(cuda_dev):
+    """A store ordered by DECREASING distance to the queries' common direction: almost every row a workgroup meets beats its
+    current threshold, so the candidate lists are pushed and pruned (radix select) about once per 28 rows instead of ~13 times
+    per sweep -- the worst case for the list maintenance of all three sweep forms.  Results must still be the oracle's."""
+    from oracle import c_oracle, synth
+    N, D, k = 70_000, 64, 16
+    rng = np.random.default_rng(3)
+    c = synth.synth_unit_rows(1, D, 5)[0]
+    X = (c + rng.standard_normal((N, D)).astype(np.float32) * 0.5).astype(np.float32)
+    d = ((X - c) ** 2).sum(1)
+    X = np.ascontiguousarray(X[np.argsort(-d, kind="stable")])              # farthest first, nearest last
+    for nq in (3, 24, 40):                                                  # ring sweep / 32-column plane tile / 64-column plane tile
+        Q = (c + rng.standard_normal((nq, D)).astype(np.float32) * 0.01).astype(np.float32)
+        dd, ii, nfb = _run(X, Q, k, cuda_dev)                               # (_run also compares with the fp32 sweep path)
+        assert _run.form == 2
+        oD, oI = c_oracle.knn_l2_topk_batch(X, Q, k)
+        assert np.array_equal(ii, oI) and _ulp_close(dd, oD)
