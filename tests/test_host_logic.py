@@ -498,3 +498,61 @@ def test_unpack_of_the_packed_device_result():
     assert got == [[("abcd"[cls[q, j]], float(val[q, j])) for j in range(kk)] for q in range(b)]
     h.id_to_label = {0: "w", 1: "x", 2: "y", 3: "z"}             # relabelled: no stale names
     assert AdaptiveClassifier._unpack(h, host, layout, 1)[0][0][0] == "wxyz"[cls[0, 0]]
+
+
+def test_predict_retry_contract_without_a_gpu():
+    """AdaptiveClassifier._predict_with_retry / _encoder_options (host logic only): the chain runs with verify=False first; NaN
+    scores after a one-launch forward repeat it layer by layer; NaN scores with the encoder's fused-LayerNorm verdict set switch
+    the fusion off (stubbed here) and repeat with verify=True; anything else is returned as computed.  A user-supplied encoder
+    without the options is called without them."""
+    from adaptive_classifier import AdaptiveClassifier
+    from adaptive_classifier import classifier as cmod
+
+    class Enc:
+        def __init__(self, one_launch=False, ln_aborted=False):
+            self.last_one_launch, self._ln, self.calls = one_launch, ln_aborted, []
+
+        def encode_cls(self, ids, types=None, mask=None, verify=True, force_layered=False):
+            self.calls.append((verify, force_layered))
+            return "emb%d" % len(self.calls)
+
+        def ln_fusion_aborted(self):
+            return self._ln
+
+    def run(enc, nan_until):
+        c = AdaptiveClassifier.__new__(AdaptiveClassifier)
+        c.model = enc
+        seen = []
+
+        def finish(emb):
+            seen.append(emb)
+            return ["result of " + emb], len(seen) <= nan_until
+        return c, c._predict_with_retry(lambda v, f: c._encode_tokens(None, None, None, verify=v, force_layered=f), finish), seen
+
+    c, res, seen = run(Enc(), 0)                                    # the common case: one pass, no sync asked of the encoder
+    assert res == ["result of emb1"] and c.model.calls == [(False, False)]
+    c, res, seen = run(Enc(one_launch=True), 1)                     # one-launch forward gave NaN -> layer by layer, verified
+    assert res == ["result of emb2"] and c.model.calls == [(False, False), (True, True)]
+    switched = []
+    real_lib = cmod.nv.lib
+    cmod.nv.lib = lambda: type("L", (), {"ac_gemm_set_ln_fusion": staticmethod(lambda on: switched.append(on) or 0)})
+    try:
+        c, res, seen = run(Enc(ln_aborted=True), 1)                 # fused LayerNorm gave up -> fusion off, batch encoded again
+    finally:
+        cmod.nv.lib = real_lib
+    assert res == ["result of emb2"] and c.model.calls == [(False, False), (True, False)] and switched == [0]
+    c, res, seen = run(Enc(), 5)                                    # NaN that the encoder does not explain: returned as computed
+    assert res == ["result of emb1"] and c.model.calls == [(False, False)]
+
+    class Plain:                                                    # a user encoder: no options in its signature
+        last_one_launch = False
+
+        def __init__(self):
+            self.calls = 0
+
+        def encode_cls(self, ids, types=None, mask=None):
+            self.calls += 1
+            return "e"
+    c = AdaptiveClassifier.__new__(AdaptiveClassifier)
+    c.model = Plain()
+    assert c._encoder_options() == set() and c._encode_tokens(None, verify=False, force_layered=True) == "e" and c.model.calls == 1
