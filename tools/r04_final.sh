@@ -13,9 +13,10 @@ import json;d=json.load(open('$O/bench_line.json'))
 print({k:d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'], d['roofline_fp16_plane']['frac'], d.get('latency_ms_b1',{}).get('value'), d.get('cfg4',{}).get('value'), d.get('add_examples',{}).get('value'))
 print(d['stages_ms'], d.get('parity'))"
 AC_BENCH_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 5 --warmup 1 > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2_gloo.err; echo "gpus2 rc=$? lines=$(grep -c '^{' $O/bench_gpus2_gloo.json)"
-( AC_KNN_RING=0 timeout 300 python -m pytest tests/test_knn_gpu.py -x -q -m gpu 2>&1 | tail -1
-  AC_KNN_PLANE=0 timeout 300 python -m pytest tests/test_knn_batch_gpu.py -x -q -m gpu -k "not plane and not load_rows and not second_search" 2>&1 | tail -1
-  AC_GEMM_ARITH=f32 timeout 400 python -m pytest tests/test_encoder_gpu.py -x -q -m gpu 2>&1 | tail -1
+# (tests that assert WHICH form ran are left out of the run that switches that form off)
+( AC_KNN_RING=0 timeout 300 python -m pytest tests/test_knn_gpu.py -q -m gpu -k "not lds_ring" 2>&1 | tail -1
+  AC_KNN_PLANE=0 timeout 300 python -m pytest tests/test_knn_batch_gpu.py -q -m gpu -k "not plane and not load_rows and not second_search and not push_pressure" 2>&1 | tail -1
+  AC_GEMM_ARITH=f32 timeout 400 python -m pytest tests/test_encoder_gpu.py -q -m gpu -k "not fused_into and not starved and not sticky" 2>&1 | tail -1
   AC_LN_FUSION=0 timeout 400 python -m pytest tests/test_encoder_gpu.py tests/test_classifier_gpu.py -x -q -m gpu -k "not starved and not sticky and not fused_into and not gave_up" 2>&1 | tail -1 ) > $O/alternate_paths.txt 2>&1
 cat $O/alternate_paths.txt
 cd /tmp && export TMPDIR=/tmp; T=/tmp/prof_fin4; rm -rf $T
