@@ -1,8 +1,9 @@
 """HipBertEncoder: the encoder call of the hot path on MI355X.
 
 Replaces `self.model(**inputs).last_hidden_state[:, 0, :]` + `F.normalize`
-(/root/reference/src/adaptive_classifier/classifier.py:1271-1275) for BERT-architecture
-and DistilBERT checkpoints (bert-base-uncased, bert-large, e5-large-v2, bert-tiny, distilbert-base-*) with one native call,
+(/root/reference/src/adaptive_classifier/classifier.py:1271-1275) for BERT-architecture, DistilBERT and RoBERTa-family
+checkpoints (bert-base-uncased, bert-large, e5-large-v2, bert-tiny, distilbert-base-*, roberta-*, xlm-roberta-* /
+multilingual-e5-*) with one native call,
 `ac_bert_encode_cls`, that writes unit-norm CLS vectors straight into a device buffer usable as the
 kNN query block (no device->host copy, cf. classifier.py:1282).
 
@@ -30,6 +31,8 @@ class _Cfg:
         self._name_or_path = name_or_path
 
 
+ROBERTA_TYPES = ("roberta", "xlm-roberta", "camembert")
+
 SMALL_TOKENS = 32     # up to here ac_bert_encode_cls runs the whole forward as one persistent launch (bert_small.hip): no packing
 
 
@@ -44,11 +47,18 @@ class HipBertEncoder:
         self.ln_gave_up = 0                   # encode_cls calls repeated because a fused-LayerNorm exchange gave up
         cfg = hf_bert.config
         mtype = getattr(cfg, "model_type", "bert")
-        if mtype not in ("bert", "distilbert"):
-            raise nv.NativeError(f"HipBertEncoder covers BERT / DistilBERT encoders, got {mtype!r}")
+        if mtype not in ("bert", "distilbert") + ROBERTA_TYPES:
+            raise nv.NativeError(f"HipBertEncoder covers BERT / DistilBERT / RoBERTa-family encoders, got {mtype!r}")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         sd = {k: v.detach() for k, v in hf_bert.state_dict().items()}
-        if mtype == "bert":
+        pos_offset = 0
+        if mtype == "bert" or mtype in ROBERTA_TYPES:
+            # RoBERTa / XLM-RoBERTa / CamemBERT (modeling_roberta.py): the BERT block under the same parameter names; positions
+            # count from padding_idx + 1 (create_position_ids_from_input_ids: cumsum over the non-pad tokens + padding_idx), which
+            # for right-padded inputs -- the only kind the classifier's tokenizer call produces -- is a constant row offset into
+            # the position table; padded positions never reach the CLS row.  One token type (ids are 0 or absent).
+            if mtype in ROBERTA_TYPES:
+                pos_offset = int(cfg.pad_token_id) + 1
             if getattr(cfg, "position_embedding_type", "absolute") not in (None, "absolute"):
                 raise nv.NativeError("HipBertEncoder: only absolute position embeddings are supported")
             act = cfg.hidden_act
@@ -73,7 +83,7 @@ class HipBertEncoder:
             raise nv.NativeError(f"HipBertEncoder: activation {act!r} unsupported (erf-GELU only)")
         self.config = _Cfg(H, getattr(cfg, "_name_or_path", ""))
         self.training = False
-        self.ccfg = nv.ac_bert_config(H, L, A, I, cfg.vocab_size, cfg.max_position_embeddings, type_vocab, eps)
+        self.ccfg = nv.ac_bert_config(H, L, A, I, cfg.vocab_size, cfg.max_position_embeddings - pos_offset, type_vocab, eps)
 
         def dev(t):
             return t.to(device=self.device, dtype=torch.float32).contiguous()
@@ -100,7 +110,7 @@ class HipBertEncoder:
         self._arrays = {}
         w = nv.ac_bert_weights()
         w.word_emb = own(sd[names["word"]]).data_ptr()
-        w.pos_emb = own(sd[names["pos"]]).data_ptr()
+        w.pos_emb = own(sd[names["pos"]][pos_offset:]).data_ptr()
         w.type_emb = own(sd[names["type"]] if names["type"] else torch.zeros(1, H)).data_ptr()
         w.emb_ln_g = own(sd[names["eln"] + ".weight"]).data_ptr()
         w.emb_ln_b = own(sd[names["eln"] + ".bias"]).data_ptr()

@@ -85,6 +85,45 @@ def encode_cls(model, ids, types, mask):
     return F.normalize(emb, p=2, dim=1)             # classifier.py:1275
 
 
+def make_roberta(hidden=128, layers=2, heads=2, intermediate=512, vocab=2000, max_pos=66, seed=0, model_type="roberta"):
+    """transformers RobertaModel / XLMRobertaModel (modeling_roberta.py: the BERT block; positions count from
+    padding_idx + 1 over the non-pad tokens), fp32 / eval / eager attention, random init."""
+    if model_type == "xlm-roberta":
+        from transformers import XLMRobertaConfig as Cfg, XLMRobertaModel as Mdl
+    else:
+        from transformers import RobertaConfig as Cfg, RobertaModel as Mdl
+    cfg = Cfg(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+              intermediate_size=intermediate, max_position_embeddings=max_pos, pad_token_id=1, bos_token_id=0, eos_token_id=2,
+              hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-5)
+    try:
+        cfg._attn_implementation = "eager"
+    except Exception:
+        pass
+    torch.manual_seed(seed)
+    return Mdl(cfg, add_pooling_layer=False).eval()
+
+
+def roberta_batch(b, S, vocab=2000, seed=1234, ragged=True, pad_id=1):
+    """Right-padded RoBERTa inputs: <s> = 0 first, ids ~U[3, vocab), </s> = 2 last, pad id in the padding (the reference
+    model derives the position ids from `input_ids != pad_id`, so the padding must really hold it)."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, vocab, (b, S), generator=g)
+    ids[:, 0] = 0
+    lens = torch.randint(max(2, S // 4), S + 1, (b,), generator=g) if ragged else torch.full((b,), S)
+    lens[0] = S
+    mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64)
+    for i in range(b):
+        ids[i, lens[i] - 1] = 2
+        ids[i, lens[i]:] = pad_id
+    return ids, mask
+
+
+@torch.no_grad()
+def encode_cls_roberta(model, ids, mask):
+    out = model(input_ids=ids, attention_mask=mask)
+    return F.normalize(out.last_hidden_state[:, 0, :], p=2, dim=1)
+
+
 def make_modernbert(hidden=768, layers=22, heads=12, intermediate=1152, vocab=50368, max_pos=8192, local_attention=128,
                     global_every=3, seed=0, init_scale=1.0):
     """transformers ModernBertModel (modeling_modernbert.py), fp32 / eval / eager attention, random init.

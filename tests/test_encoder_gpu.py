@@ -337,6 +337,33 @@ def test_starved_layernorm_exchange_gives_up_loudly(cuda_dev):
     assert (enc.encode_cls(ids, types, mask).cpu() - want).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("model_type,hidden,layers,heads,inter,b,S,ragged", [
+    ("roberta", 128, 2, 2, 512, 24, 16, True),          # packed (padding-free) path
+    ("roberta", 128, 3, 2, 512, 40, 16, False),         # full rows, LayerNorm-fused GEMM epilogues
+    ("xlm-roberta", 768, 2, 12, 3072, 8, 24, True),     # bert-base width
+    ("roberta", 128, 2, 2, 512, 1, 12, False),          # a single short query: the one-launch kernel
+])
+def test_roberta_family_matches_transformers(model_type, hidden, layers, heads, inter, b, S, ragged, cuda_dev):
+    """RoBERTa / XLM-RoBERTa (multilingual-e5-*): the BERT kernels with the position table entered at padding_idx + 1
+    (modeling_roberta.py create_position_ids_from_input_ids, right-padded inputs).  Unit-norm CLS vs transformers fp32 <= 1e-4."""
+    from adaptive_classifier.encoder import HipBertEncoder, make_encoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_roberta(hidden, layers, heads, inter, vocab=2000, max_pos=S + 8, seed=4, model_type=model_type)
+    ids, mask = bert_oracle.roberta_batch(b, S, vocab=2000, seed=17, ragged=ragged)
+    want = bert_oracle.encode_cls_roberta(model, ids, mask)
+    enc = make_encoder(model, device=cuda_dev)
+    assert isinstance(enc, HipBertEncoder)
+    got = enc.encode_cls(ids, None, mask).cpu()
+    assert (got - want).abs().max().item() < 1e-4, (got - want).abs().max().item()
+    assert enc.ccfg.max_pos == S + 8 - 2                       # the table is entered at padding_idx + 1 = 2
+    # ... and the offset matters: with the rows of the position table moved by one the result is something else
+    sd = model.state_dict()
+    sd["embeddings.position_embeddings.weight"] = torch.roll(sd["embeddings.position_embeddings.weight"], 1, 0)
+    other = bert_oracle.make_roberta(hidden, layers, heads, inter, vocab=2000, max_pos=S + 8, seed=4, model_type=model_type)
+    other.load_state_dict(sd)
+    assert (bert_oracle.encode_cls_roberta(other, ids, mask) - want).abs().max().item() > 1e-3
+
+
 def test_layernorm_verdict_is_sticky_over_the_chunks_of_a_call(cuda_dev, monkeypatch):
     """A batch beyond MAX_TOKENS runs as several native calls sharing one workspace.  The give-up of an EARLY chunk must not be
     erased by a later chunk (here the last chunk is too small for the fused epilogue and comes out finite): the verdict word
