@@ -47,12 +47,14 @@ class HipBertEncoder:
         self.ln_gave_up = 0                   # encode_cls calls repeated because a fused-LayerNorm exchange gave up
         cfg = hf_bert.config
         mtype = getattr(cfg, "model_type", "bert")
-        if mtype not in ("bert", "distilbert") + ROBERTA_TYPES:
-            raise nv.NativeError(f"HipBertEncoder covers BERT / DistilBERT / RoBERTa-family encoders, got {mtype!r}")
+        if mtype not in ("bert", "distilbert", "electra") + ROBERTA_TYPES:
+            raise nv.NativeError(f"HipBertEncoder covers BERT / DistilBERT / RoBERTa-family / ELECTRA encoders, got {mtype!r}")
+        if mtype == "electra" and getattr(cfg, "embedding_size", cfg.hidden_size) != cfg.hidden_size:
+            raise nv.NativeError("HipBertEncoder: ELECTRA with embedding_size != hidden_size (embeddings_project) is not covered")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         sd = {k: v.detach() for k, v in hf_bert.state_dict().items()}
         pos_offset = 0
-        if mtype == "bert" or mtype in ROBERTA_TYPES:
+        if mtype in ("bert", "electra") or mtype in ROBERTA_TYPES:          # (ELECTRA's discriminator body is the BERT block, same names)
             # RoBERTa / XLM-RoBERTa / CamemBERT (modeling_roberta.py): the BERT block under the same parameter names; positions
             # count from padding_idx + 1 (create_position_ids_from_input_ids: cumsum over the non-pad tokens + padding_idx), which
             # for right-padded inputs -- the only kind the classifier's tokenizer call produces -- is a constant row offset into

@@ -364,6 +364,28 @@ def test_roberta_family_matches_transformers(model_type, hidden, layers, heads, 
     assert (bert_oracle.encode_cls_roberta(other, ids, mask) - want).abs().max().item() > 1e-3
 
 
+def test_electra_body_matches_transformers(cuda_dev):
+    """ELECTRA (google/electra-base-*: embedding_size == hidden_size) is the BERT block under BERT's parameter names."""
+    from transformers import ElectraConfig, ElectraModel
+    from adaptive_classifier import _native as nv
+    from adaptive_classifier.encoder import make_encoder
+    from oracle import bert_oracle
+    cfg = ElectraConfig(vocab_size=2000, embedding_size=128, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                        intermediate_size=512, max_position_embeddings=64)
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(9)
+    model = ElectraModel(cfg).eval()
+    ids, types, mask = bert_oracle.synthetic_batch(20, 16, vocab=2000, seed=5)
+    types[:, 8:] = 1
+    want = bert_oracle.encode_cls(model, ids, types, mask)
+    got = make_encoder(model, device=cuda_dev).encode_cls(ids, types, mask).cpu()
+    assert (got - want).abs().max().item() < 1e-4
+    small = ElectraModel(ElectraConfig(vocab_size=2000, embedding_size=64, hidden_size=128, num_hidden_layers=1,
+                                       num_attention_heads=2, intermediate_size=512))
+    with pytest.raises(nv.NativeError, match="embeddings_project"):
+        make_encoder(small, device=cuda_dev)
+
+
 def test_layernorm_verdict_is_sticky_over_the_chunks_of_a_call(cuda_dev, monkeypatch):
     """A batch beyond MAX_TOKENS runs as several native calls sharing one workspace.  The give-up of an EARLY chunk must not be
     erased by a later chunk (here the last chunk is too small for the fused epilogue and comes out finite): the verdict word
