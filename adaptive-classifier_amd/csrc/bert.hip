@@ -171,31 +171,34 @@ __device__ __forceinline__ void rope_rotate(f32x4 (&x)[8], const float* cs, cons
 // window >= 0 (sliding-window layers, masking_utils.py:141-151): key k is visible to query q iff |q - k| <= window.
 // cu (packed / padding-free mode): sequence bi owns rows [cu[bi], cu[bi+1]) of qkv / ctx, all of them real tokens
 // (no mask); total_rows = cu[batch] is the row count of the planes output.  cu == nullptr: rows bi*S .. bi*S+S-1.
-template <bool ROPE>
+// DHT = head dimension: 64 (BERT-base / large, DistilBERT, RoBERTa, ModernBERT) or 32 (the MiniLM family: 384 = 12 x 32).
+template <bool ROPE, int DHT = 64>
 __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, const int64_t* mask, int S_, int H,
                                                             float scale, float* ctx, uint16_t* ctx_planes,
                                                             const float* rope_cos, const float* rope_sin,
                                                             int window, const int32_t* __restrict__ cu = nullptr,
                                                             int64_t total_rows = 0) {
+    static_assert(DHT == 64 || (DHT == 32 && !ROPE), "head dim 64, or 32 without RoPE");
+    constexpr int NKB = DHT / 8;                                     // 8-dim k-blocks of the QK^T product
     const int lane = threadIdx.x;
     const int qt = blockIdx.x, head = blockIdx.y, bi = blockIdx.z;
     const int64_t ld = 3 * (int64_t)H;
     const int64_t row0 = cu ? (int64_t)cu[bi] : (int64_t)bi * S_;
     const int S = cu ? cu[bi + 1] - cu[bi] : S_;
     if (qt * 32 >= S) return;                                        // (packed mode: short sequence)
-    const float* base = qkv + row0 * ld + head * DH;
+    const float* base = qkv + row0 * ld + head * DHT;
     const int j = lane & 31, h = lane >> 5;
     const int qi = qt * 32 + j;
     const bool qvalid = qi < S;
 
-    f32x4 Qf[8];
+    f32x4 Qf[NKB];
     {
         const float* qp = base + (int64_t)(qvalid ? qi : S - 1) * ld + 4 * h;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) Qf[kb] = *reinterpret_cast<const f32x4*>(qp + 8 * kb);
-        if (ROPE) rope_rotate(Qf, rope_cos, rope_sin, qvalid ? qi : S - 1, h);
+        for (int kb = 0; kb < NKB; ++kb) Qf[kb] = *reinterpret_cast<const f32x4*>(qp + 8 * kb);
+        if constexpr (ROPE) rope_rotate(Qf, rope_cos, rope_sin, qvalid ? qi : S - 1, h);
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) Qf[kb] = Qf[kb] * scale;
+        for (int kb = 0; kb < NKB; ++kb) Qf[kb] = Qf[kb] * scale;
     }
     f32x16 o0, o1;
 #pragma unroll
@@ -204,13 +207,13 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
 
     // K fragment of a tile (keys past S are clamped; they are masked below).  The next tile's fragment is
     // requested right after the QK^T MFMAs have consumed this one, so its latency hides under softmax + PV.
-    f32x4 Kf[8];
+    f32x4 Kf[NKB];
     auto load_k = [&](int k0) {
         int kr = k0 + j; if (kr > S - 1) kr = S - 1;
         const float* kp = base + (int64_t)kr * ld + H + 4 * h;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) Kf[kb] = *reinterpret_cast<const f32x4*>(kp + 8 * kb);
-        if (ROPE) rope_rotate(Kf, rope_cos, rope_sin, kr, h);
+        for (int kb = 0; kb < NKB; ++kb) Kf[kb] = *reinterpret_cast<const f32x4*>(kp + 8 * kb);
+        if constexpr (ROPE) rope_rotate(Kf, rope_cos, rope_sin, kr, h);
     };
     // key tiles that can hold a visible key for any of this tile's 32 queries (wave-uniform bounds)
     int kbeg = 0, kend = S;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
                 st = __builtin_amdgcn_mfma_f32_32x32x2f32(Kf[kb][s4], Qf[kb][s4], st, 0, 0, 0);
@@ -263,9 +266,8 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
         for (int r = 0; r < 16; ++r) {
             int vr = k0 + crow32(r, h); if (vr > S - 1) vr = S - 1;
             const float* vp = base + (int64_t)vr * ld + 2 * H + j;
-            const float v0 = vp[0], v1 = vp[32];
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, p[r], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, p[r], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], p[r], o0, 0, 0, 0);
+            if constexpr (DHT == 64) o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], p[r], o1, 0, 0, 0);
         }
     }
     if (qvalid) {
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
             // (h ^ 1) writes the other half
             const int64_t rows = cu ? total_rows : (int64_t)gridDim.z * S, row = row0 + qi, plane = rows * H;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < DHT / 32; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
@@ -284,17 +286,17 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
                     for (int e = 0; e < 4; ++e) v[e] = (t ? o1[4 * g + e] : o0[4 * g + e]) * inv;
                     uint2 Hh, Mm, Ll;
                     ac::split4(v, Hh, Mm, Ll);
-                    uint16_t* p = ctx_planes + ac::plane_off(rows, row, head * DH + 32 * t + 8 * g + 4 * h);
+                    uint16_t* p = ctx_planes + ac::plane_off(rows, row, head * DHT + 32 * t + 8 * g + 4 * h);
                     *reinterpret_cast<uint2*>(p) = Hh;
                     *reinterpret_cast<uint2*>(p + plane) = Mm;
                     *reinterpret_cast<uint2*>(p + 2 * plane) = Ll;
                 }
         } else {
-            float* dst = ctx + (row0 + qi) * H + head * DH;
+            float* dst = ctx + (row0 + qi) * H + head * DHT;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 dst[crow32(r, h)] = o0[r] * inv;
-                dst[32 + crow32(r, h)] = o1[r] * inv;
+                if constexpr (DHT == 64) dst[32 + crow32(r, h)] = o1[r] * inv;
             }
         }
     }
@@ -305,29 +307,31 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
 // lane = output dim for the P.V reduction; K tile rows padded to 65 floats (conflict-free column reads).
 // ROPE (ModernBERT): the CLS query is at position 0, whose rotation is the identity, so only the keys rotate;
 // window >= 0: only keys at positions <= window are visible to it.
-template <bool ROPE>
+template <bool ROPE, int DHT = 64>
 __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, const int64_t* mask, int S_, int H,
                                                            float scale, float* ctx_cls, const float* rope_cos,
                                                            const float* rope_sin, int window,
                                                            const int32_t* __restrict__ cu = nullptr) {
-    __shared__ float Ks[KT][DH + 1];
-    __shared__ __attribute__((aligned(16))) float Vs[KT][DH];
-    __shared__ float qs[DH];
+    static_assert(DHT == 64 || (DHT == 32 && !ROPE), "head dim 64, or 32 without RoPE");
+    __shared__ float Ks[KT][DHT + 1];
+    __shared__ __attribute__((aligned(16))) float Vs[KT][DHT];
+    __shared__ float qs[DHT];
     __shared__ float ps[KT];
     const int lane = threadIdx.x;
     const int head = blockIdx.x, bi = blockIdx.y;
     const int64_t ld = 3 * (int64_t)H;
     const int64_t row0 = cu ? (int64_t)cu[bi] : (int64_t)bi * S_;
     const int S = cu ? cu[bi + 1] - cu[bi] : S_;
-    const float* base = qkv + row0 * ld + head * DH;
-    qs[lane] = base[lane] * scale;              // CLS token = row 0 of the sequence
+    const float* base = qkv + row0 * ld + head * DHT;
+    if (lane < DHT) qs[lane] = base[lane] * scale;     // CLS token = row 0 of the sequence
     float m = -INFINITY, l = 0.f, o = 0.f;      // o: output dim `lane`
     const int Svis = (window >= 0 && window + 1 < S) ? window + 1 : S;     // keys the CLS query can see
     for (int k0 = 0; k0 < Svis; k0 += KT) {
         const int nk = (Svis - k0) < KT ? (Svis - k0) : KT;
         __syncthreads();
-        for (int r = lane >> 4; r < KT; r += 4) {
-            const int c = (lane & 15) * 4;
+        constexpr int LPR = DHT / 4;                     // lanes per key row (a float4 each)
+        for (int r = lane / LPR; r < KT; r += 64 / LPR) {
+            const int c = (lane % LPR) * 4;
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
             if (r < nk) {
                 const float* kp = base + (int64_t)(k0 + r) * ld + H;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
         __syncthreads();
         const bool valid = lane < nk && (!mask || mask[(int64_t)bi * S_ + k0 + lane] != 0);
         float sc = 0.f;
-        if (ROPE) {
+        if constexpr (ROPE) {
             const int pos = (k0 + lane < S) ? k0 + lane : S - 1;
             const float* cs = rope_cos + (int64_t)pos * 32;
             const float* sn = rope_sin + (int64_t)pos * 32;
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
             }
         } else {
 #pragma unroll 16
-            for (int d = 0; d < DH; ++d) sc = fmaf(qs[d], Ks[lane][d], sc);
+            for (int d = 0; d < DHT; ++d) sc = fmaf(qs[d], Ks[lane][d], sc);
         }
         sc = valid ? sc : -INFINITY;
         float cmax = sc;
@@ -369,10 +373,11 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
         l = l * corr + psum;
         o *= corr;
         __syncthreads();
-        for (int j = 0; j < nk; ++j) o = fmaf(ps[j], Vs[j][lane], o);
+        if (lane < DHT)
+            for (int j = 0; j < nk; ++j) o = fmaf(ps[j], Vs[j][lane], o);
         m = m_new;
     }
-    ctx_cls[(int64_t)bi * H + head * DH + lane] = l > 0.f ? o / l : 0.f;
+    if (lane < DHT) ctx_cls[(int64_t)bi * H + head * DHT + lane] = l > 0.f ? o / l : 0.f;
 }
 
 // ModernBERT MLP gate (modeling_modernbert.py:89-91): u = Wi x is [T, 2I]; g = gelu(u[:, :I]) * u[:, I:]
@@ -521,8 +526,8 @@ int check_cfg(const ac_bert_config* c) {
                "bert: bad config");
     AC_REQUIRE(c->hidden % 4 == 0 && c->hidden <= 64 * 4 * kMaxVec, AC_EUNSUPPORTED,
                "bert: hidden=%d unsupported (must be a multiple of 4 and <= %d)", c->hidden, 64 * 4 * kMaxVec);
-    AC_REQUIRE(c->hidden == c->heads * DH, AC_EUNSUPPORTED, "bert: head dim %d unsupported (only %d)",
-               c->hidden / c->heads, DH);
+    AC_REQUIRE(c->hidden == c->heads * 64 || c->hidden == c->heads * 32, AC_EUNSUPPORTED,
+               "bert: head dim %d unsupported (64 or 32)", c->hidden / c->heads);
     return AC_OK;
 }
 
@@ -578,7 +583,8 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
                        w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x,
                        pl ? xp : nullptr, tok_src);
     AC_LAUNCH_CHECK();
-    const float scale = 1.0f / sqrtf((float)DH);
+    const int dh = c.hidden / c.heads;                // 64, or 32 (MiniLM family)
+    const float scale = 1.0f / sqrtf((float)dh);
     for (int l = 0; l < c.layers; ++l) {
         const uint16_t* qkv_w3 = wplanes ? w->qkv_w3[l] : nullptr;
         const uint16_t* ao_w3 = wplanes ? w->ao_w3[l] : nullptr;
@@ -595,8 +601,12 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         const float* resid = x;                        // residual = layer input
         int64_t ldres = last ? (int64_t)S * H : H;     // CLS rows of x are S*H apart (padded layout)
         if (last) {
-            hipLaunchKernelGGL(attention_cls_kernel<false>, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale,
-                               ctx, nullptr, nullptr, -1, cu);
+            if (dh == 64)
+                hipLaunchKernelGGL((attention_cls_kernel<false, 64>), dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale,
+                                   ctx, nullptr, nullptr, -1, cu);
+            else
+                hipLaunchKernelGGL((attention_cls_kernel<false, 32>), dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale,
+                                   ctx, nullptr, nullptr, -1, cu);
             if (cu) {                                  // packed layout: the CLS rows sit at cu[s]; gather them
                 AC_LAUNCH_CHECK();
                 hipLaunchKernelGGL(gather_rows_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, cu, b, H, ffn);
@@ -604,8 +614,12 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
                 ldres = H;
             }
         } else {
-            hipLaunchKernelGGL(attention_mfma_kernel<false>, dim3((Smax + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv,
-                               d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1, cu, (int64_t)T);
+            if (dh == 64)
+                hipLaunchKernelGGL((attention_mfma_kernel<false, 64>), dim3((Smax + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv,
+                                   d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1, cu, (int64_t)T);
+            else
+                hipLaunchKernelGGL((attention_mfma_kernel<false, 32>), dim3((Smax + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv,
+                                   d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1, cu, (int64_t)T);
         }
         AC_LAUNCH_CHECK();
         const int lblocks = (Ml + 3) / 4;
@@ -848,7 +862,7 @@ int modernbert_encode_impl(const ac_modernbert_config* cfg, const ac_modernbert_
         const float* resid = x;
         int64_t ldres = last ? (int64_t)S * H : H;
         if (last) {
-            hipLaunchKernelGGL(attention_cls_kernel<true>, dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale, ctx,
+            hipLaunchKernelGGL((attention_cls_kernel<true, 64>), dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale, ctx,
                                rc_, rs_, win, cu);
             if (cu) {                                  // packed layout: the CLS rows sit at cu[s]; gather them (g is free until GeGLU)
                 AC_LAUNCH_CHECK();
@@ -857,7 +871,7 @@ int modernbert_encode_impl(const ac_modernbert_config* cfg, const ac_modernbert_
                 ldres = H;
             }
         } else {
-            hipLaunchKernelGGL(attention_mfma_kernel<true>, dim3((Smax + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv, d_mask,
+            hipLaunchKernelGGL((attention_mfma_kernel<true, 64>), dim3((Smax + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv, d_mask,
                                S, H, scale, ctx, pl ? ctxp : nullptr, rc_, rs_, win, cu, (int64_t)T);
         }
         AC_LAUNCH_CHECK();

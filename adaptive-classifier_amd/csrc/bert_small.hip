@@ -490,11 +490,9 @@ int bert_small_encode(const ac_bert_config& c, const ac_bert_weights& w, const i
     AC_HIP_CHECK(hipMemsetAsync(p.ctl, 0, sizeof(GridCtl), stream));
     const size_t lds = small_lds_bytes();
     const void* fn = T > 16 ? (const void*)bert_small_kernel<true> : (const void*)bert_small_kernel<false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[T > 16]) {
+    static std::atomic<unsigned long long> attr_set[2] = {{0}, {0}};  // (function attributes are per device)
+    if (first_call_on_device(attr_set[T > 16]))
         AC_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[T > 16] = true;
-    }
     // 192 workgroups of one per CU (LDS / registers) on 256 CUs: co-resident by construction whenever the device is not shared
     // with another compute process; a plain launch then has the same residency as a cooperative one and saves its ~30 us of
     // launch overhead -- 5 % of a single-query predict().  AC_BERT_SMALL_COOP=1 asks for the checked cooperative launch; a

@@ -1,5 +1,6 @@
 // Shared host-side helpers for libacamd.so (gfx950 only; no portability layer).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -17,6 +18,11 @@ struct DevInfo {
     size_t hbm_bytes;
 };
 const DevInfo& dev_info();   // lazily queried for the current device
+
+// One-time-per-DEVICE work on a latency-critical launch path (function attributes such as the dynamic-LDS opt-in are per
+// device; a plain `static bool` would skip them on a process's second GPU).  `done` = a static std::atomic<uint64_t> of the call
+// site; returns true the first time the current device asks (racing threads may both see true: the work must be idempotent).
+bool first_call_on_device(std::atomic<unsigned long long>& done);
 
 #define AC_HIP_CHECK(expr)                                                              \
     do {                                                                                \

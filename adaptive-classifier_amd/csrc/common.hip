@@ -44,6 +44,15 @@ const DevInfo& dev_info() {
     return info;
 }
 
+bool first_call_on_device(std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;      // unknown device: do the work every time
+    const unsigned long long bit = 1ull << dev;
+    if (done.load(std::memory_order_relaxed) & bit) return false;
+    done.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+}
+
 }  // namespace ac
 
 extern "C" const char* ac_last_error(void) { return ac::g_err; }

@@ -373,12 +373,10 @@ int launch_one(PipeParams p, hipStream_t stream) {
     constexpr int LN_BYTES = G::TR_BYTES + (WNW + 1) * G::BM * 8 + 16;                       // EPI_BIAS_RES_LN scratch
     const size_t lds = EPI == EPI_BIAS_RES_LN ? (size_t)(G::LDS_BYTES > LN_BYTES ? G::LDS_BYTES : LN_BYTES)
                                               : (size_t)(G::LDS_BYTES > G::TR_BYTES || !CP ? G::LDS_BYTES : G::TR_BYTES);
-    static bool attr_set = false;                                      // (per instantiation)
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};                // (per instantiation and, inside, per device)
+    if (ac::first_call_on_device(attr_set))
         AC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     p.stamps = (g_stamps && tiles <= g_stamp_cap) ? g_stamps : nullptr;
     hipLaunchKernelGGL((gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE>), dim3((unsigned)tiles), dim3(64 * WMW * WNW), lds, stream, p);
     AC_LAUNCH_CHECK();

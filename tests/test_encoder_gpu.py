@@ -40,6 +40,10 @@ def check_peaked(regime, model, ids, mask, types=None, S=None):
     (768, 1, 12, 3072, 3, 33, True),      # one key past a tile boundary
     (1024, 2, 16, 4096, 9, 30, True),     # bert-large width with T = 270 rows: pre-split operand planes, ragged tiles
     (1024, 24, 16, 4096, 16, 32, True),   # FULL-DEPTH bert-large = e5-large-v2 architecture (BASELINE configs[4]): 24 layers
+    (384, 6, 12, 1536, 24, 32, True),     # all-MiniLM-L6-v2 architecture: 12 heads of 32 dims (round 4), packed path
+    (384, 2, 12, 1536, 2, 130, True),     # head dim 32 over several key tiles
+    (384, 3, 12, 1536, 1, 12, False),     # head dim 32, a single short query (the one-launch kernel covers head dim 64 only: layered)
+    (384, 2, 12, 1536, 40, 16, False),    # head dim 32, full rows: LayerNorm-fused GEMM epilogues with three column tiles
 ])
 @pytest.mark.parametrize("regime", REGIMES)
 def test_encoder_cls_matches_transformers(hidden, layers, heads, inter, b, S, ragged, regime, cuda_dev):
