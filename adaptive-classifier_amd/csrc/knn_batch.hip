@@ -14,7 +14,8 @@
 //     |v - exact| <= E = gamma (max|p| + |q|)^2 with gamma = 1.01 (2^-11 + (K + 18 + sqrt K) 2^-24): input rounding, the
 //     subnormal tail, fp32 accumulation at 2 ulp per term (ac_knn_l2_topk_batch states the derivation);
 //   * it is a GEMM: 256 store rows x 256 queries per 8-wave workgroup (waves of 64 x 128), 32-k stages in a ring of four
-//     LDS slots filled by global_load_lds from the k-slot-major plane (the layout and the loop of gemm_pipe.hip: counted
+//     LDS slots filled by global_load_lds from the operand planes (the store's tile-major: a 256-row tile is one contiguous run,
+//     k-slot-major inside; the queries' [k-slot][row][8]; the loop of gemm_pipe.hip: counted
 //     vmcnt, raw barrier, fragment reads of stage s + 1 pinned under the MFMAs of stage s), ONE persistent workgroup per
 //     CU that walks its row tiles without draining the ring;
 //   * workgroup -> (query tile, row group): an XCD holds b <= 4 query tiles (their plane, <= 2 MB, stays in its L2) times
