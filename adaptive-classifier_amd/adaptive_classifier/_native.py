@@ -87,6 +87,7 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "ac_knn_store_bytes": (c_int, [c_int64, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "ac_knn_prepare_store": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "ac_knn_update_store": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "ac_knn_l2_topk_batch_workspace": (c_int, [c_int64, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "ac_knn_l2_topk_batch": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
                                      c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

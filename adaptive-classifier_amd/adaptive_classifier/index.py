@@ -33,12 +33,39 @@ BATCH_MIN_QUERIES, BATCH_MIN_ROWS, BATCH_MAX_K, BATCH_MIN_PAIRS = 64, 65536, 100
 PLANE_MIN_ROWS = 1 << 18
 
 
-def prepare_store(P, N, D):
+def store_buffers(rows, D, device):
+    """Empty (plane int16, norms fp32) buffers of a prepared store of up to `rows` rows (`ac_knn_store_bytes`)."""
+    pb, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    nv.check(nv.lib().ac_knn_store_bytes(rows, D, ctypes.byref(pb), ctypes.byref(nb)), "ac_knn_store_bytes")
+    return (torch.empty(pb.value // 2, dtype=torch.int16, device=device), torch.empty(nb.value // 4, dtype=torch.float32, device=device))
+
+
+def store_buffers_sizes(rows, D):
+    """(plane elements, norm elements) a prepared store of `rows` rows occupies"""
+    pb, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    nv.check(nv.lib().ac_knn_store_bytes(rows, D, ctypes.byref(pb), ctypes.byref(nb)), "ac_knn_store_bytes")
+    return pb.value // 2, nb.value // 4
+
+
+def update_store(P, n_old, n_new, D, prepared, row0, nrows):
+    """`ac_knn_update_store`: rows [row0, row0 + nrows) of P changed / were appended.  Returns True when the prepared store is
+    ready again, False when the new rows moved the store's power-of-two scale (every plane entry is stale: prepare anew).
+    Reads a 4-byte verdict back (one stream sync per update)."""
+    planes, norms = prepared
+    flag = torch.zeros(1, dtype=torch.int32, device=P.device)
+    with torch.cuda.device(P.device):
+        nv.check(nv.lib().ac_knn_update_store(nv.ptr(P), n_old, n_new, P.stride(0), D, nv.ptr(planes), nv.ptr(norms), row0, nrows,
+                                              nv.ptr(flag), nv.stream_ptr(P.device)), "ac_knn_update_store")
+    return int(flag.item()) == 0
+
+
+def prepare_store(P, N, D, capacity=None):
     """(plane, norms) of the first N rows of the store P for the batched search (`ac_knn_prepare_store`): one fp16
-    operand plane + |p|^2 per row.  Costs two passes over the rows and 2 B per element; redo after the rows change."""
+    operand plane + |p|^2 per row.  Costs two passes over the rows and 2 B per element.  After rows change: `update_store`
+    (appended / overwritten rows) or prepare anew.  capacity: size the buffers for that many rows (stores that grow)."""
     nv.require_gpu()
     pb, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
-    nv.check(nv.lib().ac_knn_store_bytes(N, D, ctypes.byref(pb), ctypes.byref(nb)), "ac_knn_store_bytes")
+    nv.check(nv.lib().ac_knn_store_bytes(max(N, capacity or 0), D, ctypes.byref(pb), ctypes.byref(nb)), "ac_knn_store_bytes")
     planes = torch.empty(pb.value // 2, dtype=torch.int16, device=P.device)
     norms = torch.empty(nb.value // 4, dtype=torch.float32, device=P.device)
     with torch.cuda.device(P.device):
@@ -145,9 +172,28 @@ class HipFlatL2Index:
         self._searches_since_change = 0
 
     def _rows_changed(self):
-        """the resident rows changed: the prepared plane / norms describe the old ones"""
+        """the resident rows changed in a way the prepared plane cannot follow (compaction, adoption of another matrix, reset)"""
         self._prepared = None
         self._searches_since_change = 0
+
+    def _rows_written(self, n_old, row0, nrows):
+        """rows [row0, row0 + nrows) were overwritten / appended (n_old -> self._n rows): the prepared plane follows
+        incrementally (`ac_knn_update_store`: those rows only) unless the new rows change the store's scale -- an index that is
+        both searched and added to keeps its fp16 plane instead of paying two passes over all rows per change (round 3 dropped
+        the plane on every change)."""
+        if self._prepared is None:
+            return
+        planes, norms = self._prepared
+        need_p, need_n = store_buffers_sizes(self._n, self.d)
+        if planes.numel() < need_p or norms.numel() < need_n:            # grow: the first n_old rows' entries are a prefix
+            cap = max(self._store.shape[0], self._n)
+            planes2, norms2 = store_buffers(cap, self.d, self.device)
+            old_p, old_n = store_buffers_sizes(n_old, self.d)
+            planes2[:old_p] = planes[:old_p]
+            norms2[:old_n] = norms[:old_n]
+            self._prepared = (planes2, norms2)
+        if not update_store(self._store, n_old, self._n, self.d, self._prepared, row0, nrows):
+            self._prepared = None                                         # scale changed: prepared anew at the next search
 
     @property
     def device(self):
@@ -189,7 +235,7 @@ class HipFlatL2Index:
             self._reserve(self._n + m)
             self._store[self._n: self._n + m, : self.d] = rows.to(self.device, non_blocking=True)
             self._n += m
-            self._rows_changed()
+            self._rows_written(self._n - m, self._n - m, m) if self._n > m else self._rows_changed()
         if self._store is None:
             self._reserve(1)
         if self._stats is None:
@@ -205,7 +251,7 @@ class HipFlatL2Index:
             self._reserve(self._n + m)
             self._store[self._n: self._n + m, : self.d] = rows.to(self.device)
             self._n += m
-            self._rows_changed()
+            self._rows_written(self._n - m, self._n - m, m) if self._n > m else self._rows_changed()
         else:
             self._pending.append(rows.clone())
             self._npending += rows.shape[0]
@@ -251,7 +297,16 @@ class HipFlatL2Index:
         self._materialize()
         vals = self._as_rows(values).to(self.device)
         self._store[rows.to(self.device), : self.d] = vals
-        self._rows_changed()
+        if self._prepared is not None:
+            ids = np.unique(rows.numpy())
+            runs = np.split(ids, np.nonzero(np.diff(ids) != 1)[0] + 1)       # contiguous runs of row ids
+            if len(runs) > 16:
+                self._rows_changed()                                      # many scattered rows: a fresh preparation is cheaper
+            else:
+                for run in runs:
+                    if self._prepared is None:
+                        break
+                    self._rows_written(self._n, int(run[0]), int(run.size))
 
     def search_device(self, q, k):
         """q: [nq, d] fp32 tensor (any device) -> (dist, ids) CUDA tensors; no host sync."""
@@ -264,7 +319,8 @@ class HipFlatL2Index:
         batch = batch_applies(self._n, q.shape[0], k, auto=True)
         if batch and self._prepared is None:
             # preparing costs two passes over the rows (~0.14 s at 10M x 768): at once for a many-query search (it pays within
-            # the call); for a small batch only when the store has already served a search since its rows last changed
+            # the call); for a small batch only when the store has already served a search since it was last rebuilt / compacted
+            # (appends and in-place updates do not count: once prepared, the plane follows them incrementally)
             if q.shape[0] >= BATCH_MIN_QUERIES or self._searches_since_change >= 1:
                 self._prepared = prepare_store(self._store, self._n, self.d)      # once per store content
             else:

@@ -127,6 +127,8 @@ size_t knn_planes_bytes(int64_t rows, int D);      // bytes of the fp16 plane of
 double knn_batch_gamma(int D);                     // |sweep value - exact| <= gamma (max|p| + |q|)^2
 int knn_prepare_store(const float* X, int64_t ldx, int64_t rows, int D, uint16_t* plane, float* norms, uint32_t* maxnorm_bits,
                       hipStream_t stream);
+int knn_update_store(const float* X, int64_t ldx, int64_t n_old, int64_t n_new, int D, uint16_t* plane, float* norms, int64_t row0,
+                     int64_t nrows, int32_t* exponent_changed, hipStream_t stream);
 int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t ldQ, int D, int nq, const uint32_t* maxnorm_bits,
                         double gamma, uint16_t* qplane, float* thr, float* qfac, hipStream_t stream, int32_t* zero_ints = nullptr,
                         int64_t zero_count = 0);             // zero_ints: device ints the same launch clears (the candidate counters)

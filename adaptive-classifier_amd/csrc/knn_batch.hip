@@ -56,9 +56,10 @@ __device__ __forceinline__ int unit_exponent(double x) { return x > 0.0 ? ilogb(
 // ---- store preparation ---------------------------------------------------------------------------------------------
 // pass 1: |p|^2 per row (fp64 accumulate, rounded once) and the maximum
 __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int D,
-                                                        float* __restrict__ norms, uint32_t* __restrict__ maxnorm_bits) {
+                                                        float* __restrict__ norms, uint32_t* __restrict__ maxnorm_bits,
+                                                        int64_t row_begin) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     double nn = 0.0;
     for (int c = lane; c < D; c += 64) { const double v = X[row * ldx + c]; nn = fma(v, v, nn); }
@@ -80,11 +81,11 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
                                                         uint16_t* __restrict__ plane, const double* __restrict__ sampleD, int kp,
                                                         double gamma, float* __restrict__ thr, float* __restrict__ qfac,
                                                         float* __restrict__ pad_norms, int tile_major,
-                                                        int32_t* __restrict__ zero_a, int64_t zero_na) {
+                                                        int32_t* __restrict__ zero_a, int64_t zero_na, int64_t row_begin) {
     // (query form) the counters the following launches append to start at zero: done here instead of by a memset launch
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < zero_na; i += (int64_t)gridDim.x * 256) zero_a[i] = 0;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (row_begin: incremental store updates)
     if (row >= rows_pad) return;
     const double pmax = sqrt((double)__uint_as_float(*maxnorm_bits) * 1.001);
     const int ep = unit_exponent(pmax);
@@ -469,10 +470,50 @@ int knn_prepare_store(const float* X, int64_t ldx, int64_t rows, int D, uint16_t
     const int Kp = knn_kp(D);
     const int64_t rp = (rows + 255) / 256 * 256;
     if (rp == 0) return AC_OK;
-    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, X, ldx, rows, D, norms, maxnorm_bits);
+    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, X, ldx, rows, D, norms, maxnorm_bits, (int64_t)0);
     AC_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_plane_kernel, dim3((unsigned)((rp + 3) / 4)), dim3(256), 0, stream, X, ldx, rows, rp, D, Kp, maxnorm_bits, 0,
-                       plane, (const double*)nullptr, 0, 0.0, (float*)nullptr, (float*)nullptr, norms, 1, (int32_t*)nullptr, (int64_t)0);
+                       plane, (const double*)nullptr, 0, 0.0, (float*)nullptr, (float*)nullptr, norms, 1, (int32_t*)nullptr, (int64_t)0, (int64_t)0);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+// ---- incremental maintenance of a prepared store (ac_knn_update_store) ----
+// head[0] = max |p|^2 (float bits) sits behind the tile padding, i.e. at norms[round_up(N, 256)]: it moves when N crosses a tile
+// boundary.  begin: carry the maximum to its new slot, remember the old one, clear the verdict, pad the new last tile with +inf.
+__global__ void knn_update_begin_kernel(float* norms, int64_t np_old, int64_t np_new, int64_t n_new) {
+    const int t = threadIdx.x;
+    __shared__ float old_max;
+    if (t == 0) old_max = norms[np_old];
+    __syncthreads();
+    for (int64_t r = n_new + t; r < np_new; r += blockDim.x) norms[r] = INFINITY;     // (rows [n_old, n_new) get their norms next)
+    __syncthreads();
+    if (t == 0) { norms[np_new] = old_max; norms[np_new + 2] = old_max; norms[np_new + 1] = 0.f; }
+}
+// finish: did the store's power-of-two scale change?  (then every OTHER row's fp16 plane entry is stale: the caller prepares anew)
+__global__ void knn_update_finish_kernel(const float* norms, int64_t np_new, int32_t* exponent_changed) {
+    const double po = sqrt((double)norms[np_new + 2] * 1.001), pn = sqrt((double)norms[np_new] * 1.001);
+    *exponent_changed = unit_exponent(po) != unit_exponent(pn) ? 1 : 0;
+}
+
+int knn_update_store(const float* X, int64_t ldx, int64_t n_old, int64_t n_new, int D, uint16_t* plane, float* norms, int64_t row0,
+                     int64_t nrows, int32_t* exponent_changed, hipStream_t stream) {
+    const int Kp = knn_kp(D);
+    const int64_t np_old = (n_old + 255) / 256 * 256, np_new = (n_new + 255) / 256 * 256;
+    uint32_t* maxbits = reinterpret_cast<uint32_t*>(norms + np_new);
+    hipLaunchKernelGGL(knn_update_begin_kernel, dim3(1), dim3(256), 0, stream, norms, np_old, np_new, n_new);
+    AC_LAUNCH_CHECK();
+    // norms of the changed rows (atomicMax into the maximum), then their plane entries with the scale of the (possibly raised)
+    // maximum; when rows were appended the rest of the last tile is rewritten too (zero plane entries behind the last row)
+    const int64_t r_end = n_new > n_old ? np_new : row0 + nrows;
+    const int64_t cnt_n = row0 + nrows - row0, cnt_p = r_end - row0;
+    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((cnt_n + 3) / 4)), dim3(256), 0, stream, X, ldx, row0 + nrows, D, norms, maxbits, row0);
+    AC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_plane_kernel, dim3((unsigned)((cnt_p + 3) / 4)), dim3(256), 0, stream, X, ldx, n_new, r_end, D, Kp, maxbits, 0,
+                       plane, (const double*)nullptr, 0, 0.0, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1, (int32_t*)nullptr,
+                       (int64_t)0, row0);
+    AC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_update_finish_kernel, dim3(1), dim3(1), 0, stream, norms, np_new, exponent_changed);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
@@ -483,7 +524,7 @@ int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t l
     const int Kp = knn_kp(D);
     const int64_t qp = ((int64_t)nq + 255) / 256 * 256;
     hipLaunchKernelGGL(knn_plane_kernel, dim3((unsigned)((qp + 3) / 4)), dim3(256), 0, stream, Q, ldQ, (int64_t)nq, qp, D, Kp,
-                       maxnorm_bits, 1, qplane, sampleD, kp, gamma, thr, qfac, (float*)nullptr, 0, zero_ints, zero_count);
+                       maxnorm_bits, 1, qplane, sampleD, kp, gamma, thr, qfac, (float*)nullptr, 0, zero_ints, zero_count, (int64_t)0);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }

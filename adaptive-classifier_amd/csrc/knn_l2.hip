@@ -1972,6 +1972,17 @@ extern "C" int ac_knn_prepare_store(const float* d_P, int64_t N, int64_t ldP, in
     return ac::knn_prepare_store(d_P, ldP, N, D, d_planes, d_norms, reinterpret_cast<uint32_t*>(d_norms + np), stream);
 }
 
+extern "C" int ac_knn_update_store(const float* d_P, int64_t N_old, int64_t N_new, int64_t ldP, int D, uint16_t* d_planes,
+                                   float* d_norms, int64_t row0, int64_t nrows, int32_t* d_exponent_changed, ac_stream_t stream_) {
+    AC_REQUIRE(d_P && d_planes && d_norms && d_exponent_changed && D >= 1 && ldP >= D, AC_EINVAL, "knn_update_store: bad arguments");
+    AC_REQUIRE(N_old >= 1 && N_new >= N_old && row0 >= 0 && nrows >= 1 && row0 + nrows <= N_new, AC_EINVAL,
+               "knn_update_store: rows [%lld, %lld) outside a store of %lld rows (was %lld)", (long long)row0, (long long)(row0 + nrows),
+               (long long)N_new, (long long)N_old);
+    AC_REQUIRE(N_new == N_old || (row0 + nrows == N_new && row0 <= N_old), AC_EINVAL,
+               "knn_update_store: an append must cover every new row: [row0, row0 + nrows) = [<= N_old, N_new)");
+    return ac::knn_update_store(d_P, ldP, N_old, N_new, D, d_planes, d_norms, row0, nrows, d_exponent_changed, (hipStream_t)stream_);
+}
+
 extern "C" int ac_knn_l2_topk_batch_workspace(int64_t N, int D, int nq, int k, size_t* bytes) {
     AC_REQUIRE(bytes != nullptr, AC_EINVAL, "knn batch workspace: bytes is NULL");
     BatchPlan bp;

@@ -122,6 +122,17 @@ int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
 int ac_knn_store_bytes(int64_t N, int D, size_t* planes_bytes, size_t* norms_bytes);
 int ac_knn_prepare_store(const float* d_P, int64_t N, int64_t ldP, int D,
                          uint16_t* d_planes, float* d_norms, ac_stream_t stream);
+/* Incremental maintenance of a prepared store after `index.add` / an in-place row update (memory.py:159,172,190; round 4):
+ * rows [row0, row0 + nrows) of d_P changed or were appended (N_new >= N_old; an append passes row0 <= N_old and
+ * row0 + nrows == N_new).  d_planes / d_norms must hold a store of N_new rows (ac_knn_store_bytes(N_new); the tile-major plane and
+ * the norms of the first N_old rows are a PREFIX of the larger buffers, so growing them is a plain copy).  Recomputes the norms
+ * and fp16 plane entries of those rows, carries the maximum |p|^2 (it only ever grows: an upper bound is what the certificate
+ * needs), pads the new last tile.  *d_exponent_changed (device int) = 1 when the new maximum moved the store's power-of-two
+ * scale: every OTHER row's plane entry is stale then and the caller must ac_knn_prepare_store again; 0 = the store is ready.
+ * Cost: four small launches + nrows rows, instead of two passes over all N rows. */
+int ac_knn_update_store(const float* d_P, int64_t N_old, int64_t N_new, int64_t ldP, int D,
+                        uint16_t* d_planes, float* d_norms, int64_t row0, int64_t nrows,
+                        int32_t* d_exponent_changed, ac_stream_t stream);
 int ac_knn_l2_topk_batch_workspace(int64_t N, int D, int nq, int k, size_t* bytes);
 int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, int D,
                          const uint16_t* d_planes, const float* d_norms,

@@ -100,7 +100,8 @@ def test_batched_path_candidate_overflow_goes_to_exact_fallback(cuda_dev):
 
 
 def test_index_uses_the_batched_path_and_invalidates_on_change(cuda_dev, request):
-    """HipFlatL2Index prepares the store lazily for many-query searches and drops the planes when rows change."""
+    """HipFlatL2Index prepares the store lazily for many-query searches; the plane follows in-place row updates and is dropped
+    by a compaction (remove_ids)."""
     from adaptive_classifier.index import HipFlatL2Index
     from oracle import c_oracle, synth
     D = 64
@@ -116,13 +117,15 @@ def test_index_uses_the_batched_path_and_invalidates_on_change(cuda_dev, request
     assert idx._prepared is not None
     assert np.array_equal(i, c_oracle.knn_l2_topk_batch(X, Q, 5)[1])
     idx.update_rows([3], Q[:1])                                        # row 3 := query 0 -> must be found at distance 0
-    assert idx._prepared is None
+    assert idx._prepared is not None                                   # (round 4: the plane follows the row, ac_knn_update_store)
     d, i = idx.search(Q, 5)
     assert i[0, 0] == 3 and d[0, 0] == 0.0
     X2 = X.copy(); X2[3] = Q[0]
     assert np.array_equal(i, c_oracle.knn_l2_topk_batch(X2, Q, 5)[1])
     d1, i1 = idx.search(Q[:8], 5)                                      # few queries: the fp32 sweep path, same answer
     assert np.array_equal(i1, i[:8]) and np.array_equal(d1, d[:8])
+    idx.remove_ids(np.array([10]))
+    assert idx._prepared is None
 
 
 def test_batched_path_two_threshold_stages_of_similar_size(cuda_dev):
@@ -203,7 +206,7 @@ def test_plane_sweep_unnormalised_near_ties_duplicates_and_clusters(cuda_dev):
 
 def test_index_prepares_for_small_batches_from_the_second_search_on(cuda_dev, request):
     """HipFlatL2Index: a big store's first few-query search runs the fp32 sweep (no preparation cost), the following ones the
-    fp16-plane sweep; a row change drops the plane again.  Same answers throughout."""
+    fp16-plane sweep; an in-place row update is folded into the plane, a compaction drops it.  Same answers throughout."""
     from adaptive_classifier import index as ixm
     from adaptive_classifier.index import HipFlatL2Index
     from oracle import c_oracle, synth
@@ -221,12 +224,16 @@ def test_index_prepares_for_small_batches_from_the_second_search_on(cuda_dev, re
     d1, i1 = idx.search(Q, 5)
     assert idx._prepared is not None and int(idx._stats[1].item()) == 2
     assert np.array_equal(i1, want) and np.array_equal(d1, d0)
-    idx.update_rows([3], Q[:1])
-    assert idx._prepared is None
+    idx.update_rows([3], Q[:1])                                        # the plane follows the row
+    assert idx._prepared is not None
     d2, i2 = idx.search(Q, 5)
-    assert idx._prepared is None and i2[0, 0] == 3 and d2[0, 0] == 0.0
+    assert int(idx._stats[1].item()) == 2 and i2[0, 0] == 3 and d2[0, 0] == 0.0
+    idx.remove_ids(np.array([7]))                                      # a compaction drops it; prepared anew from the second search on
+    assert idx._prepared is None
     d3, i3 = idx.search(Q, 5)
-    assert idx._prepared is not None and np.array_equal(i3, i2) and np.array_equal(d3, d2)
+    assert idx._prepared is None
+    d4, i4 = idx.search(Q, 5)
+    assert idx._prepared is not None and np.array_equal(i4, i3) and np.array_equal(d4, d3)
 
 
 def test_load_rows_prepare_makes_the_first_small_search_use_the_plane(cuda_dev, request):
@@ -264,3 +271,54 @@ def test_sweeps_under_maximal_push_pressure(cuda_dev):
         assert _run.form == 2
         oD, oI = c_oracle.knn_l2_topk_batch(X, Q, k)
         assert np.array_equal(ii, oI) and _ulp_close(dd, oD)
+
+
+def test_prepared_store_follows_appends_and_row_updates_incrementally(cuda_dev, request):
+    """ac_knn_update_store through HipFlatL2Index: an index that is searched AND added to keeps its fp16 plane -- appended rows
+    (across a tile boundary, across a reallocation of the store) and overwritten rows are folded in; a row that moves the
+    store's power-of-two scale drops the plane (prepared anew later).  The answers are the oracle's throughout."""
+    from adaptive_classifier import index as ixm
+    from adaptive_classifier.index import HipFlatL2Index
+    from oracle import c_oracle, synth
+    old = ixm.PLANE_MIN_ROWS
+    ixm.PLANE_MIN_ROWS = 65_536
+    request.addfinalizer(lambda: setattr(ixm, "PLANE_MIN_ROWS", old))
+    D, k = 64, 7
+    X = synth.synth_unit_rows(70_000, D, 31)
+    Q = synth.synth_unit_rows(6, D, 32)
+    idx = HipFlatL2Index(D, device=cuda_dev)
+    idx.add(X)
+
+    def check(Xh, plane):
+        d, i = idx.search(Q, k)
+        assert (int(idx._stats[1].item()) == 2) == plane, (int(idx._stats[1].item()), plane)
+        oD, oI = c_oracle.knn_l2_topk_batch(Xh, Q, k)
+        assert np.array_equal(i, oI) and _ulp_close(d, oD)
+    check(X, False)                                    # first search of a fresh store: fp32 sweep
+    check(X, True)                                     # second: prepared
+    planes0 = idx._prepared[0]
+    A = synth.synth_unit_rows(300, D, 33)              # 70 000 -> 70 300 rows: the last tile fills up and a new one starts
+    A[5] = Q[2] * 0.999                                # ... and one of the new rows is query 2's nearest neighbour
+    idx.add(torch.from_numpy(A).to(cuda_dev))
+    X1 = np.concatenate([X, A])
+    assert idx._prepared is not None
+    check(X1, True)
+    idx.update_rows([3, 4, 5, 69_999, 70_200], np.stack([Q[0], Q[1] * 1.001, Q[3], Q[4] * 0.998, Q[5]]))      # in place, two tiles
+    X2 = X1.copy(); X2[[3, 4, 5, 69_999, 70_200]] = np.stack([Q[0], Q[1] * 1.001, Q[3], Q[4] * 0.998, Q[5]])
+    assert idx._prepared is not None
+    check(X2, True)
+    B = synth.synth_unit_rows(90_000, D, 34)           # beyond the store's capacity: matrix and plane buffers are reallocated
+    idx.add(B)                                         # (host rows: uploaded by the next search)
+    X3 = np.concatenate([X2, B])
+    check(X3, True)
+    assert idx._prepared is not None and idx._prepared[0].numel() > planes0.numel()
+    big = (Q[0] * 40.0)[None, :]                       # |p| = 40: the store's scale 2^e_p must grow -> every plane entry is stale
+    idx.add(torch.from_numpy(big).to(cuda_dev))
+    X4 = np.concatenate([X3, big])
+    assert idx._prepared is None
+    check(X4, True)                                    # prepared anew by this search (the store has been searched before)
+    idx.remove_ids(np.array([0, 70_005]))              # compaction: the plane cannot follow
+    assert idx._prepared is None
+    X5 = np.delete(X4, [0, 70_005], axis=0)
+    check(X5, False)                                   # like a fresh store: fp32 sweep first,
+    check(X5, True)                                    # prepared from the second search on
