@@ -14,7 +14,9 @@ N > 1    one process per GPU.  step = one 4096-query batch of BASELINE configs[2
          ranks, k = 32, every rank owns 4096 / N queries: all-gather(queries) + local exact search + all-to-all(exact fp64
          distance, id) over RCCL + merge of the rank's own block.  value = 4096 * K / max-over-ranks time
          ("scaling": "strong"; rank 0 also measures the one-GPU form of the same job inside the run).  configs[1] data
-         parallel (every rank encodes its own 256 texts, 100k rows sharded) is carried as `configs1_weak`.
+         parallel (every rank encodes its own 256 texts, 100k rows sharded) is carried as `configs1_weak`, and configs[4] (e5-large-v2
+         architecture, 2M x 1024 store row-sharded, 1024 texts per step data parallel: the BASELINE quotes it on 4 GPUs) as
+         `configs4_data_parallel_sharded` (--no-extras skips it).
 roofline the kNN distance sweep in its HBM-bound regime (the north star's roofline target): knn_sweep
          over 10M x 768 fp32 rows (30.7 GB) with 16 resident queries, timed with HIP events recorded
          around that kernel on its own stream (ac_knn_set_profile_events).  algorithmic bytes = N*D*4.
@@ -747,6 +749,51 @@ def encoder_roofline(clf, stages, enc_flops, enc_peak, arith):
                                              "batch divided by the time this path takes for the same outputs"}}
 
 
+def cfg4_multi(dev, rank, world, steps, warmup):
+    """BASELINE configs[4] on N GPUs (it is quoted on 4): e5-large-v2 architecture (BERT-large, random init) replicated, 1024 texts
+    per step data parallel (1024 / N per rank, ragged <= 32 tokens), the 2M x 1024 store row-sharded, 64 classes, k = 32: encoder ->
+    all-gather(queries) -> local exact search -> all-to-all -> merge -> head -> blend -> result lists on every rank."""
+    from adaptive_classifier import AdaptiveClassifier, AdaptiveHead
+    from adaptive_classifier import index as ix
+    from adaptive_classifier.encoder import HipBertEncoder
+    from adaptive_classifier.sharded import ShardedSearch, shard_bounds
+    from transformers import BertConfig, BertModel
+    D, NP_, C, B, K_, S = 1024, 2_000_000, 64, 1024, 32, 32
+    cfg = BertConfig(hidden_size=D, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    torch.manual_seed(0)
+    enc = HipBertEncoder(BertModel(cfg, add_pooling_layer=False).eval(), device=dev)
+    clf = AdaptiveClassifier("e5-large-v2(random-init)", device=str(dev), encoder=enc, tokenizer=None)
+    labels = [f"c{i}" for i in range(C)]
+    clf.label_to_id = {l: i for i, l in enumerate(labels)}
+    clf.id_to_label = {i: l for i, l in enumerate(labels)}
+    clf.training_history = {l: 25 for l in labels}
+    clf.adaptive_head = AdaptiveHead(D, C, [D, D // 2]).to(dev).eval()
+    lo, hi = shard_bounds(NP_, world, rank)
+    rows = ix.synth_unit_rows(hi - lo, D, 1, row_offset=lo, device=dev)
+    clf.memory.load_rows(rows, torch.arange(NP_, dtype=torch.int32) % C, labels,
+                         sharded=ShardedSearch(rows, hi - lo, D, lo, equal_blocks=True))
+    b = B // world
+    g = torch.Generator().manual_seed(1234 + rank)
+    ids = torch.randint(1000, VOCAB, (b, S), generator=g); ids[:, 0] = 101
+    lens = torch.randint(8, S + 1, (b,), generator=g); lens[0] = S
+    mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64)
+    ids = (ids * mask).to(dev); mask = mask.to(dev); types = torch.zeros_like(ids)
+    for _ in range(warmup):
+        preds = clf.predict_tokens(ids, types, mask, k=K_)
+    _job_barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        preds = clf.predict_tokens(ids, types, mask, k=K_)
+    _job_barrier()
+    dt = _max_over_ranks(time.perf_counter() - t0, dev)
+    assert len(preds) == b
+    del clf, enc, rows
+    torch.cuda.empty_cache()
+    return {"workload": "BASELINE configs[4]: e5-large-v2 architecture (random init), %d x %d store row-sharded over %d GPUs, %d classes, "
+                        "k=%d, %d texts per step data parallel (%d per rank, <= %d tokens, ragged)" % (NP_, D, world, C, K_, b * world, b, S),
+            "value": b * world * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "rows_per_gpu": hi - lo}
+
+
 def main_multi(args, dev, rank, world):
     """The N > 1 line.  `value` = BASELINE configs[2] -- the 10M x 768 store row-sharded over the N ranks, k = 32, 4096
     queries per step, through the production exchange (strong scaling: the job is the same at every N; the one-GPU form of
@@ -786,6 +833,10 @@ def main_multi(args, dev, rank, world):
                           "value": BATCH * world * args.steps / dt, "unit": "queries/s", "scaling": "weak",
                           "ms_per_step": dt / args.steps * 1e3, "stages_ms": stages},
     }
+    if not args.no_extras:
+        del clf
+        torch.cuda.empty_cache()
+        line["configs4_data_parallel_sharded"] = cfg4_multi(dev, rank, world, steps=max(2, min(args.steps, 5)), warmup=1)
     if backend != "nccl":
         line["not_a_measurement"] = ("backend %s: ranks may share one GPU and device tensors are staged through the host -- this run "
                                      "exercises the N-rank code path only" % backend)
