@@ -734,10 +734,11 @@ class AdaptiveClassifier:
         """classifier.py:1533-1573."""
         return select_representative_examples(examples, k)
 
-    def save(self, save_dir: str, all_examples: bool = False):
+    def save(self, save_dir: str, all_examples: bool = False, include_onnx: bool = False, quantize_onnx: bool = False):
         """On-disk layout of classifier.py:524-628 (config.json, examples.json, model.safetensors).
         Like the reference, examples.json holds the k-means representatives of every class
-        (config.num_representative_examples, :560-566); `all_examples=True` (additive) writes every stored example."""
+        (config.num_representative_examples, :560-566); `all_examples=True` (additive) writes every stored example.
+        include_onnx / quantize_onnx (classifier.py:1185-1197) are accepted and ignored: ONNX export is outside this build."""
         from safetensors.torch import save_file
         d = Path(save_dir)
         d.mkdir(parents=True, exist_ok=True)
@@ -769,6 +770,32 @@ class AdaptiveClassifier:
         return clf.load_state(save_dir)
 
     _from_pretrained = load
+
+    def save_pretrained(self, save_directory: str, **kwargs):
+        """ModelHubMixin.save_pretrained for a local directory (classifier.py:524): the files save() writes."""
+        self.save(str(save_directory))
+        return str(save_directory)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, *, device: Optional[str] = None, revision: Optional[str] = None,
+                        cache_dir: Optional[str] = None, local_files_only: bool = False, token=None, trust_remote_code: bool = False,
+                        encoder=None, tokenizer=None, **kwargs):
+        """The reference's usual entry point (README: `AdaptiveClassifier.from_pretrained("adaptive-classifier/llm-router")`,
+        ModelHubMixin -> _from_pretrained, classifier.py:631-915): a local directory is loaded as it is; anything else is taken
+        for a Hub repository id and fetched with huggingface_hub.snapshot_download (config.json, examples.json,
+        model.safetensors -- the ONNX files of a repository are not needed), then loaded the same way.  Uploading
+        (push_to_hub), model cards and ONNX export stay outside this build."""
+        import os
+        path = str(pretrained_model_name_or_path)
+        if not os.path.isdir(path):
+            from huggingface_hub import snapshot_download
+            path = snapshot_download(repo_id=path, revision=revision, cache_dir=cache_dir, local_files_only=local_files_only,
+                                     token=token, allow_patterns=["config.json", "examples.json", "*.safetensors"])
+        return cls.load(path, device=device, trust_remote_code=trust_remote_code, encoder=encoder, tokenizer=tokenizer)
+
+    def push_to_hub(self, *args, **kwargs):
+        raise NotImplementedError("push_to_hub (classifier.py:917+, ModelHubMixin) is outside the MI355X hot-path build: "
+                                  "save() the classifier and upload the directory with huggingface_hub")
 
     def load_state(self, save_dir: str):
         """Restore labels, examples, prototypes and head from a directory written by save(), by the

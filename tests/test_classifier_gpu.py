@@ -128,6 +128,22 @@ def test_save_load_roundtrip(clf, tmp_path, cuda_dev):
         assert np.allclose([s for _, s in a], [s for _, s in b], atol=1e-6)
 
 
+def test_from_pretrained_and_save_pretrained_on_a_local_directory(clf, tmp_path, cuda_dev):
+    """The reference's usual entry point (README: AdaptiveClassifier.from_pretrained(...), ModelHubMixin): a local directory goes
+    through load(); save_pretrained writes what save() writes; the reference's save(dir, include_onnx, quantize_onnx) keywords are
+    accepted; push_to_hub says that it is outside this build."""
+    from adaptive_classifier import AdaptiveClassifier
+    out = clf.save_pretrained(tmp_path / "m")
+    assert (tmp_path / "m" / "config.json").exists() and out == str(tmp_path / "m")
+    clf.save(str(tmp_path / "m2"), include_onnx=True, quantize_onnx=False)
+    c2 = AdaptiveClassifier.from_pretrained(str(tmp_path / "m"), device="cuda:0", encoder=clf.model, tokenizer=HashTokenizer())
+    assert c2.label_to_id == clf.label_to_id
+    a, b = clf.predict("really great product", k=3), c2.predict("really great product", k=3)
+    assert [l for l, _ in a] == [l for l, _ in b] and np.allclose([s for _, s in a], [s for _, s in b], atol=1e-6)
+    with pytest.raises(NotImplementedError, match="push_to_hub"):
+        clf.push_to_hub("someone/some-model")
+
+
 def test_cpu_device_rejected():
     from adaptive_classifier import AdaptiveClassifier, _native as nv
     with pytest.raises(nv.NativeError):
