@@ -793,6 +793,22 @@ class AdaptiveClassifier:
                                      token=token, allow_patterns=["config.json", "examples.json", "*.safetensors"])
         return cls.load(path, device=device, trust_remote_code=trust_remote_code, encoder=encoder, tokenizer=tokenizer)
 
+    def _outside_this_build(self, what, where):
+        raise NotImplementedError(f"{what} ({where}) is outside the MI355X hot-path build (predict / add_examples); "
+                                  "use the reference package for it")
+
+    def predict_strategic(self, *args, **kwargs):
+        self._outside_this_build("strategic prediction", "classifier.py:1594+")
+
+    def predict_robust(self, *args, **kwargs):
+        self._outside_this_build("robust prediction", "classifier.py:1594+")
+
+    def evaluate_strategic_robustness(self, *args, **kwargs):
+        self._outside_this_build("strategic evaluation", "classifier.py:1594+")
+
+    def export_onnx(self, *args, **kwargs):
+        self._outside_this_build("ONNX export", "classifier.py:1031-1104")
+
     def push_to_hub(self, *args, **kwargs):
         raise NotImplementedError("push_to_hub (classifier.py:917+, ModelHubMixin) is outside the MI355X hot-path build: "
                                   "save() the classifier and upload the directory with huggingface_hub")
