@@ -23,6 +23,7 @@ class NativeError(RuntimeError):
     pass
 
 
+AC_GEMM_F32, AC_GEMM_BF16X3, AC_GEMM_F16X2 = 0, 1, 2     # include/acamd.h: ac_gemm_set_arith
 AC_BERT_LAYERED = 1     # include/acamd.h: ac_bert_encode_cls_opts never takes the one-launch path
 
 
@@ -72,7 +73,7 @@ class ac_bert_weights(ctypes.Structure):
         "word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b",
         "qkv_w", "qkv_b", "ao_w", "ao_b", "ln1_g", "ln1_b",
         "ff1_w", "ff1_b", "ff2_w", "ff2_b", "ln2_g", "ln2_b",
-        "qkv_w3", "ao_w3", "ff1_w3", "ff2_w3")]
+        "qkv_w3", "ao_w3", "ff1_w3", "ff2_w3", "qkv_wh", "ao_wh", "ff1_wh", "ff2_wh")]
 
 
 # name -> (restype, argtypes); must list every symbol include/acamd.h declares
@@ -106,11 +107,15 @@ _SIGNATURES = {
     "ac_gemm_set_variant": (c_int, [c_int]),
     "ac_gemm_debug_stamps": (c_int, [c_void_p, c_int64]),
     "ac_gemm_set_pipe_table": (c_int, [ctypes.c_char_p]),
+    "ac_gemm_set_pipe_table_f16": (c_int, [ctypes.c_char_p]),
     "ac_gemm_set_ln_fusion": (c_int, [c_int]),
     "ac_gemm_ln_fusion_launches": (c_int64, []),
     "ac_set_persistent_kernels": (c_int, [c_int]),
     "ac_gemm_occupancy": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "ac_split_bf16x3": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "ac_split_f16x2": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "ac_linear_f16x2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int,
+                                c_int, c_int, c_void_p]),
     "ac_linear_bf16x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ac_head_param_count": (c_int64, [ctypes.POINTER(ac_head_dims)]),

@@ -82,6 +82,12 @@ class AdaptiveClassifier:
             if tokenizer is None:
                 tokenizer = AutoTokenizer.from_pretrained(model_name, trust_remote_code=trust_remote_code)
         self.model = encoder
+        if (config or {}).get("gemm_arith") is not None:
+            # "f32" | "bf16x3" (the default) | "f16x2" (opt-in, include/acamd.h): process-wide, like the environment variable
+            mode = {"f32": nv.AC_GEMM_F32, "bf16x3": nv.AC_GEMM_BF16X3, "f16x2": nv.AC_GEMM_F16X2}[config["gemm_arith"]]
+            nv.check(nv.lib().ac_gemm_set_arith(mode), "ac_gemm_set_arith")
+            if mode == nv.AC_GEMM_F16X2 and hasattr(encoder, "enable_f16x2"):
+                encoder.enable_f16x2()
         if tokenizer is not None and (config or {}).get("device_tokenizer", True):
             # BERT WordPiece vocabularies are tokenised on the device (ac_wordpiece_encode); anything else stays as given
             from .tokenizer import maybe_device_tokenizer
@@ -545,6 +551,14 @@ class AdaptiveClassifier:
                                "now off for this process and the batch is encoded again")
                 nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
                 res, nan = finish(encode(True, False))
+            f16 = getattr(self.model, "f16x2_active", None)
+            if nan and f16 is not None and f16():
+                # opt-in fp16x2 arithmetic: an activation beyond fp16's range turns its rows into NaN; back to bf16x3
+                logger.warning("encoder: non-finite result under fp16x2 arithmetic; the encoder goes back to bf16x3 and the "
+                               "batch is encoded again")
+                self.model.f16x2_overflows += 1
+                self.model.disable_f16x2()
+                res, nan = finish(encode(True, False))
         return res                      # (still NaN: non-finite inputs or weights -- the caller's data, returned as computed)
 
     def _predict_regular(self, text: str, k: int = 5) -> List[Tuple[str, float]]:
@@ -563,10 +577,15 @@ class AdaptiveClassifier:
         return self._predict_with_retry(encode, finish)
 
     def predict_batch(self, texts: List[str], k: int = 5, batch_size: int = 32) -> List[List[Tuple[str, float]]]:
-        """classifier.py:1308-1388: top-k prototypes + top-k head classes, fixed 0.7/0.3 weights."""
+        """classifier.py:1308-1388: top-k prototypes + top-k head classes, fixed 0.7/0.3 weights.
+        `batch_size` bounds the reference's CPU memory (default 32); here it is a LOWER bound on the device batch: a text's result
+        does not depend on which texts share its batch (padding-free forward, exact search), and 32 texts are ~600 token rows --
+        a launch-bound encoder call -- so lists are walked in chunks of max(batch_size, config["min_device_batch"]) texts
+        (default 256, what BASELINE configs[1] is quoted on; set it to 1 to get the reference's chunking)."""
         if not texts:
             raise ValueError("Empty input batch")
         out = []
+        batch_size = max(int(batch_size), int(self.config.config.get("min_device_batch", 256)), 1)
         for i in range(0, len(texts), batch_size):
             batch = texts[i:i + batch_size]
             out.extend(self._predict_batch_core(lambda verify, force_layered: self._embed_device(

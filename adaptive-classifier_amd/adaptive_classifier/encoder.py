@@ -133,6 +133,40 @@ class HipBertEncoder:
         self.weights = w
         self._ws = None
         self.num_params = sum(t.numel() for t in self._keep)
+        self._gemm_w = {k: per[k] for k in ("qkv_w", "ao_w", "ff1_w", "ff2_w")}
+        self._planes_f16 = None               # fp16x2 weight planes (enable_f16x2)
+        self.f16x2_overflows = 0              # encode_cls calls repeated in bf16x3 because an activation left the fp16 range
+        if nv.lib().ac_gemm_get_arith() == nv.AC_GEMM_F16X2:     # AC_GEMM_ARITH=f16x2 in the environment
+            self.enable_f16x2()
+
+    # -- opt-in fp16x2 arithmetic of the token-row GEMMs (include/acamd.h: AC_GEMM_F16X2) ------
+    F16X2_MAX_WEIGHT = 63.9                   # |w| 2^10 must stay below fp16's 65504
+
+    def enable_f16x2(self):
+        """Build the fp16x2 planes of the four GEMM weights per layer (ac_split_f16x2, once) and hand them to the native
+        encoder.  They are USED while the process-wide arithmetic is AC_GEMM_F16X2 (ac_gemm_set_arith(2) or the environment
+        variable AC_GEMM_ARITH=f16x2) and the call has >= 192 token rows; see include/acamd.h for what the mode trades."""
+        if self._planes_f16 is None:
+            big = max(float(t.abs().max()) for ts in self._gemm_w.values() for t in ts)
+            if not big < self.F16X2_MAX_WEIGHT:
+                raise nv.NativeError(f"fp16x2 arithmetic: a GEMM weight of magnitude {big:g} leaves the fp16 range at scale 2^10 "
+                                     f"(|w| < {self.F16X2_MAX_WEIGHT}); keep the default bf16x3 arithmetic for this model")
+            self._planes_f16 = {k: [_split_planes_f16(t, self.device) for t in ts] for k, ts in self._gemm_w.items()}
+        L = self.ccfg.layers
+        for k, planes in self._planes_f16.items():
+            arr = (ctypes.c_void_p * L)(*[t.data_ptr() for t in planes])
+            self._arrays[k + "h"] = arr
+            setattr(self.weights, k + "h", ctypes.cast(arr, ctypes.c_void_p).value)
+        return self
+
+    def disable_f16x2(self):
+        """Back to bf16x3 for this encoder whatever the process-wide mode (the planes stay allocated)."""
+        for k in ("qkv_wh", "ao_wh", "ff1_wh", "ff2_wh"):
+            setattr(self.weights, k, None)
+        return self
+
+    def f16x2_active(self) -> bool:
+        return bool(self.weights.qkv_wh) and nv.lib().ac_gemm_get_arith() == nv.AC_GEMM_F16X2
 
     # -- the nn.Module-ish surface classifier.py touches (:1253-1255,1278-1279,1215) ----------
     def eval(self):
@@ -198,6 +232,15 @@ class HipBertEncoder:
                 nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
                 nv.check(nv.lib().ac_bert_ln_fusion_clear(nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
                          "ac_bert_ln_fusion_clear")
+                self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered)
+            if verify and layered and self.f16x2_active() and not bool(torch.isfinite(out).all()):
+                # an activation beyond fp16's range at scale 2^6 turned its rows into NaN (never into a wrong number)
+                import logging
+                logging.getLogger(__name__).warning(
+                    "encoder: non-finite embeddings under fp16x2 arithmetic (an activation beyond +-1023?); this encoder "
+                    "goes back to bf16x3 and the batch is encoded again")
+                self.f16x2_overflows += 1
+                self.disable_f16x2()
                 self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered)
         return out
 
@@ -291,6 +334,15 @@ def _split_planes(t, device):
     pl = torch.empty(3 * rows * K, dtype=torch.int16, device=device)
     with torch.cuda.device(device):           # the launch must target the weights' GPU, not the process's current one
         nv.check(nv.lib().ac_split_bf16x3(t.data_ptr(), K, rows, K, pl.data_ptr(), nv.stream_ptr(device)), "ac_split_bf16x3")
+    return pl
+
+
+def _split_planes_f16(t, device):
+    """ac_split_f16x2 of one [rows, K] fp32 weight at scale 2^10 (operand planes for AC_GEMM_F16X2)."""
+    rows, K = t.shape
+    pl = torch.empty(2 * rows * K, dtype=torch.int16, device=device)
+    with torch.cuda.device(device):
+        nv.check(nv.lib().ac_split_f16x2(t.data_ptr(), K, rows, K, 10, pl.data_ptr(), nv.stream_ptr(device)), "ac_split_f16x2")
     return pl
 
 

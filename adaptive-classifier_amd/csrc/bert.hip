@@ -29,7 +29,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // dst: the fp32 row; planes (optional): the same row as bf16x3 operand planes of a [rows, H] matrix
 __device__ __forceinline__ void layernorm_store(f32x4 (&x)[kMaxVec], int H, int lane, const float* g,
                                                 const float* b, float eps, float* dst, uint16_t* planes = nullptr,
-                                                int64_t rows = 0, int64_t row = 0) {
+                                                int64_t rows = 0, int64_t row = 0, int f16 = 0) {
     const int nv = H >> 2;
     float s = 0.f;
 #pragma unroll
@@ -57,15 +57,8 @@ __device__ __forceinline__ void layernorm_store(f32x4 (&x)[kMaxVec], int H, int 
             y.z = (x[e].z - mean) * rstd * gg.z + bb.z;
             y.w = (x[e].w - mean) * rstd * gg.w + bb.w;
             *reinterpret_cast<f32x4*>(dst + 4 * c4) = y;
-            if (planes) {     // lanes 2j, 2j+1 fill the two halves of k-slot j
-                uint2 Hh, Mm, Ll;
-                ac::split4(y, Hh, Mm, Ll);
-                uint16_t* p = planes + ac::plane_off(rows, row, 4 * c4);
-                const int64_t plane = rows * (int64_t)H;
-                *reinterpret_cast<uint2*>(p) = Hh;
-                *reinterpret_cast<uint2*>(p + plane) = Mm;
-                *reinterpret_cast<uint2*>(p + 2 * plane) = Ll;
-            }
+            if (planes)       // lanes 2j, 2j+1 fill the two halves of k-slot j
+                ac::emit_planes4(planes + ac::plane_off(rows, row, 4 * c4), rows * (int64_t)H, y, f16);
         }
     }
 }
@@ -76,7 +69,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const
                                                        int H, const float* word, const float* pos,
                                                        const float* type, const float* g, const float* b,
                                                        float eps, float* out, uint16_t* planes,
-                                                       const int32_t* __restrict__ tok_src = nullptr) {
+                                                       const int32_t* __restrict__ tok_src = nullptr, int f16 = 0) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -100,11 +93,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const
             }
         }
     }
-    layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t);
+    layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t, f16);
 }
 
 __global__ __launch_bounds__(256) void ln_kernel(const float* in, int T, int H, const float* g, const float* b,
-                                                 float eps, float* out, uint16_t* planes, int64_t in_stride) {
+                                                 float eps, float* out, uint16_t* planes, int64_t in_stride, int f16 = 0) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -115,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* in, int T, int H, 
         const int c4 = lane + 64 * e;
         if (c4 < nv) x[e] = *reinterpret_cast<const f32x4*>(in + (int64_t)t * in_stride + 4 * c4);
     }
-    layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t);
+    layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t, f16);
 }
 
 // last_hidden_state[:, 0, :] -> F.normalize(p=2, dim=1, eps=1e-12)
@@ -177,7 +170,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
                                                             float scale, float* ctx, uint16_t* ctx_planes,
                                                             const float* rope_cos, const float* rope_sin,
                                                             int window, const int32_t* __restrict__ cu = nullptr,
-                                                            int64_t total_rows = 0) {
+                                                            int64_t total_rows = 0, int f16 = 0) {
     static_assert(DHT == 64 || (DHT == 32 && !ROPE), "head dim 64, or 32 without RoPE");
     constexpr int NKB = DHT / 8;                                     // 8-dim k-blocks of the QK^T product
     const int lane = threadIdx.x;
@@ -284,12 +277,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (t ? o1[4 * g + e] : o0[4 * g + e]) * inv;
-                    uint2 Hh, Mm, Ll;
-                    ac::split4(v, Hh, Mm, Ll);
-                    uint16_t* p = ctx_planes + ac::plane_off(rows, row, head * DHT + 32 * t + 8 * g + 4 * h);
-                    *reinterpret_cast<uint2*>(p) = Hh;
-                    *reinterpret_cast<uint2*>(p + plane) = Mm;
-                    *reinterpret_cast<uint2*>(p + 2 * plane) = Ll;
+                    ac::emit_planes4(ctx_planes + ac::plane_off(rows, row, head * DHT + 32 * t + 8 * g + 4 * h), plane, v, f16);
                 }
         } else {
             float* dst = ctx + (row0 + qi) * H + head * DHT;
@@ -571,6 +559,11 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
     const bool wplanes = w->qkv_w3 && w->ao_w3 && w->ff1_w3 && w->ff2_w3;
     const bool pl = wplanes && ac::linear_takes_planes(T, H, H) && ac::linear_takes_planes(T, H, I) && (H % 8) == 0;
     // bias + residual + LayerNorm in the epilogue of the attention-output and FFN2 GEMMs (one-round launches only)
+    // AC_GEMM_F16X2 (opt-in): the same flow on fp16x2 planes when the fp16 weight planes are there and all four token-row GEMMs
+    // take the ring-staged kernel; the CLS-only tail of the last layer (fp32 activations, b rows) stays bf16x3
+    const bool f16 = pl && ac::gemm_arith() == AC_GEMM_F16X2 && w->qkv_wh && w->ao_wh && w->ff1_wh && w->ff2_wh && c.layers > 1 &&
+                     ac::linear_f16x2_takes(T, 3 * H, H) && ac::linear_f16x2_takes(T, H, H) && ac::linear_f16x2_takes(T, I, H) &&
+                     ac::linear_f16x2_takes(T, H, I);
     const bool fuse_ln = pl && c.layers > 1 && ac::pipe_ln_applies(T, H, H) && ac::pipe_ln_applies(T, H, I);
     unsigned* ln_abort = (unsigned*)base;
     hipLaunchKernelGGL(ln_verdict_roll_kernel, dim3(1), dim3(1), 0, stream, ln_abort);
@@ -581,7 +574,7 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
 
     hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, T, S, H,
                        w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x,
-                       pl ? xp : nullptr, tok_src);
+                       pl ? xp : nullptr, tok_src, (int)f16);
     AC_LAUNCH_CHECK();
     const int dh = c.hidden / c.heads;                // 64, or 32 (MiniLM family)
     const float scale = 1.0f / sqrtf((float)dh);
@@ -590,8 +583,9 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         const uint16_t* ao_w3 = wplanes ? w->ao_w3[l] : nullptr;
         const uint16_t* ff1_w3 = wplanes ? w->ff1_w3[l] : nullptr;
         const uint16_t* ff2_w3 = wplanes ? w->ff2_w3[l] : nullptr;
-        rc = ac::linear_f32(x, H, w->qkv_w[l], H, w->qkv_b[l], nullptr, 0, qkv, 3 * H, T, 3 * H, H, 0, nullptr, 1.f,
-                            stream, 0.f, 0, qkv_w3, pl ? xp : nullptr);
+        rc = f16 ? ac::linear_f16x2(xp, w->qkv_wh[l], w->qkv_b[l], nullptr, 0, qkv, 3 * H, nullptr, T, 3 * H, H, 0, stream)
+                 : ac::linear_f32(x, H, w->qkv_w[l], H, w->qkv_b[l], nullptr, 0, qkv, 3 * H, T, 3 * H, H, 0, nullptr, 1.f,
+                                  stream, 0.f, 0, qkv_w3, pl ? xp : nullptr);
         if (rc) return rc;
         const bool last = (l == c.layers - 1);
         // After the last layer's attention only the CLS row of each sequence is consumed, so the
@@ -616,50 +610,53 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         } else {
             if (dh == 64)
                 hipLaunchKernelGGL((attention_mfma_kernel<false, 64>), dim3((Smax + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv,
-                                   d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1, cu, (int64_t)T);
+                                   d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1, cu, (int64_t)T, (int)f16);
             else
                 hipLaunchKernelGGL((attention_mfma_kernel<false, 32>), dim3((Smax + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv,
-                                   d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1, cu, (int64_t)T);
+                                   d_mask, S, H, scale, ctx, lp ? ctxp : nullptr, nullptr, nullptr, -1, cu, (int64_t)T, (int)f16);
         }
         AC_LAUNCH_CHECK();
         const int lblocks = (Ml + 3) / 4;
         const bool fl = fuse_ln && lp;                 // x <- LayerNorm(x + ctx Wo^T + b) in ONE launch, in place
         if (fl) {
-            rc = ac::launch_gemm_pipe_ln(ctxp, Ml, ao_w3, H, w->ao_b[l], x, H, x, H, Ml, H, H, w->ln1_g[l], w->ln1_b[l], c.ln_eps,
-                                         base + ws.lnpart, ln_count + (size_t)(2 * l) * ln_panels, ln_abort, xp, stream);
+            rc = ac::launch_gemm_pipe_ln(ctxp, Ml, f16 ? w->ao_wh[l] : ao_w3, H, w->ao_b[l], x, H, x, H, Ml, H, H, w->ln1_g[l], w->ln1_b[l], c.ln_eps,
+                                         base + ws.lnpart, ln_count + (size_t)(2 * l) * ln_panels, ln_abort, xp, stream, (int)f16);
             if (rc) return rc;
         } else {
             // (last layer: b CLS rows = a handful of output tiles -> split-K over the qkv buffer, which is dead by now)
             rc = last ? ac::linear_f32_splitk(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, ao_w3, qkv,
                                               (size_t)T * 3 * H * sizeof(float), stream)
-                      : ac::linear_f32(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f, stream,
-                                       0.f, 0, ao_w3, lp ? ctxp : nullptr);
+                      : (f16 ? ac::linear_f16x2(ctxp, w->ao_wh[l], w->ao_b[l], resid, ldres, y, H, nullptr, Ml, H, H, 0, stream)
+                             : ac::linear_f32(ctx, H, w->ao_w[l], H, w->ao_b[l], resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f, stream,
+                                              0.f, 0, ao_w3, lp ? ctxp : nullptr));
             if (rc) return rc;
             // (last layer: x is overwritten with b compact rows; its old contents are no longer needed)
             hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln1_g[l], w->ln1_b[l],
-                               c.ln_eps, last ? ctx : x, lp ? xp : nullptr, (int64_t)H);
+                               c.ln_eps, last ? ctx : x, lp ? xp : nullptr, (int64_t)H, (int)f16);
             AC_LAUNCH_CHECK();
         }
         float* x1 = last ? ctx : x;                    // ctx is free again after the AO projection
         rc = last ? ac::linear_f32_splitk(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, ff1_w3, qkv,
                                           (size_t)T * 3 * H * sizeof(float), stream)
-                  : ac::linear_f32(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, nullptr, 1.f, stream,
-                                   0.f, 0, ff1_w3, lp ? xp : nullptr, lp ? ffnp : nullptr);
+                  : (f16 ? ac::linear_f16x2(xp, w->ff1_wh[l], w->ff1_b[l], nullptr, 0, nullptr, I, ffnp, Ml, I, H, 2, stream)
+                         : ac::linear_f32(x1, H, w->ff1_w[l], H, w->ff1_b[l], nullptr, 0, ffn, I, Ml, I, H, 2, nullptr, 1.f, stream,
+                                          0.f, 0, ff1_w3, lp ? xp : nullptr, lp ? ffnp : nullptr));
         if (rc) return rc;
         if (fl) {                                      // x <- LayerNorm(x + ffn W2^T + b), planes for the next layer's QKV GEMM
-            rc = ac::launch_gemm_pipe_ln(ffnp, Ml, ff2_w3, H, w->ff2_b[l], x, H, x, H, Ml, H, I, w->ln2_g[l], w->ln2_b[l], c.ln_eps,
-                                         base + ws.lnpart, ln_count + (size_t)(2 * l + 1) * ln_panels, ln_abort, xp, stream);
+            rc = ac::launch_gemm_pipe_ln(ffnp, Ml, f16 ? w->ff2_wh[l] : ff2_w3, H, w->ff2_b[l], x, H, x, H, Ml, H, I, w->ln2_g[l], w->ln2_b[l], c.ln_eps,
+                                         base + ws.lnpart, ln_count + (size_t)(2 * l + 1) * ln_panels, ln_abort, xp, stream, (int)f16);
             if (rc) return rc;
             continue;
         }
         rc = last ? ac::linear_f32_splitk(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, ff2_w3, qkv,
                                           (size_t)T * 3 * H * sizeof(float), stream)
-                  : ac::linear_f32(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, nullptr, 1.f, stream, 0.f, 0,
-                                   ff2_w3, lp ? ffnp : nullptr);
+                  : (f16 ? ac::linear_f16x2(ffnp, w->ff2_wh[l], w->ff2_b[l], x1, H, y, H, nullptr, Ml, H, I, 0, stream)
+                         : ac::linear_f32(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, nullptr, 1.f, stream, 0.f, 0,
+                                          ff2_w3, lp ? ffnp : nullptr));
         if (rc) return rc;
         // the next layer's QKV GEMM reads x as planes; the last layer's output (b compact rows) stays fp32
         hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln2_g[l], w->ln2_b[l],
-                           c.ln_eps, x, lp ? xp : nullptr, (int64_t)H);
+                           c.ln_eps, x, lp ? xp : nullptr, (int64_t)H, (int)f16);
         AC_LAUNCH_CHECK();
     }
     // after the CLS-only last layer x holds b compact rows (sequence stride 1)

@@ -75,7 +75,7 @@ int pipe_ln_panels(int M);
 int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias,
                         const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, const float* gamma,
                         const float* beta, float eps, void* part, unsigned* count, unsigned* abort_flag, uint16_t* planes,
-                        hipStream_t stream);
+                        hipStream_t stream, int f16 = 0);      // f16: operands AND emitted planes are fp16x2
 // true when linear_f32(M, N, K) with W planes takes the pre-split kernel (only then may A / C planes be passed)
 bool linear_takes_planes(int M, int N, int K);
 
@@ -116,6 +116,62 @@ __device__ __forceinline__ void split8(const f32x4_t& x0, const f32x4_t& x1, uin
     split2(x1[0], x1[1], H.z, M.z, L.z);
     split2(x1[2], x1[3], H.w, M.w, L.w);
 }
+// ---- fp16x2 operand planes (AC_GEMM_F16X2): x * 2^s = h + l, two fp16 terms (RNE), same plane layout, planes 0 and 1 ----
+// h = fp16(x 2^s), l = fp16(x 2^s - h): the subtraction is exact, so |x 2^s - h - l| <= max(2^-22 |x 2^s|, 2^-25) (the
+// second term: l in fp16's subnormal range).  The scale is a fixed power of two per operand KIND -- activations 2^6 (|x| <
+// 1023.5), weights 2^10 (|w| < 63.97) -- so a GEMM's result is the fp32 accumulator times 2^-16.  An operand element beyond
+// that range makes h = inf, l = -inf, hence NaN in every output it feeds: the caller sees non-finite rows and repeats the
+// call in bf16x3 (adaptive_classifier/encoder.py), it does not get a silently wrong number.
+constexpr int kF16ActLog2 = 6, kF16WLog2 = 10;
+constexpr float kF16ActScale = 64.0f, kF16OutScale = 1.0f / 65536.0f;
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h(float a, float b, float s, uint32_t& h, uint32_t& l) {
+    a *= s; b *= s;
+    const f16x2_t hv = {(_Float16)a, (_Float16)b};
+    const f16x2_t lv = {(_Float16)(a - (float)hv[0]), (_Float16)(b - (float)hv[1])};
+    h = __builtin_bit_cast(uint32_t, hv);
+    l = __builtin_bit_cast(uint32_t, lv);
+}
+__device__ __forceinline__ void split4h(const f32x4_t& x, float s, uint2& H, uint2& L) {
+    split2h(x[0], x[1], s, H.x, L.x);
+    split2h(x[2], x[3], s, H.y, L.y);
+}
+__device__ __forceinline__ void split8h(const f32x4_t& x0, const f32x4_t& x1, float s, uint4& H, uint4& L) {
+    split2h(x0[0], x0[1], s, H.x, L.x);
+    split2h(x0[2], x0[3], s, H.y, L.y);
+    split2h(x1[0], x1[1], s, H.z, L.z);
+    split2h(x1[2], x1[3], s, H.w, L.w);
+}
+// what a producer of ACTIVATION planes stores for 4 / 8 consecutive k of one row: three bf16 planes, or (f16 != 0, wave
+// uniform) the two fp16 planes; p = the element's address in plane 0, `plane` = the plane stride
+__device__ __forceinline__ void emit_planes4(uint16_t* p, int64_t plane, const f32x4_t& v, int f16) {
+    if (f16) {
+        uint2 H, L;
+        split4h(v, kF16ActScale, H, L);
+        *reinterpret_cast<uint2*>(p) = H;
+        *reinterpret_cast<uint2*>(p + plane) = L;
+    } else {
+        uint2 H, M, L;
+        split4(v, H, M, L);
+        *reinterpret_cast<uint2*>(p) = H;
+        *reinterpret_cast<uint2*>(p + plane) = M;
+        *reinterpret_cast<uint2*>(p + 2 * plane) = L;
+    }
+}
+__device__ __forceinline__ void emit_planes8(uint16_t* p, int64_t plane, const f32x4_t& v0, const f32x4_t& v1, int f16) {
+    if (f16) {
+        uint4 H, L;
+        split8h(v0, v1, kF16ActScale, H, L);
+        *reinterpret_cast<uint4*>(p) = H;
+        *reinterpret_cast<uint4*>(p + plane) = L;
+    } else {
+        uint4 H, M, L;
+        split8(v0, v1, H, M, L);
+        *reinterpret_cast<uint4*>(p) = H;
+        *reinterpret_cast<uint4*>(p + plane) = M;
+        *reinterpret_cast<uint4*>(p + 2 * plane) = L;
+    }
+}
 // element offset (uint16 units) of (row, k) inside one plane of a [rows, K] operand: planes[p][k/8][row][k%8]
 __device__ __forceinline__ int64_t plane_off(int64_t rows, int64_t row, int k) {
     return ((int64_t)(k >> 3) * rows + row) * 8 + (k & 7);
@@ -137,9 +193,15 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
                      const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int segs, int64_t row_stride,
                      int best_only, hipStream_t stream, int32_t* clear_ctr = nullptr, int32_t* clear_stats = nullptr);
 
-// arithmetic of the LDS-tiled GEMMs (ac_gemm_set_arith / env AC_GEMM_ARITH = f32 | bf16x3)
+// arithmetic of the LDS-tiled GEMMs (ac_gemm_set_arith / env AC_GEMM_ARITH = f32 | bf16x3 | f16x2)
 int gemm_arith();
 void set_gemm_arith(int mode);
+inline bool arith_split() { return gemm_arith() != AC_GEMM_F32; }   // bf16x3, or f16x2 (= bf16x3 wherever no fp16 planes exist)
+// C = epi(A W^T) on fp16x2 operand planes (gemm_pipe.hip only): A planes at scale 2^kF16ActLog2, W planes at 2^kF16WLog2.
+// C fp32 rows, or (Cp) the fp16x2 activation planes of the next GEMM.  act: 0 none, 2 gelu (planes output only).
+bool linear_f16x2_takes(int M, int N, int K);
+int linear_f16x2(const uint16_t* Ap, const uint16_t* Wp, const float* bias, const float* residual, int64_t ldr, float* C,
+                 int64_t ldc, uint16_t* Cp, int M, int N, int K, int act, hipStream_t stream);
 //   C = alpha * op(A) op(B) + beta * C; if gate != null: C = gate[m,n] != 0 ? C * gate_scale : 0
 int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
              const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* gate,

@@ -296,6 +296,22 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     *reinterpret_cast<uint4*>(dst + 2 * plane) = L;
 }
 
+// the two fp16 planes of X 2^s (AC_GEMM_F16X2; common.h split2h), same unit -> thread mapping
+__global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows,
+                                                               int K, float scale, uint16_t* __restrict__ P) {
+    const int nq = K >> 3;
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= rows * nq) return;
+    const int64_t row = u / nq;
+    const int q = (int)(u - row * nq);
+    const float* src = X + row * ldx + 8 * q;
+    uint4 H, L;
+    ac::split8h(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), scale, H, L);
+    uint16_t* dst = P + ((int64_t)q * rows + row) * 8;
+    *reinterpret_cast<uint4*>(dst) = H;
+    *reinterpret_cast<uint4*>(dst + rows * (int64_t)K) = L;
+}
+
 constexpr int SBK = 16;   // k per stage = one bf16 MFMA chunk
 
 // C[M,N] = epi(A . W^T) with W given as planes; A as fp32 (split while staged) or as planes.
@@ -726,7 +742,7 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         const int cus = ac::dev_info().cus;
         const int64_t ntn = (N + BN - 1) / BN;
         const int64_t b128 = (int64_t)((M + 127) / 128) * ntn, b64 = (int64_t)((M + 63) / 64) * ntn;
-        const int r128 = ac::gemm_arith() == AC_GEMM_BF16X3 ? 3 : 2, r64 = r128 + 1;   // resident blocks per CU
+        const int r128 = ac::arith_split() ? 3 : 2, r64 = r128 + 1;   // resident blocks per CU
         const int64_t cost128 = ((b128 + r128 * cus - 1) / (r128 * cus)) * 128 * r128;
         const int64_t cost64 = ((b64 + r64 * cus - 1) / (r64 * cus)) * 64 * r64;
         // the 128-row tile does ~15 % more work per staged byte: take the 64-row one only for a clear win
@@ -744,7 +760,7 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         AC_REQUIRE(epi.act != ACT_GEGLU32 || (cls == EPI_GEGLU32 && Cp && (N % 64) == 0), AC_EUNSUPPORTED,
                    "gemm: the fused GeGLU epilogue needs planes output, a bias vector and N %% 64 == 0");
         const dim3 grid((unsigned)nblk), block(kTileThreads);
-        const bool split = ac::gemm_arith() == AC_GEMM_BF16X3;
+        const bool split = ac::arith_split();
         const bool planes = split && Bp != nullptr;      // (K % 32 == 0 here, so K % SBK == 0)
 #define AC_LAUNCH_PLANES(E, AP)                                                                               \
     do {                                                                                                      \
@@ -845,7 +861,8 @@ int gemm_arith() {
     int v = g_gemm_arith.load(std::memory_order_relaxed);
     if (v < 0) {
         v = AC_GEMM_BF16X3;
-        if (const char* e = getenv("AC_GEMM_ARITH")) v = (strcmp(e, "f32") == 0) ? AC_GEMM_F32 : AC_GEMM_BF16X3;
+        if (const char* e = getenv("AC_GEMM_ARITH"))
+            v = (strcmp(e, "f32") == 0) ? AC_GEMM_F32 : (strcmp(e, "f16x2") == 0) ? AC_GEMM_F16X2 : AC_GEMM_BF16X3;
         g_gemm_arith.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -863,7 +880,7 @@ int gemm_variant() {
 }
 bool linear_takes_planes(int M, int N, int K) {
     // mirrors launch_gemm: not the small-M kernel, the LDS-tiled path, split arithmetic
-    return gemm_arith() == AC_GEMM_BF16X3 && !(M <= 64 && N >= 16) && M >= 192 && K >= 32 && (K % 32) == 0 && N >= 1;
+    return arith_split() && !(M <= 64 && N >= 16) && M >= 192 && K >= 32 && (K % 32) == 0 && N >= 1;
 }
 // internal entry used by head.hip / bert.hip
 int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
@@ -876,6 +893,25 @@ int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const f
     e.drop_p = mask ? 0.f : drop_p; e.drop_seed = drop_seed;
     return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream, Wp, N, Ap, M, Cp);
 }
+// fp16x2 planes in, ring-staged kernels only (the BERT encoder under AC_GEMM_F16X2; ac_linear_f16x2)
+bool linear_f16x2_takes(int M, int N, int K) {
+    const int v = gemm_variant();
+    return (v == 0 || v >= 1000) && M >= 192 && N >= 8 && (N % 8) == 0 && (K % 32) == 0 && K >= 64;
+}
+int linear_f16x2(const uint16_t* Ap, const uint16_t* Wp, const float* bias, const float* residual, int64_t ldr, float* C,
+                 int64_t ldc, uint16_t* Cp, int M, int N, int K, int act, hipStream_t stream) {
+    AC_REQUIRE(Ap && Wp && bias && (C || Cp), AC_EINVAL, "linear_f16x2: null pointer");
+    AC_REQUIRE(linear_f16x2_takes(M, N, K), AC_EUNSUPPORTED, "linear_f16x2: %d x %d x %d does not take the ring-staged kernel", M, N, K);
+    AC_REQUIRE((act == ACT_NONE || (act == ACT_GELU && Cp)) && !(Cp && residual), AC_EUNSUPPORTED,
+               "linear_f16x2: act %d / residual / planes-out combination not built", act);
+    Epilogue e;
+    e.bias = bias; e.residual = residual; e.ldr = ldr; e.act = act; e.alpha = 1.f; e.beta = 0.f; e.mask = nullptr;
+    e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;
+    const int cls = act == ACT_GELU ? EPI_BIAS_GELU : (residual ? EPI_BIAS_RES : EPI_BIAS);
+    const int v = gemm_variant();
+    const int cfg = v >= 1000 ? v : pipe_choose_f16(M, N, K);
+    return launch_gemm_pipe(cfg, Ap, M, Wp, N, C, ldc, Cp, M, N, K, cls, e, stream, 1);
+}
 // linear_f32 for shapes with few output tiles: split-K over `scratch` (see gemm_planes_splitk_nt); falls back to
 // linear_f32 when the shape has enough tiles, the arithmetic is not bf16x3, or the scratch is too small.
 int linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,
@@ -884,7 +920,7 @@ int linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, 
     const int cus = dev_info().cus;
     const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + BN - 1) / BN);
     int ksplit = 1;
-    if (Wp && scratch && gemm_arith() == AC_GEMM_BF16X3 && gemm_variant() == 0 && M >= 65 && M <= 512 && (N % 4) == 0 &&
+    if (Wp && scratch && arith_split() && gemm_variant() == 0 && M >= 65 && M <= 512 && (N % 4) == 0 &&
         (K % 32) == 0 && (lda % 4) == 0 && ((((uintptr_t)A) & 15) == 0) && 2 * tiles <= cus) {
         const int nk = K / SBK;
         // as many slices as fill ~1.5 workgroups per CU, each at least 6 stages long, dividing the stage count
@@ -954,7 +990,7 @@ extern "C" int ac_gemm_f32(int transA, int transB, int M, int N, int K, float al
 }
 
 extern "C" int ac_gemm_set_arith(int mode) {
-    AC_REQUIRE(mode == AC_GEMM_F32 || mode == AC_GEMM_BF16X3, AC_EINVAL, "gemm arith: unknown mode %d", mode);
+    AC_REQUIRE(mode == AC_GEMM_F32 || mode == AC_GEMM_BF16X3 || mode == AC_GEMM_F16X2, AC_EINVAL, "gemm arith: unknown mode %d", mode);
     ac::set_gemm_arith(mode);
     return AC_OK;
 }
@@ -977,6 +1013,29 @@ extern "C" int ac_split_bf16x3(const float* d_X, int64_t ldx, int64_t rows, int 
                        d_X, ldx, rows, K, d_planes);
     AC_LAUNCH_CHECK();
     return AC_OK;
+}
+
+extern "C" int ac_split_f16x2(const float* d_X, int64_t ldx, int64_t rows, int K, int scale_log2, uint16_t* d_planes,
+                              ac_stream_t stream) {
+    AC_REQUIRE(d_X && d_planes, AC_EINVAL, "split: null pointer");
+    AC_REQUIRE(rows >= 0 && K >= 8 && (K % 8) == 0 && ldx >= K && (ldx % 4) == 0 && (((uintptr_t)d_X) & 15) == 0 &&
+                   (((uintptr_t)d_planes) & 15) == 0 && scale_log2 >= -14 && scale_log2 <= 15,
+               AC_EINVAL, "split: K=%d must be a multiple of 8, rows 16-byte aligned, scale 2^%d", K, scale_log2);
+    if (rows == 0) return AC_OK;
+    const int64_t units = rows * (K / 8);
+    hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_X, ldx, rows, K, ldexpf(1.0f, scale_log2), d_planes);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
+
+extern "C" int ac_linear_f16x2(const uint16_t* d_A_planes, const uint16_t* d_W_planes, const float* d_bias,
+                               const float* d_residual, int64_t ldr, float* d_C, int64_t ldc, uint16_t* d_C_planes, int M,
+                               int N, int K, int act, ac_stream_t stream) {
+    AC_REQUIRE(M >= 1 && N >= 1 && K >= 1 && (d_C_planes || ldc >= N) && (!d_residual || ldr >= N), AC_EINVAL,
+               "linear_f16x2: bad shape M=%d N=%d K=%d", M, N, K);
+    return ac::linear_f16x2(d_A_planes, d_W_planes, d_bias, d_residual, ldr, d_C, ldc, d_C_planes, M, N, K, act,
+                            (hipStream_t)stream);
 }
 
 extern "C" int ac_linear_bf16x3(const float* d_A, int64_t lda, const uint16_t* d_A_planes, const float* d_W,

@@ -135,7 +135,7 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* __restr
 constexpr int kTrLd = 36;                                  // padded row of the 32x32 transpose scratch (floats)
 constexpr int kTrFloats = 32 * kTrLd;                      // per wave
 
-template <int EPI, int TM, int TN = 2>
+template <int EPI, int TM, int TN = 2, int AR = 3>
 __device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][TN], uint16_t* __restrict__ Cp, int M, int N,
                                                   int m0, int n0, int wm, int wn, int lane, const Epilogue& epi,
                                                   float* scratch /* this wave's kTrFloats floats of LDS */) {
@@ -172,14 +172,8 @@ __device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][TN], uint16_
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(scratch + rr * kTrLd + 8 * q + 4);
                 const int64_t row = rbase + rr;
                 const int cq = c0 + 8 * q;
-                if (row < M && cq < NO) {
-                    uint4 H, Mi, L;
-                    ac::split8(v0, v1, H, Mi, L);
-                    uint16_t* dst = Cp + ac::plane_off(M, row, cq);
-                    *reinterpret_cast<uint4*>(dst) = H;              // (N % 8 == 0: checked at launch)
-                    *reinterpret_cast<uint4*>(dst + plane) = Mi;
-                    *reinterpret_cast<uint4*>(dst + 2 * plane) = L;
-                }
+                if (row < M && cq < NO)                              // (N % 8 == 0: checked at launch)
+                    ac::emit_planes8(Cp + ac::plane_off(M, row, cq), plane, v0, v1, AR == 2);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -188,6 +182,7 @@ __device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][TN], uint16_
 
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
@@ -206,7 +201,8 @@ namespace ac {
 // gemm_pipe.hip: the planes GEMM with its operand stages in an LDS ring (counted vmcnt, raw barrier)
 bool pipe_takes(int M, int N, int K, int cls, bool c_planes);
 int pipe_choose(int M, int N, int K, int cls, bool c_planes);   // 0 = keep the two-buffer tile kernels of gemm.hip
+int pipe_choose_f16(int M, int N, int K);                        // fp16x2 operands (never 0: there is no other kernel for them)
 int launch_gemm_pipe(int cfg, const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, float* C, int64_t ldc,
-                     uint16_t* Cp, int M, int N, int K, int cls, const acg::Epilogue& epi, hipStream_t stream);
+                     uint16_t* Cp, int M, int N, int K, int cls, const acg::Epilogue& epi, hipStream_t stream, int f16 = 0);
 int gemm_variant();            // diagnostic switch (ac_gemm_set_variant): 0 = default dispatch, 1 = two-buffer kernels only, >= 1000 = one ring configuration
 }  // namespace ac

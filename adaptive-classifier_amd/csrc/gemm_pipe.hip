@@ -54,13 +54,14 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TM, int TN, int WMW, int WNW, int NS> struct PipeGeom {
+// AR = operand planes per stage: 3 = bf16x3 (six bf16 products), 2 = fp16x2 (three fp16 products, AC_GEMM_F16X2)
+template <int TM, int TN, int WMW, int WNW, int NS, int AR = 3> struct PipeGeom {
     static constexpr int BM = 32 * TM * WMW, BN = 32 * TN * WNW;
     static constexpr int RA = BM / 32, RW = BN / 32, RG = RA + RW;      // 32-row groups per stage
-    static constexpr int NP = 3 * RG;                                    // 1 KB DMA pieces per stage
+    static constexpr int NP = AR * RG;                                   // 1 KB DMA pieces per stage
     static constexpr int NW = WMW * WNW;                                 // waves
     static constexpr int PPW = (NP + NW - 1) / NW;                       // pieces per wave and stage (excess = duplicates)
-    static constexpr int SLOT = 3 * RG * 64;                             // uint4 per ring slot
+    static constexpr int SLOT = AR * RG * 64;                            // uint4 per ring slot
     static constexpr int LDS_BYTES = NS * SLOT * 16;
     static constexpr int TR_BYTES = NW * kTrFloats * 4;                  // transpose scratch of the planes epilogue
     static constexpr int BPC_LDS = (160 * 1024) / (LDS_BYTES > TR_BYTES ? LDS_BYTES : TR_BYTES);
@@ -94,7 +95,7 @@ __device__ __forceinline__ void ln_prefetch_residual(float (&res)[TM * TN * 16],
 // device by two processes could still starve each other: the wait is bounded and the rows turn NaN, which the host reports) -- then
 // combines the partials (Chan et al.: equal counts), normalises its accumulators in place and stores them twice.
 // Replaces a separate LayerNorm launch (read fp32 y, write fp32 x + planes: 20 us at 5141 x 768) by ~3 us of exchange.
-template <int TM, int TN, int WMW, int WNW>
+template <int TM, int TN, int WMW, int WNW, int AR>
 __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float (&res)[TM * TN * 16], const PipeParams& prm,
                                               int bm, int bn, int ntn, int wm, int wn, int lane, int tid, int wave, float* lds_f) {
     constexpr int BM = 32 * TM * WMW, BN = 32 * TN * WNW, NW = WMW * WNW, WC = 32 * TN;
@@ -206,16 +207,17 @@ __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float
     // 7. fp32 rows (later residuals) and the operand planes of the next GEMM
     store_tile<EPI_IDENT, TM, BM, TN>(acc, prm.C, prm.ldc, prm.M, prm.N, m0, n0, wm, wn, lane, e);
     if (ln.planes)
-        store_tile_planes<EPI_IDENT, TM, TN>(acc, ln.planes, prm.M, prm.N, m0, n0, wm, wn, lane, e, lds_f + wave * kTrFloats);
+        store_tile_planes<EPI_IDENT, TM, TN, AR>(acc, ln.planes, prm.M, prm.N, m0, n0, wm, wn, lane, e, lds_f + wave * kTrFloats);
 }
 
-template <int EPI, int TM, int TN, int WMW, int WNW, int NS, bool C_PLANES, int PIPE>
-__global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS>::WAVES_PER_SIMD)) void gemm_pipe_nt(PipeParams prm) {
-    using G = PipeGeom<TM, TN, WMW, WNW, NS>;
+template <int EPI, int TM, int TN, int WMW, int WNW, int NS, bool C_PLANES, int PIPE, int AR = 3>
+__global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>::WAVES_PER_SIMD)) void gemm_pipe_nt(PipeParams prm) {
+    using G = PipeGeom<TM, TN, WMW, WNW, NS, AR>;
+    static_assert(AR == 3 || AR == 2, "operand planes: 3 = bf16x3, 2 = fp16x2");
     constexpr int BM = G::BM, BN = G::BN, RA = G::RA, RG = G::RG, NP = G::NP, NW = G::NW, PPW = G::PPW, SLOT = G::SLOT;
     static_assert(PIPE == 0 || NS >= 3, "the software-pipelined loop needs a ring of >= 3 stages");
     static_assert(NS >= 2, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [NS][3 planes][RG groups][64 lanes]
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [NS][AR planes][RG groups][64 lanes]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -270,26 +272,35 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS>::WA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    struct Frags { bf16x8_t a[TM][3], b[TN][3]; };
+    struct Frags { uint4 a[TM][AR], b[TN][AR]; };
     auto read_frags = [&](Frags& F, int slot) {
         const uint4* base = lds + slot * SLOT + lane;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < AR; ++p) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) F.a[a][p] = __builtin_bit_cast(bf16x8_t, base[(p * RG + TM * wm + a) * 64]);
+            for (int a = 0; a < TM; ++a) F.a[a][p] = base[(p * RG + TM * wm + a) * 64];
 #pragma unroll
-            for (int b = 0; b < TN; ++b) F.b[b][p] = __builtin_bit_cast(bf16x8_t, base[(p * RG + RA + TN * wn + b) * 64]);
+            for (int b = 0; b < TN; ++b) F.b[b][p] = base[(p * RG + RA + TN * wn + b) * 64];
         }
     };
+    constexpr int NPROD = AR == 3 ? 6 : 3;
     auto mfmas = [&](const Frags& F) {
-        constexpr int PAIRS[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};   // smallest products first
+        // smallest products first: bf16x3 (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); fp16x2 (l,h) (h,l) (h,h)
+        constexpr int PAIRS3[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+        constexpr int PAIRS2[3][2] = {{1, 0}, {0, 1}, {0, 0}};
 #pragma unroll
-        for (int pr = 0; pr < 6; ++pr)
+        for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][PAIRS[pr][0]], F.b[b][PAIRS[pr][1]], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TN; ++b) {
+                    if constexpr (AR == 3)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, F.a[a][PAIRS3[pr][0]]),
+                                                                            __builtin_bit_cast(bf16x8_t, F.b[b][PAIRS3[pr][1]]), acc[a][b], 0, 0, 0);
+                    else
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, F.a[a][PAIRS2[pr][0]]),
+                                                                           __builtin_bit_cast(f16x8_t, F.b[b][PAIRS2[pr][1]]), acc[a][b], 0, 0, 0);
+                }
     };
 
     // ---- prologue: NS - 1 stages in flight, stage 0 landed and visible ----
@@ -305,7 +316,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS>::WA
         Frags F0, F1;
         read_frags(F0, 0);
         int slot = 1 % NS;                                              // ring slot of stage s + 1
-        constexpr int NREAD = 3 * (TM + TN), NMFMA = 6 * TM * TN, MPR = NMFMA / NREAD;   // MFMAs pinned in front of each read
+        constexpr int NREAD = AR * (TM + TN), NMFMA = NPROD * TM * TN, MPR = NMFMA / NREAD;   // MFMAs pinned in front of each read
+        static_assert(MPR >= 1, "at least one MFMA per fragment read");
 #define AC_PIPE_STEP(FC, FN)                                                                                     \
         do {                                                                                                     \
             wait_vm<(NS - 3) * PPW>();                   /* this wave's pieces of stage s + 1 have landed */      \
@@ -346,16 +358,24 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS>::WA
     }
     wait_vm<0>();                                                       // the over-issued tail stages: LDS is about to be reused / released
     stamp(prm, wave, 2);
+    if constexpr (AR == 2) {                                            // operands were x 2^6 and w 2^10
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] *= ac::kF16OutScale;
+    }
     if constexpr (EPI == EPI_BIAS_RES_LN) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                                   // nobody's DMA may land in the epilogue's LDS scratch
         __builtin_amdgcn_sched_barrier(0);
-        store_tile_ln<TM, TN, WMW, WNW>(acc, lnres, prm, bm, bn, ntn, wm, wn, lane, tid, wave, reinterpret_cast<float*>(lds));
+        store_tile_ln<TM, TN, WMW, WNW, AR>(acc, lnres, prm, bm, bn, ntn, wm, wn, lane, tid, wave, reinterpret_cast<float*>(lds));
     } else if (C_PLANES) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                                   // nobody's DMA may land in the transpose scratch
         __builtin_amdgcn_sched_barrier(0);
-        store_tile_planes<EPI, TM, TN>(acc, reinterpret_cast<uint16_t*>(prm.C), prm.M, prm.N, m0, n0, wm, wn, lane, prm.epi,
+        store_tile_planes<EPI, TM, TN, AR>(acc, reinterpret_cast<uint16_t*>(prm.C), prm.M, prm.N, m0, n0, wm, wn, lane, prm.epi,
                                        reinterpret_cast<float*>(lds) + wave * kTrFloats);
     } else {
         store_tile<EPI, TM, BM, TN>(acc, prm.C, prm.ldc, prm.M, prm.N, m0, n0, wm, wn, lane, prm.epi);
@@ -366,21 +386,34 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS>::WA
 unsigned long long* g_stamps = nullptr;      // ac_gemm_debug_stamps
 int64_t g_stamp_cap = 0;
 
-template <int EPI, int TM, int TN, int WMW, int WNW, int NS, bool CP, int PIPE>
+template <int EPI, int TM, int TN, int WMW, int WNW, int NS, bool CP, int PIPE, int AR = 3>
 int launch_one(PipeParams p, hipStream_t stream) {
-    using G = PipeGeom<TM, TN, WMW, WNW, NS>;
+    using G = PipeGeom<TM, TN, WMW, WNW, NS, AR>;
     const int64_t tiles = (int64_t)((p.M + G::BM - 1) / G::BM) * ((p.N + G::BN - 1) / G::BN);
     constexpr int LN_BYTES = G::TR_BYTES + (WNW + 1) * G::BM * 8 + 16;                       // EPI_BIAS_RES_LN scratch
     const size_t lds = EPI == EPI_BIAS_RES_LN ? (size_t)(G::LDS_BYTES > LN_BYTES ? G::LDS_BYTES : LN_BYTES)
                                               : (size_t)(G::LDS_BYTES > G::TR_BYTES || !CP ? G::LDS_BYTES : G::TR_BYTES);
     static std::atomic<unsigned long long> attr_set{0};                // (per instantiation and, inside, per device)
     if (ac::first_call_on_device(attr_set))
-        AC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE>,
+        AC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE, AR>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.stamps = (g_stamps && tiles <= g_stamp_cap) ? g_stamps : nullptr;
-    hipLaunchKernelGGL((gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE>), dim3((unsigned)tiles), dim3(64 * WMW * WNW), lds, stream, p);
+    hipLaunchKernelGGL((gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE, AR>), dim3((unsigned)tiles), dim3(64 * WMW * WNW), lds, stream, p);
     AC_LAUNCH_CHECK();
     return AC_OK;
+}
+
+// fp16x2 operands: what the BERT layer needs -- QKV (bias), FFN1 (bias + GELU -> planes), AO / FFN2 (bias + residual [+ LN])
+template <int TM, int TN, int WMW, int WNW, int NS, int PIPE>
+int launch_cfg_f16(int cls, bool cp, const PipeParams& p, hipStream_t stream) {
+    if (cp && cls == EPI_BIAS_GELU) return launch_one<EPI_BIAS_GELU, TM, TN, WMW, WNW, NS, true, PIPE, 2>(p, stream);
+    if (cp && cls == EPI_BIAS) return launch_one<EPI_BIAS, TM, TN, WMW, WNW, NS, true, PIPE, 2>(p, stream);
+    if (!cp && cls == EPI_BIAS) return launch_one<EPI_BIAS, TM, TN, WMW, WNW, NS, false, PIPE, 2>(p, stream);
+    if (!cp && cls == EPI_BIAS_RES) return launch_one<EPI_BIAS_RES, TM, TN, WMW, WNW, NS, false, PIPE, 2>(p, stream);
+    if constexpr (TM == 1 && TN == 2 && WMW == 4 && WNW == 2 && NS == 6 && PIPE == 2)
+        if (!cp && cls == EPI_BIAS_RES_LN) return launch_one<EPI_BIAS_RES_LN, TM, TN, WMW, WNW, NS, false, PIPE, 2>(p, stream);
+    ac::set_error("gemm_pipe: epilogue class %d (planes out %d) not built for fp16x2 operands", cls, (int)cp);
+    return AC_EUNSUPPORTED;
 }
 
 // the (EPI, C_PLANES) combinations the encoders use
@@ -429,6 +462,13 @@ bool pipe_takes(int M, int N, int K, int cls, bool c_planes) {
     X(3, 2, 2, 4, 3, 2) /* 192 x 256, 8 waves of 96 x 64, ring of 3 */                              \
     X(2, 4, 4, 2, 3, 2) /* 256 x 256, 8 waves of 64 x 128, ring of 3 */
 
+// fp16x2 operands only: a stage is 2/3 of the bytes and half the matrix-pipe time, so the same tiles with deeper rings
+#define AC_PIPE_CONFIGS_F16(X)                                                                     \
+    X(2, 4, 4, 2, 4, 2) /* 256 x 256, ring of 4 (128 KB) */                                          \
+    X(2, 3, 4, 2, 4, 2) /* 256 x 192, ring of 4 */                                                   \
+    X(2, 2, 4, 2, 6, 2) /* 256 x 128, ring of 6 */                                                   \
+    X(1, 2, 4, 2, 8, 2) /* 128 x 128, 8 waves, ring of 8 */
+
 // per-shape configuration of the default dispatch (0 = the two-buffer tile kernels).  A runtime table (ac_gemm_set_pipe_table,
 // tuning / A-B runs) takes precedence over the built-in choice.
 struct PipeRule { int N, K, cfg; };
@@ -442,12 +482,26 @@ static int g_nrules = -1;          // -1: no runtime table
 // reproduces the measured best (or a configuration within ~2 % of it) on every bert-base / bert-large shape at ~5 k and ~20 k
 // packed token rows.  The two-buffer kernels of gemm.hip are not candidates: no measured shape has them ahead of the best
 // ring configuration (they stay for A given as fp32, for epilogues outside pipe_takes, and behind ac_gemm_set_variant(1)).
+static PipeRule g_rules_f16[16];
+static int g_nrules_f16 = -1;
+static int builtin_choose(int M, int N, int K, int cls);
 int pipe_choose(int M, int N, int K, int cls, bool c_planes) {
-    (void)c_planes; (void)K;
+    (void)c_planes;
     if (g_nrules >= 0) {
         for (int i = 0; i < g_nrules; ++i) if (g_rules[i].N == N && g_rules[i].K == K) return g_rules[i].cfg;
         return 0;
     }
+    return builtin_choose(M, N, K, cls);
+}
+// fp16x2 operands: its own runtime table (ac_gemm_set_pipe_table_f16), else the tile the bf16x3 rule picks -- the round
+// quantisation argument is the same, and the fused-LayerNorm launches need the same 128 x 128 tile in both arithmetics
+int pipe_choose_f16(int M, int N, int K) {
+    if (g_nrules_f16 >= 0)
+        for (int i = 0; i < g_nrules_f16; ++i) if (g_rules_f16[i].N == N && g_rules_f16[i].K == K && g_rules_f16[i].cfg) return g_rules_f16[i].cfg;
+    return builtin_choose(M, N, K, EPI_BIAS);
+}
+static int builtin_choose(int M, int N, int K, int cls) {
+    (void)K;
     const int64_t cus = dev_info().cus;
     struct Cand { int cfg, bm, bn; double s; };
     static const Cand cands[] = {
@@ -468,7 +522,7 @@ int pipe_choose(int M, int N, int K, int cls, bool c_planes) {
 }
 
 int launch_gemm_pipe(int cfg, const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, float* C, int64_t ldc,
-                     uint16_t* Cp, int M, int N, int K, int cls, const acg::Epilogue& epi, hipStream_t stream) {
+                     uint16_t* Cp, int M, int N, int K, int cls, const acg::Epilogue& epi, hipStream_t stream, int f16) {
     PipeParams p;
     p.Ap = Ap; p.a_rows = a_rows; p.Wp = Wp; p.w_rows = w_rows;
     p.C = Cp ? reinterpret_cast<float*>(Cp) : C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epi;
@@ -476,8 +530,13 @@ int launch_gemm_pipe(int cfg, const uint16_t* Ap, int64_t a_rows, const uint16_t
     p.stamps = nullptr;
     const bool cp = Cp != nullptr;
 #define AC_CASE(TM, TN, WMW, WNW, NS, PIPE) \
-    if (cfg == (((((TM * 10 + TN) * 10 + WMW) * 10 + WNW) * 10 + NS) * 10 + PIPE)) return launch_cfg<TM, TN, WMW, WNW, NS, PIPE>(cls, cp, p, stream);
+    if (!f16 && cfg == (((((TM * 10 + TN) * 10 + WMW) * 10 + WNW) * 10 + NS) * 10 + PIPE)) return launch_cfg<TM, TN, WMW, WNW, NS, PIPE>(cls, cp, p, stream);
     AC_PIPE_CONFIGS(AC_CASE)
+#undef AC_CASE
+#define AC_CASE(TM, TN, WMW, WNW, NS, PIPE) \
+    if (f16 && cfg == (((((TM * 10 + TN) * 10 + WMW) * 10 + WNW) * 10 + NS) * 10 + PIPE)) return launch_cfg_f16<TM, TN, WMW, WNW, NS, PIPE>(cls, cp, p, stream);
+    AC_PIPE_CONFIGS(AC_CASE)
+    AC_PIPE_CONFIGS_F16(AC_CASE)
 #undef AC_CASE
     set_error("gemm_pipe: configuration %d not built", cfg);
     return AC_EUNSUPPORTED;
@@ -500,7 +559,7 @@ bool ln_fusion_enabled() {
 // The launch must be ONE round of one workgroup per CU (all tiles of a row panel co-resident) and the default dispatch must
 // pick the 128 x 128 eight-wave tile for the shape anyway.
 bool pipe_ln_applies(int M, int N, int K) {
-    if (!ln_fusion_enabled() || gemm_arith() != AC_GEMM_BF16X3 || gemm_variant() != 0) return false;
+    if (!ln_fusion_enabled() || !arith_split() || gemm_variant() != 0) return false;
     if (M < 192 || (N % kLnBN) != 0 || N / kLnBN > 8 || (K % 32) != 0 || K < 64) return false;
     const int64_t tiles = (int64_t)((M + kLnBM - 1) / kLnBM) * (N / kLnBN);
     return tiles <= dev_info().cus && pipe_choose(M, N, K, EPI_BIAS_RES, false) == kLnCfg;
@@ -511,7 +570,7 @@ int pipe_ln_panels(int M) { return (M + kLnBM - 1) / kLnBM; }
 int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias,
                         const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, const float* gamma,
                         const float* beta, float eps, void* part, unsigned* count, unsigned* abort_flag, uint16_t* planes,
-                        hipStream_t stream) {
+                        hipStream_t stream, int f16) {
     AC_REQUIRE(pipe_ln_applies(M, N, K), AC_EUNSUPPORTED, "gemm_pipe: fused LayerNorm epilogue not applicable to %d x %d x %d", M, N, K);
     AC_REQUIRE(Ap && Wp && bias && residual && C && gamma && beta && part && count && abort_flag, AC_EINVAL, "gemm_pipe_ln: null pointer");
     PipeParams p;
@@ -524,7 +583,8 @@ int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, 
     p.ln.planes = planes; p.ln.starve = g_ln_fusion.load(std::memory_order_relaxed) == 2 ? 1 : 0;
     p.stamps = nullptr;
     g_ln_launches.fetch_add(1, std::memory_order_relaxed);
-    return launch_cfg<1, 2, 4, 2, 6, 2>(EPI_BIAS_RES_LN, false, p, stream);
+    return f16 ? launch_cfg_f16<1, 2, 4, 2, 6, 2>(EPI_BIAS_RES_LN, false, p, stream)
+               : launch_cfg<1, 2, 4, 2, 6, 2>(EPI_BIAS_RES_LN, false, p, stream);
 }
 }  // namespace ac
 
@@ -539,17 +599,20 @@ extern "C" int ac_gemm_set_ln_fusion(int on) {
 
 extern "C" int64_t ac_gemm_ln_fusion_launches(void) { return (int64_t)ac::g_ln_launches.load(std::memory_order_relaxed); }
 
-extern "C" int ac_gemm_set_pipe_table(const char* spec) {
-    if (!spec) { ac::g_nrules = -1; return AC_OK; }
+static int parse_pipe_table(const char* spec, ac::PipeRule* rules, int* nrules) {
+    if (!spec) { *nrules = -1; return AC_OK; }
     int n = 0;
     const char* p = spec;
     while (*p && n < 16) {
         int N = 0, K = 0, cfg = 0, used = 0;
         if (sscanf(p, "%dx%d=%d%n", &N, &K, &cfg, &used) != 3) { ac::set_error("gemm pipe table: cannot parse '%s'", p); return AC_EINVAL; }
-        ac::g_rules[n++] = {N, K, cfg};
+        rules[n++] = {N, K, cfg};
         p += used;
         if (*p == ';') ++p;
     }
-    ac::g_nrules = n;
+    *nrules = n;
     return AC_OK;
 }
+extern "C" int ac_gemm_set_pipe_table(const char* spec) { return parse_pipe_table(spec, ac::g_rules, &ac::g_nrules); }
+/* the same for the fp16x2 kernels (AC_GEMM_F16X2); shapes the table does not name keep the built-in choice */
+extern "C" int ac_gemm_set_pipe_table_f16(const char* spec) { return parse_pipe_table(spec, ac::g_rules_f16, &ac::g_nrules_f16); }

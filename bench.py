@@ -736,6 +736,7 @@ def encoder_roofline(clf, stages, enc_flops, enc_peak, arith):
             "frac": enc_flops / stages["encode_ms"] / 1e9 / enc_peak,
             "flops_per_step": enc_flops,
             "peak_note": ("fp32-equivalent: bf16 MFMA dense peak 2500 / 6 products" if arith == 1
+                          else "fp16 MFMA dense peak 2500 / 3 products (opt-in fp16x2 arithmetic)" if arith == 2
                           else "fp32-input MFMA dense peak"),
             "tokens_per_step": int(getattr(clf.model, "last_tokens", BATCH * SEQ)),
             "tokens_per_step_padded": BATCH * SEQ,
@@ -958,13 +959,46 @@ def main():
     nv.check(nv.lib().ac_gemm_set_arith(0), "ac_gemm_set_arith")
     dt32 = timed_predict(clf, ids, types, mask, args.steps, 2)
     nv.check(nv.lib().ac_gemm_set_arith(arith), "ac_gemm_set_arith")
+    # ... and with the OPT-IN fp16x2 arithmetic (include/acamd.h AC_GEMM_F16X2: operands rounded to two fp16 terms = 22 bits,
+    # three fp16 MFMA products; NOT the arithmetic of `value`): the same loop, its embeddings measured against the bf16x3 ones
+    # of the same batch and against transformers fp32, the predicted labels against the headline's
+    f16 = None
+    if arith == 1 and hasattr(clf.model, "enable_f16x2"):
+        with torch.no_grad():
+            emb3 = clf.model.encode_cls(ids, types, mask).clone()
+            res3 = predict_step(clf, ids, types, mask)
+            clf.model.enable_f16x2()
+            nv.check(nv.lib().ac_gemm_set_arith(2), "ac_gemm_set_arith")
+            dt16 = timed_predict(clf, ids, types, mask, args.steps, 2)
+            active = bool(clf.model.f16x2_active())
+            emb16 = clf.model.encode_cls(ids, types, mask).clone()
+            res16 = predict_step(clf, ids, types, mask)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                clf.model.encode_cls(ids, types, mask, verify=False)
+            e1.record(); torch.cuda.synchronize()
+            want = torch.nn.functional.normalize(
+                hf(input_ids=ids[:8].cpu(), token_type_ids=types[:8].cpu(), attention_mask=mask[:8].cpu()).last_hidden_state[:, 0, :], dim=1)
+            nv.check(nv.lib().ac_gemm_set_arith(arith), "ac_gemm_set_arith")
+            clf.model.disable_f16x2()
+        f16 = {"value": BATCH * args.steps / dt16, "unit": "queries/s", "ms_per_step": dt16 / args.steps * 1e3,
+               "encode_ms": e0.elapsed_time(e1) / 5, "ran_fp16x2": active, "overflow_fallbacks": int(clf.model.f16x2_overflows),
+               "max_abs_embedding_diff_vs_bf16x3": float((emb16 - emb3).abs().max()),
+               "encoder_max_abs_diff_vs_transformers_fp32": float((emb16[:8].cpu() - want).abs().max()),
+               "same_labels_as_value": [[l for l, _ in p] for p in res16] == [[l for l, _ in p] for p in res3],
+               "max_score_diff_vs_value": float(max(abs(x[1] - y[1]) for p, q in zip(res16, res3) for x, y in zip(p, q))),
+               "note": "OPT-IN, not `value`: config gemm_arith='f16x2' / AC_GEMM_ARITH=f16x2.  Operands of the token-row GEMMs rounded "
+                       "to two fp16 terms of x 2^s (22 bits), 3 fp16 MFMA products instead of 6 bf16 ones; error per product <= 3 * "
+                       "2^-22 |a||b| (tests/test_gemm_f16x2_gpu.py measures it next to fp32-MFMA and bf16x3 against fp64); an operand "
+                       "out of fp16 range gives NaN and the call is repeated in bf16x3"}
     # ... and with every text at the full 32 tokens (no padding to leave out): same timed loop, same arithmetic as `value`
     ids_f, types_f, mask_f = synthetic_tokens(dev, rank, full_length=True)
     dt_full = timed_predict(clf, ids_f, types_f, mask_f, args.steps, 2)
     tokens_full = int(getattr(clf.model, "last_tokens", BATCH * SEQ))
     predict_step(clf, ids, types, mask)          # (restores last_tokens of the headline batch for the accounting below)
 
-    enc_peak = BF16_MFMA_PEAK_TF / 6.0 if arith == 1 else F32_MFMA_PEAK_TF
+    enc_peak = BF16_MFMA_PEAK_TF / 6.0 if arith == 1 else BF16_MFMA_PEAK_TF / 3.0 if arith == 2 else F32_MFMA_PEAK_TF
     lens_h = mask.sum(1).double().cpu()
     tokens = int(getattr(clf.model, "last_tokens", BATCH * SEQ))
     unpadded = tokens < BATCH * SEQ
@@ -987,7 +1021,10 @@ def main():
                    "prototypes": NPROTO, "dim": DIM, "k": KNN_K, "classes": NCLASS, "parallelism": "dp1",
                    "gemm_arith": ("bf16x3 split: fp32 operands = h+m+l exactly, 6 bf16 MFMA products, fp32 "
                                   "accumulate (fp32-grade; tests/test_gemm_split_gpu.py)" if arith == 1
+                                  else "fp16x2 (AC_GEMM_ARITH=f16x2 in the environment: OPT-IN, operands rounded to 22 bits, "
+                                       "3 fp16 MFMA products; NOT fp32-grade -- see include/acamd.h)" if arith == 2
                                   else "fp32-input MFMA"),
+                   "value_f16x2_opt_in": f16,
                    "value_f32_mfma": BATCH * args.steps / dt32,
                    "ms_per_step_f32_mfma": dt32 / args.steps * 1e3,
                    "value_full_length": BATCH * args.steps / dt_full,

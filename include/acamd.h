@@ -217,11 +217,22 @@ int ac_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
  *                   products (hh, hm, mh, mm, hl, lh) accumulated in fp32: per-product error <= 2^-26,
  *                   i.e. fp32-grade results (tests/test_gemm_split_gpu.py bounds it against fp64), at
  *                   6/16 of the matrix-pipe time.  Non-finite operands yield NaN.
+ *   AC_GEMM_F16X2   OPT-IN, not fp32-exact on its inputs: in the BERT encoder's token-row GEMMs (ac_bert_encode_cls* with the
+ *                   fp16 weight planes of ac_bert_weights present) every operand is rounded to TWO fp16 terms of x 2^s
+ *                   (22 significant bits; s = 6 for activations, 10 for weights) and a product is three fp16 MFMAs
+ *                   (lh, hl, hh) in fp32: per-product error <= 3 * 2^-22 |a||b| -- inside the a-priori bound K 2^-24
+ *                   sum|a||b| of an fp32 dot product for K >= 12, but several times the error the fp32 MFMA or the bf16x3
+ *                   split actually make (tests/test_gemm_f16x2_gpu.py measures all three against fp64) -- at half the
+ *                   matrix-pipe time of bf16x3.  An operand beyond the fp16 range at its scale (|activation| >= 1023.5,
+ *                   |weight| >= 63.97) turns the rows it feeds into NaN, never into a wrong finite number; the Python
+ *                   encoder repeats such a call in bf16x3.  Everywhere else (head, ModernBERT, small shapes, ac_linear_*)
+ *                   this mode IS bf16x3.
  * The reference computes these products with torch fp32 matmuls (transformers BertModel called at
  * classifier.py:1271; nn.Linear in models.py:49-80).  Process-wide; the initial value comes from the
- * environment variable AC_GEMM_ARITH ("f32" | "bf16x3"; default bf16x3). */
+ * environment variable AC_GEMM_ARITH ("f32" | "bf16x3" | "f16x2"; default bf16x3). */
 #define AC_GEMM_F32 0
 #define AC_GEMM_BF16X3 1
+#define AC_GEMM_F16X2 2
 int ac_gemm_set_arith(int mode);
 int ac_gemm_get_arith(void);
 /* Diagnostic / A-B switch for the large-M pre-split GEMM: 0 = default dispatch (per-shape choice between the two-buffer
@@ -237,6 +248,10 @@ int ac_gemm_debug_stamps(unsigned long long* d_buf, int64_t capacity_workgroups)
  * one ring configuration (cfg as in ac_gemm_set_variant) for planes GEMMs with N output columns and inner dimension K;
  * "" = two-buffer kernels everywhere; NULL restores the built-in table (tools/encode_ab.py). */
 int ac_gemm_set_pipe_table(const char* spec);
+/* The same for the fp16x2 kernels of AC_GEMM_F16X2 (a shape the table does not name, or names with cfg 0, keeps the built-in
+ * choice -- there is no two-buffer kernel for fp16x2 operands); the configurations built for fp16x2 only are listed in
+ * gemm_pipe.hip (AC_PIPE_CONFIGS_F16). */
+int ac_gemm_set_pipe_table_f16(const char* spec);
 /* The BERT encoder folds `x = LayerNorm(x + A W^T + b)` (BertSelfOutput / BertOutput, transformers modeling_bert.py) into
  * the epilogue of the attention-output and FFN2 GEMMs when the launch is one round of 128 x 128 tiles, one per CU: the
  * tiles of a 128-row panel exchange per-row (mean, M2) partials and each normalises its own block (gemm_pipe.hip).
@@ -265,6 +280,21 @@ int ac_gemm_occupancy(int kernel, int tm, int* blocks_per_cu);
  * emitted planes. */
 int ac_split_bf16x3(const float* d_X, int64_t ldx, int64_t rows, int K,
                     uint16_t* d_planes, ac_stream_t stream);
+
+/* Operand planes for AC_GEMM_F16X2: X[rows, K] fp32 -> two fp16 planes h, l of X 2^scale_log2 (h = fp16(x 2^s), l = fp16(x 2^s
+ * - h), round to nearest even) in the layout of ac_split_bf16x3's first two planes: planes[p][k / 8][row][k % 8], p = 0, 1,
+ * plane stride rows * K (2 * rows * K uint16 in total).  scale_log2: 10 for weights (what ac_bert_weights.*_wh hold), 6 for
+ * activations (what the encoder's producers emit). */
+int ac_split_f16x2(const float* d_X, int64_t ldx, int64_t rows, int K, int scale_log2,
+                   uint16_t* d_planes, ac_stream_t stream);
+
+/* C[M,N] = act(A W^T + bias) (+ residual) on fp16x2 planes (A at scale 2^6, W at 2^10), the ring-staged kernels of
+ * gemm_pipe.hip only: M >= 192, K % 32 == 0, K >= 64 (AC_EUNSUPPORTED otherwise).  d_C fp32 rows, or -- d_C_planes non-NULL,
+ * N % 8 == 0, no residual, act 0 or 2 -- the fp16x2 activation planes of the next GEMM instead.  Test / tuning entry: the
+ * encoder calls the same internal function. */
+int ac_linear_f16x2(const uint16_t* d_A_planes, const uint16_t* d_W_planes, const float* d_bias,
+                    const float* d_residual, int64_t ldr, float* d_C, int64_t ldc, uint16_t* d_C_planes,
+                    int M, int N, int K, int act, ac_stream_t stream);
 
 /* ac_linear_f32 with optional pre-split operands (either may be NULL; A planes require W planes).  The
  * planes are used when the arithmetic mode is AC_GEMM_BF16X3 and the shape takes the LDS-tiled path
@@ -452,6 +482,13 @@ typedef struct {
     const uint16_t* const* ao_w3;
     const uint16_t* const* ff1_w3;
     const uint16_t* const* ff2_w3;
+    /* Optional (all four or none, and only next to the four above): ac_split_f16x2(scale_log2 = 10) of the same matrices.
+     * Used when the arithmetic mode is AC_GEMM_F16X2 and every token-row GEMM of the call takes the ring-staged kernel
+     * (>= 192 token rows); otherwise the call runs as under AC_GEMM_BF16X3. */
+    const uint16_t* const* qkv_wh;
+    const uint16_t* const* ao_wh;
+    const uint16_t* const* ff1_wh;
+    const uint16_t* const* ff2_wh;
 } ac_bert_weights;
 
 /*

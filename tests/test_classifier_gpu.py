@@ -50,6 +50,17 @@ def test_predict_batch_and_errors(clf):
     out = clf.predict_batch(["great product", "awful thing", "fine I guess", "x"], k=2, batch_size=3)
     assert len(out) == 4 and all(len(p) <= 2 for p in out)
     assert all(isinstance(s, float) for p in out for _, s in p)
+    # batch_size is a lower bound on the device batch: a text's result does not depend on what shares its batch
+    texts = ["great product", "awful thing", "fine I guess", "x", "the worst", "lovely, would buy again", "meh"]
+    big = clf.predict_batch(texts, k=2, batch_size=3)
+    clf.config.config["min_device_batch"] = 1
+    try:
+        small = clf.predict_batch(texts, k=2, batch_size=3)
+    finally:
+        del clf.config.config["min_device_batch"]
+    assert [[l for l, _ in p] for p in big] == [[l for l, _ in p] for p in small]
+    for a, b in zip(big, small):
+        assert all(abs(x[1] - y[1]) < 1e-5 for x, y in zip(a, b))
     with pytest.raises(ValueError, match="Empty input batch"):
         clf.predict_batch([])
     with pytest.raises(ValueError, match="Empty input lists"):
