@@ -473,6 +473,23 @@ def measure_cfg4(dev, args, steps=None, warmup=None, parity_queries=16):
                   "encoder_max_abs_diff_vs_transformers_fp32": float((emb[:4].cpu() - want.detach()).abs().max())}
     lens_h = mask.sum(1).double().cpu()
     enc_flops = enc.flops(B, S, tokens=float(lens_h.sum()), sum_len_sq=float((lens_h ** 2).sum())) if enc.last_tokens < B * S else enc.flops(B, S)
+    f16 = None
+    from adaptive_classifier import _native as nv
+    if nv.lib().ac_gemm_get_arith() == 1:          # the opt-in fp16x2 arithmetic on the same batch (see main(): value_f16x2_opt_in)
+        enc.enable_f16x2()
+        nv.check(nv.lib().ac_gemm_set_arith(2), "ac_gemm_set_arith")
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(2, steps // 2)):
+            step()
+        torch.cuda.synchronize()
+        dt16 = (time.perf_counter() - t0) / max(2, steps // 2)
+        emb16 = clf.model.encode_cls(ids, types, mask)
+        nv.check(nv.lib().ac_gemm_set_arith(1), "ac_gemm_set_arith")
+        enc.disable_f16x2()
+        f16 = {"value": B / dt16, "unit": "queries/s", "ms_per_step": dt16 * 1e3, "overflow_fallbacks": int(enc.f16x2_overflows),
+               "max_abs_embedding_diff_vs_bf16x3": float((emb16 - emb).abs().max()), "note": "OPT-IN arithmetic, not `value`"}
     del rows, clf, enc
     torch.cuda.empty_cache()
     return {
@@ -488,7 +505,7 @@ def measure_cfg4(dev, args, steps=None, warmup=None, parity_queries=16):
                              "frac": enc_flops / ev[0].elapsed_time(ev[1]) / 1e9 / (BF16_MFMA_PEAK_TF / 6.0),
                              "note": "executed FLOPs (padding tokens left out, last layer on the CLS rows) against the fp32-equivalent "
                                      "bf16x3 ceiling 2500 / 6"},
-        "parity": parity}
+        "parity": parity, "value_f16x2_opt_in": f16}
 
 
 def measure_add_examples(dev, args, n=None, modes=("as_wired", "intended"), with_cpu=None):
