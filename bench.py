@@ -1078,7 +1078,8 @@ def main():
         del clf
         torch.cuda.empty_cache()
         c4 = measure_cfg4(dev, args, steps=5, warmup=2, parity_queries=8)
-        line["cfg4"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "steps", "stages_ms", "roofline_encoder", "parity", "config")}
+        line["cfg4"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "steps", "stages_ms", "roofline_encoder", "parity", "config",
+                                               "value_f16x2_opt_in")}
         ae = measure_add_examples(dev, args, n=6000, modes=("as_wired",), with_cpu=False)
         m = ae["modes"]["as_wired"]
         line["add_examples"] = {"value": ae["value"], "unit": ae["unit"], "examples": m["examples"], "train_steps": m["train_steps"],
