@@ -544,6 +544,20 @@ def test_predict_retry_contract_without_a_gpu():
     c, res, seen = run(Enc(), 5)                                    # NaN that the encoder does not explain: returned as computed
     assert res == ["result of emb1"] and c.model.calls == [(False, False)]
 
+    class EncF16(Enc):                                              # opt-in fp16x2 arithmetic: NaN = an operand left fp16's range
+        f16x2_overflows, _f16 = 0, True
+
+        def f16x2_active(self):
+            return self._f16
+
+        def disable_f16x2(self):
+            self._f16 = False
+    c, res, seen = run(EncF16(), 1)                                 # -> the encoder goes back to bf16x3, the batch is encoded again
+    assert res == ["result of emb2"] and c.model.calls == [(False, False), (True, False)]
+    assert c.model.f16x2_overflows == 1 and not c.model.f16x2_active()
+    c, res, seen = run(EncF16(), 0)                                 # finite scores: fp16x2 stays on, one pass
+    assert res == ["result of emb1"] and c.model.f16x2_overflows == 0 and c.model.f16x2_active()
+
     class Plain:                                                    # a user encoder: no options in its signature
         last_one_launch = False
 
