@@ -108,6 +108,7 @@ _SIGNATURES = {
     "ac_gemm_debug_stamps": (c_int, [c_void_p, c_int64]),
     "ac_gemm_set_pipe_table": (c_int, [ctypes.c_char_p]),
     "ac_gemm_set_pipe_table_f16": (c_int, [ctypes.c_char_p]),
+    "ac_gemm_set_krot": (c_int, [c_int]),
     "ac_gemm_set_ln_fusion": (c_int, [c_int]),
     "ac_gemm_ln_fusion_launches": (c_int64, []),
     "ac_set_persistent_kernels": (c_int, [c_int]),

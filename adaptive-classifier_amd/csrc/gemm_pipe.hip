@@ -39,6 +39,7 @@ struct PipeParams {
     Epilogue epi;
     LnFuse ln;                          // EPI_BIAS_RES_LN only
     unsigned long long* stamps;         // diagnostic (ac_gemm_debug_stamps): 4 shader-clock stamps per workgroup, or null
+    int krot;                           // XCD x starts its k-loop at stage x nk / 8 and wraps (ac_gemm_set_krot; default on)
 };
 
 // shader-clock stamp `i` of this workgroup (wave 0 only; a wave-uniform branch on a kernel argument)
@@ -250,6 +251,17 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
         }
     }
     int iss = 0;                                                        // next stage to issue
+    // Rotated k order (round 4): in a one-round launch all workgroups run their k-loops in lockstep, so the 8 XCDs' L2s would miss
+    // on the SAME slice of W at the same moment, every stage.  XCD x starts at stage x nk / 8 and wraps: the XCDs ask the fabric
+    // for 8 different slices, and what one fetched is in the memory-side cache when the next gets there.  Measured in the encoder
+    // (profiles/r04/krot_ab_base.txt): 5.99 -> 5.51 ms bf16x3, 4.30 -> 3.83 ms fp16x2; no change for multi-round launches.
+    // A tile's fp32 accumulation order now depends on its XCD: deterministic per shape, rounding-level differences between
+    // shapes / batch positions (tests: integer operands, where every order is exact, must give the exact product).
+    int a_cur = prm.krot ? ((int)(blockIdx.x & 7) * nk / 8) & ~1 : 0;    // actual stage the pointers are at
+    if (a_cur) {
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) pp[t] += (int64_t)a_cur * (((wave + NW * t) % NP) % RG < RA ? a_step : w_step);
+    }
     auto issue = [&]() {                                                // always PPW DMA instructions (exact vmcnt accounting)
         const int slot = iss % NS;
 #pragma unroll
@@ -257,7 +269,15 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
             const int j = (wave + NW * t) % NP, p = j / RG, g = j % RG;
             __builtin_amdgcn_global_load_lds((glb_void_t*)pp[t], (lds_void_t*)&lds[slot * SLOT + (p * RG + g) * 64], 16, 0, 0);
         }
-        if (iss + 1 < nk) {                                             // past the end: the last stage again (harmless duplicates)
+        if (prm.krot) {                                                 // wrap around; past the end the walk simply goes on
+            const bool wrap = a_cur + 1 == nk;
+            a_cur = wrap ? 0 : a_cur + 1;
+#pragma unroll
+            for (int t = 0; t < PPW; ++t) {
+                const int64_t st = ((wave + NW * t) % NP) % RG < RA ? a_step : w_step;
+                pp[t] += wrap ? -(int64_t)(nk - 1) * st : st;
+            }
+        } else if (iss + 1 < nk) {                                      // past the end: the last stage again (harmless duplicates)
 #pragma unroll
             for (int t = 0; t < PPW; ++t) pp[t] += ((wave + NW * t) % NP) % RG < RA ? a_step : w_step;
         }
@@ -383,6 +403,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
     if (prm.stamps) { wait_vm<0>(); stamp(prm, wave, 3); }
 }
 
+int g_krot = -1;                              // ac_gemm_set_krot (-1 = environment AC_GEMM_KROT, default on)
 unsigned long long* g_stamps = nullptr;      // ac_gemm_debug_stamps
 int64_t g_stamp_cap = 0;
 
@@ -398,6 +419,8 @@ int launch_one(PipeParams p, hipStream_t stream) {
         AC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE, AR>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.stamps = (g_stamps && tiles <= g_stamp_cap) ? g_stamps : nullptr;
+    static const int krot_env = getenv("AC_GEMM_KROT") ? atoi(getenv("AC_GEMM_KROT")) : 1;
+    p.krot = g_krot >= 0 ? g_krot : krot_env;
     hipLaunchKernelGGL((gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE, AR>), dim3((unsigned)tiles), dim3(64 * WMW * WNW), lds, stream, p);
     AC_LAUNCH_CHECK();
     return AC_OK;
@@ -437,6 +460,8 @@ int launch_cfg(int cls, bool cp, const PipeParams& p, hipStream_t stream) {
 
 /* diagnostic: the ring-staged GEMM kernels write 4 shader-clock stamps per workgroup (start, ring filled, loop done, stores
  * drained) into d_buf[4 * workgroup] while d_buf is set and holds the grid (tools/gemm_bench.hip); null switches it off. */
+/* 1 (default) = the XCDs start their k-loops at different stages; 0 = all at stage 0 (bit-for-bit comparisons between kernels) */
+extern "C" int ac_gemm_set_krot(int on) { g_krot = on ? 1 : 0; return AC_OK; }
 extern "C" int ac_gemm_debug_stamps(unsigned long long* d_buf, int64_t capacity_workgroups) {
     g_stamps = d_buf;
     g_stamp_cap = d_buf ? capacity_workgroups : 0;

@@ -18,6 +18,7 @@ def arith():
     before = lib.ac_gemm_get_arith()
     yield lambda mode: nv.check(lib.ac_gemm_set_arith(mode), "ac_gemm_set_arith")
     lib.ac_gemm_set_arith(before)
+    lib.ac_gemm_set_krot(1)
 
 
 def _planes(nv, dev, Xd):
@@ -233,6 +234,7 @@ def test_ring_staged_kernels_equal_the_two_buffer_kernels_bit_for_bit(M, N, K, a
     want = _ref(A, W, b, R, act)
     arith(BF16X3)
     lib = nv.lib()
+    lib.ac_gemm_set_krot(0)          # every workgroup walks k in order: the same sums in the same order whatever the tile
     try:
         nv.check(lib.ac_gemm_set_variant(1), "ac_gemm_set_variant")
         base = _linear(nv, cuda_dev, A, W, b, R, act, "aw")
@@ -245,5 +247,46 @@ def test_ring_staged_kernels_equal_the_two_buffer_kernels_bit_for_bit(M, N, K, a
                 assert np.array_equal(got, base), (cfg, rep, int((got != base).sum()), float(np.abs(got - base).max()))
         nv.check(lib.ac_gemm_set_variant(0), "ac_gemm_set_variant")      # the default dispatch (per-shape choice)
         assert np.array_equal(_linear(nv, cuda_dev, A, W, b, R, act, "aw"), base)
+    finally:
+        lib.ac_gemm_set_variant(0)
+
+
+@pytest.mark.parametrize("M,N,K,res", [
+    (5141, 768, 768, True),         # one round of 128 x 128 tiles: every XCD starts at a different stage
+    (1000, 2304, 64, False),        # 4 k-stages: fewer than XCDs (start stages 0, 0, 0, 0, 2, 2, 2, 2)
+    (261, 200, 96, False),          # ragged, 6 stages
+    (5141, 768, 3072, True),        # the long k-loop
+])
+def test_rotated_k_order_sums_every_stage_exactly_once(M, N, K, res, cuda_dev, arith):
+    """ac_gemm_set_krot(1), the default: workgroups on XCD x walk the k stages x nk / 8 ... nk - 1, 0 ... x nk / 8 - 1.  With small
+    INTEGER operands every partial sum is exact in fp32 whatever the order, so each configuration must return the exact integer
+    product bit for bit -- a stage skipped, repeated or read from the wrong ring slot after the wrap cannot pass.  On random
+    operands the rotated result stays within fp32 rounding of the in-order one (and inside the a-priori bound)."""
+    from adaptive_classifier import _native as nv
+    rng = np.random.default_rng(M + N + K)
+    A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+    W = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    b = rng.integers(-5, 6, N).astype(np.float32)
+    R = rng.integers(-9, 10, (M, N)).astype(np.float32) if res else None
+    want = _ref(A, W, b, R, 0)
+    Ar = rng.standard_normal((M, K)).astype(np.float32)
+    Wr = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    wantr = _ref(Ar, Wr, b, R, 0)
+    bound = K * 2.0 ** -24 * (np.abs(Ar).astype(np.float64) @ np.abs(Wr).astype(np.float64).T) + 1e-6
+    arith(BF16X3)
+    lib = nv.lib()
+    try:
+        lib.ac_gemm_set_krot(0)
+        nv.check(lib.ac_gemm_set_variant(0), "ac_gemm_set_variant")
+        inorder = _linear(nv, cuda_dev, Ar, Wr, b, R, 0, "aw")
+        lib.ac_gemm_set_krot(1)
+        for cfg in [0] + PIPE_CFGS:
+            nv.check(lib.ac_gemm_set_variant(cfg), "ac_gemm_set_variant")
+            for rep in range(2):
+                got = _linear(nv, cuda_dev, A, W, b, R, 0, "aw")
+                assert np.array_equal(got, want), (cfg, rep, int((got != want).sum()))
+            got = _linear(nv, cuda_dev, Ar, Wr, b, R, 0, "aw")
+            assert np.all(np.abs(got - wantr) <= bound), cfg
+            assert np.abs(got - inorder).max() <= 64 * 2.0 ** -24 * np.abs(wantr).max() + 1e-6, cfg
     finally:
         lib.ac_gemm_set_variant(0)
