@@ -579,7 +579,8 @@ class AdaptiveClassifier:
     def predict_batch(self, texts: List[str], k: int = 5, batch_size: int = 32) -> List[List[Tuple[str, float]]]:
         """classifier.py:1308-1388: top-k prototypes + top-k head classes, fixed 0.7/0.3 weights.
         `batch_size` bounds the reference's CPU memory (default 32); here it is a LOWER bound on the device batch: a text's result
-        does not depend on which texts share its batch (padding-free forward, exact search), and 32 texts are ~600 token rows --
+        does not depend on which texts share its batch beyond fp32 rounding of the encoder's sums (padding-free forward, exact
+        search; the reference's own batched matmuls are batch-dependent in the same way), and 32 texts are ~600 token rows --
         a launch-bound encoder call -- so lists are walked in chunks of max(batch_size, config["min_device_batch"]) texts
         (default 256, what BASELINE configs[1] is quoted on; set it to 1 to get the reference's chunking)."""
         if not texts:

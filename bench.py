@@ -1004,6 +1004,11 @@ def main():
                "max_abs_embedding_diff_vs_bf16x3": float((emb16 - emb3).abs().max()),
                "encoder_max_abs_diff_vs_transformers_fp32": float((emb16[:8].cpu() - want).abs().max()),
                "same_labels_as_value": [[l for l, _ in p] for p in res16] == [[l for l, _ in p] for p in res3],
+               "queries_with_the_same_neighbour_ids": float((clf.memory.search_batch(emb16, KNN_K)[1] ==
+                                                              clf.memory.search_batch(emb3, KNN_K)[1]).all(1).float().mean()),
+               "score_note": "the synthetic store is 100k random unit vectors: the k-th neighbours of a query are near-ties, so "
+                             "embeddings 2e-7 apart can swap one and move a blended score by a few percent -- the same happens "
+                             "between any two fp32 evaluation orders",
                "max_score_diff_vs_value": float(max(abs(x[1] - y[1]) for p, q in zip(res16, res3) for x, y in zip(p, q))),
                "note": "OPT-IN, not `value`: config gemm_arith='f16x2' / AC_GEMM_ARITH=f16x2.  Operands of the token-row GEMMs rounded "
                        "to two fp16 terms of x 2^s (22 bits), 3 fp16 MFMA products instead of 6 bf16 ones; error per product <= 3 * "

@@ -221,15 +221,18 @@ def test_encoder_under_f16x2_matches_transformers(arch, peaked, cuda_dev, arith)
     else:
         model = bert_oracle.make_bert(1024, 4, 16, 4096, vocab=2000, seed=1, **kw)
         b, S = 48, 32
+    import copy
     ids, types, mask = bert_oracle.synthetic_batch(b, S, vocab=2000, seed=99, ragged=True)
-    want = bert_oracle.encode_cls(model, ids, types, mask)
+    want = bert_oracle.encode_cls(model, ids, types, mask)                                    # the reference: transformers fp32
+    exact = bert_oracle.encode_cls(copy.deepcopy(model).double(), ids, types, mask)            # ... and what it approximates
+    ref_err = (want.double() - exact)
     enc = HipBertEncoder(model, device=cuda_dev).enable_f16x2()
     arith(BF16X3)
     assert not enc.f16x2_active()
-    d3 = enc.encode_cls(ids, types, mask).cpu() - want
+    got3 = enc.encode_cls(ids, types, mask).cpu()
     arith(F16X2)
     assert enc.f16x2_active()
-    errs, rms = {}, {}
+    errs, rms, rms64 = {}, {}, {}
     for name, unpad, fusion in (("packed+ln", True, 1), ("packed", True, 0), ("padded+ln", False, 1), ("padded", False, 0)):
         nv.check(nv.lib().ac_gemm_set_ln_fusion(fusion), "ac_gemm_set_ln_fusion")
         enc.unpad = unpad
@@ -237,15 +240,18 @@ def test_encoder_under_f16x2_matches_transformers(arch, peaked, cuda_dev, arith)
         assert torch.isfinite(got).all() and enc.f16x2_overflows == 0
         errs[name] = (got - want).abs().max().item()
         rms[name] = (got - want).pow(2).mean().sqrt().item()
+        rms64[name] = (got.double() - exact).pow(2).mean().sqrt().item()
     nv.lib().ac_gemm_set_ln_fusion(1)
-    e3, r3 = d3.abs().max().item(), d3.pow(2).mean().sqrt().item()
-    print(f"\n  {arch} peaked={peaked}: |CLS - transformers fp32|  bf16x3 max {e3:.2e} rms {r3:.2e}   fp16x2 max "
-          + " ".join(f"{k} {v:.2e}" for k, v in errs.items()) + "   rms " + " ".join(f"{k} {v:.2e}" for k, v in rms.items()))
-    assert max(errs.values()) < 1e-4, errs                              # the contract
-    # measured: ~1.5e-7 on the transformers-init model (bf16x3: 1.9e-7); the peaked model amplifies ANY rounding ~100x
-    # (bf16x3: 1.3e-5) -- fp16x2 must stay in the same class there, not merely under the contract
-    assert max(errs.values()) < (5e-5 if peaked else 2e-6), errs
-    assert max(rms.values()) <= 4.0 * r3 + 1e-8, (rms, r3)
+    e3, r3 = (got3 - want).abs().max().item(), (got3 - want).pow(2).mean().sqrt().item()
+    r3_64, rref = (got3.double() - exact).pow(2).mean().sqrt().item(), ref_err.pow(2).mean().sqrt().item()
+    print(f"\n  {arch} peaked={peaked}: vs transformers fp32: bf16x3 max {e3:.2e} rms {r3:.2e} | fp16x2 max "
+          + " ".join(f"{k} {v:.2e}" for k, v in errs.items()) + " rms " + " ".join(f"{k} {v:.2e}" for k, v in rms.items())
+          + f"\n      rms vs transformers fp64 (the exact forward): transformers fp32 {rref:.2e}  bf16x3 {r3_64:.2e}  fp16x2 "
+          + " ".join(f"{k} {v:.2e}" for k, v in rms64.items()))
+    assert max(errs.values()) < 1e-4, errs                              # the contract: within 1e-4 of the fp32 reference
+    # the honest yardstick is the EXACT forward (fp64): fp16x2 must be as close to it as the fp32 reference itself is, and as
+    # bf16x3 is (the peaked model amplifies any rounding ~100x, so all four numbers move together there)
+    assert max(rms64.values()) <= 3.0 * max(rref, r3_64) + 1e-8, (rms64, rref, r3_64)
 
 
 def test_encoder_f16x2_overflow_falls_back_to_bf16x3(cuda_dev, arith):

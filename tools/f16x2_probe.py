@@ -72,7 +72,12 @@ if "--no-sweep" not in args:
         lib.ac_gemm_set_arith(1)
         t3 = timed(run3)
         flop = 2.0 * T * N * K
-        row = [f"{name:5s} {T}x{N}x{K}: bf16x3 default {t3:7.1f} us ({6 * flop / t3 / 1e6 / 2500:.2f} of the bf16 pipe) | fp16x2:"]
+        row3 = []
+        for c in (222232, 124262, 224242, 234232, 322432, 244232):          # the bf16x3 configurations on the same shape
+            nv.check(lib.ac_gemm_set_pipe_table(f"{N}x{K}={c}".encode()), "table")
+            row3.append(f"{c} {timed(run3):6.1f}")
+        lib.ac_gemm_set_pipe_table(None)
+        row = [f"{name:5s} {T}x{N}x{K}: bf16x3 default {t3:7.1f} us ({6 * flop / t3 / 1e6 / 2500:.2f} of the bf16 pipe) [" + " ".join(row3) + "] | fp16x2:"]
         lib.ac_gemm_set_pipe_table_f16(None)
         tb = timed(run16)
         row.append(f"builtin {tb:6.1f}")
