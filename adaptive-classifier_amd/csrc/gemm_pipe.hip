@@ -257,11 +257,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
     // (profiles/r04/krot_ab_base.txt): 5.99 -> 5.51 ms bf16x3, 4.30 -> 3.83 ms fp16x2; no change for multi-round launches.
     // A tile's fp32 accumulation order now depends on its XCD: deterministic per shape, rounding-level differences between
     // shapes / batch positions (tests: integer operands, where every order is exact, must give the exact product).
-    int a_cur = prm.krot ? ((int)(blockIdx.x & 7) * nk / 8) & ~1 : 0;    // actual stage the pointers are at
+    int a_cur = prm.krot ? ((int)(blockIdx.x & 7) * nk / 8) : 0;         // the stage the pointers are at (wave-uniform)
     if (a_cur) {
 #pragma unroll
         for (int t = 0; t < PPW; ++t) pp[t] += (int64_t)a_cur * (((wave + NW * t) % NP) % RG < RA ? a_step : w_step);
     }
+    const int64_t a_back = (int64_t)(nk - 1) * a_step, w_back = (int64_t)(nk - 1) * w_step;
     auto issue = [&]() {                                                // always PPW DMA instructions (exact vmcnt accounting)
         const int slot = iss % NS;
 #pragma unroll
@@ -269,18 +270,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
             const int j = (wave + NW * t) % NP, p = j / RG, g = j % RG;
             __builtin_amdgcn_global_load_lds((glb_void_t*)pp[t], (lds_void_t*)&lds[slot * SLOT + (p * RG + g) * 64], 16, 0, 0);
         }
-        if (prm.krot) {                                                 // wrap around; past the end the walk simply goes on
-            const bool wrap = a_cur + 1 == nk;
-            a_cur = wrap ? 0 : a_cur + 1;
+        // next stage, wrapping to stage 0 after the last one -- one branch-free form for both k orders (scalar selects): in
+        // order the wrap falls on the first over-issued tail stage, whose contents nobody reads
+        const bool wrap = a_cur + 1 == nk;
+        a_cur = wrap ? 0 : a_cur + 1;
+        const int64_t da = wrap ? -a_back : a_step, dw = wrap ? -w_back : w_step;
 #pragma unroll
-            for (int t = 0; t < PPW; ++t) {
-                const int64_t st = ((wave + NW * t) % NP) % RG < RA ? a_step : w_step;
-                pp[t] += wrap ? -(int64_t)(nk - 1) * st : st;
-            }
-        } else if (iss + 1 < nk) {                                      // past the end: the last stage again (harmless duplicates)
-#pragma unroll
-            for (int t = 0; t < PPW; ++t) pp[t] += ((wave + NW * t) % NP) % RG < RA ? a_step : w_step;
-        }
+        for (int t = 0; t < PPW; ++t) pp[t] += ((wave + NW * t) % NP) % RG < RA ? da : dw;
         ++iss;
     };
 
@@ -403,7 +399,16 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
     if (prm.stamps) { wait_vm<0>(); stamp(prm, wave, 3); }
 }
 
-int g_krot = -1;                              // ac_gemm_set_krot (-1 = environment AC_GEMM_KROT, default on)
+std::atomic<int> g_krot{-1};                  // ac_gemm_set_krot (-1 = environment AC_GEMM_KROT, default on)
+int krot_enabled() {
+    int v = g_krot.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("AC_GEMM_KROT");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+        g_krot.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 unsigned long long* g_stamps = nullptr;      // ac_gemm_debug_stamps
 int64_t g_stamp_cap = 0;
 
@@ -419,8 +424,7 @@ int launch_one(PipeParams p, hipStream_t stream) {
         AC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE, AR>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.stamps = (g_stamps && tiles <= g_stamp_cap) ? g_stamps : nullptr;
-    static const int krot_env = getenv("AC_GEMM_KROT") ? atoi(getenv("AC_GEMM_KROT")) : 1;
-    p.krot = g_krot >= 0 ? g_krot : krot_env;
+    p.krot = krot_enabled();
     hipLaunchKernelGGL((gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE, AR>), dim3((unsigned)tiles), dim3(64 * WMW * WNW), lds, stream, p);
     AC_LAUNCH_CHECK();
     return AC_OK;
@@ -461,7 +465,7 @@ int launch_cfg(int cls, bool cp, const PipeParams& p, hipStream_t stream) {
 /* diagnostic: the ring-staged GEMM kernels write 4 shader-clock stamps per workgroup (start, ring filled, loop done, stores
  * drained) into d_buf[4 * workgroup] while d_buf is set and holds the grid (tools/gemm_bench.hip); null switches it off. */
 /* 1 (default) = the XCDs start their k-loops at different stages; 0 = all at stage 0 (bit-for-bit comparisons between kernels) */
-extern "C" int ac_gemm_set_krot(int on) { g_krot = on ? 1 : 0; return AC_OK; }
+extern "C" int ac_gemm_set_krot(int on) { g_krot.store(on ? 1 : 0, std::memory_order_relaxed); return AC_OK; }
 extern "C" int ac_gemm_debug_stamps(unsigned long long* d_buf, int64_t capacity_workgroups) {
     g_stamps = d_buf;
     g_stamp_cap = d_buf ? capacity_workgroups : 0;
