@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 namespace {
 using namespace acg;
@@ -288,15 +289,19 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    struct Frags { uint4 a[TM][AR], b[TN][AR]; };
+    // (the fragments are kept in the MFMA's own operand type, converted AT the LDS load: with them held as uint4 and converted at
+    //  the MFMA, hipcc put an s_waitcnt vmcnt(0) in front of every stage's first ds_read -- it no longer proved the reads
+    //  independent of the LDS-DMA writes in flight -- which drained the ring every stage: encode 4.96 -> 6.09 ms)
+    using frag_t = std::conditional_t<AR == 3, bf16x8_t, f16x8_t>;
+    struct Frags { frag_t a[TM][AR], b[TN][AR]; };
     auto read_frags = [&](Frags& F, int slot) {
         const uint4* base = lds + slot * SLOT + lane;
 #pragma unroll
         for (int p = 0; p < AR; ++p) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) F.a[a][p] = base[(p * RG + TM * wm + a) * 64];
+            for (int a = 0; a < TM; ++a) F.a[a][p] = __builtin_bit_cast(frag_t, base[(p * RG + TM * wm + a) * 64]);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) F.b[b][p] = base[(p * RG + RA + TN * wn + b) * 64];
+            for (int b = 0; b < TN; ++b) F.b[b][p] = __builtin_bit_cast(frag_t, base[(p * RG + RA + TN * wn + b) * 64]);
         }
     };
     constexpr int NPROD = AR == 3 ? 6 : 3;
@@ -311,11 +316,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
                     if constexpr (AR == 3)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, F.a[a][PAIRS3[pr][0]]),
-                                                                            __builtin_bit_cast(bf16x8_t, F.b[b][PAIRS3[pr][1]]), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][PAIRS3[pr][0]], F.b[b][PAIRS3[pr][1]], acc[a][b], 0, 0, 0);
                     else
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, F.a[a][PAIRS2[pr][0]]),
-                                                                           __builtin_bit_cast(f16x8_t, F.b[b][PAIRS2[pr][1]]), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[a][PAIRS2[pr][0]], F.b[b][PAIRS2[pr][1]], acc[a][b], 0, 0, 0);
                 }
     };
 

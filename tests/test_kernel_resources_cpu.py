@@ -56,3 +56,29 @@ def test_streaming_sweeps_keep_their_prefetch_queue():
         body = m.group(3)
         assert "flat_load" not in body and "flat_store" not in body and "flat_atomic" not in body, m.group(1)
     assert seen >= 4
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_ring_gemm_loops_wait_on_counted_vmcnt_only():
+    """gemm_pipe_nt drains its LDS ring with COUNTED waits: (NS - 2) PPW before the loop, (NS - 3) PPW in each of the loop's two
+    steps.  hipcc inserts an s_waitcnt vmcnt(0) of its own in front of an LDS read it cannot prove independent of the LDS-DMA
+    writes in flight -- it did when the fragments were loaded as uint4 and converted at the MFMA (round 4), right after every
+    counted wait, and the encoder went from 4.96 to 6.09 ms.  For every instantiation with a ring of >= 4 slots the first three
+    vmcnt waits of the listing must therefore be the counted, non-zero ones."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-S",
+                               "--cuda-device-only", os.path.join(CSRC, "gemm_pipe.hip"), "-o", out], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    seen = 0
+    for m in re.finditer(r"^(_ZN\S*gemm_pipe_ntI(\S+?)EEvNS\S*):[^\n]*\n(.*?)\.Lfunc_end", text, re.S | re.M):
+        args = [int(x) for x in re.findall(r"L[ib](\d+)", m.group(2) + "E")]  # EPI TM TN WMW WNW NS CP PIPE AR
+        epi, tm, tn, wmw, wnw, ns, cp, pipe, ar = args
+        if ns < 4 or pipe == 0:
+            continue
+        seen += 1
+        rg = tm * wmw + tn * wnw
+        ppw = -(-ar * rg // (wmw * wnw))
+        waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", m.group(3))]
+        assert waits[:3] == [(ns - 2) * ppw, (ns - 3) * ppw, (ns - 3) * ppw], (m.group(1), waits[:6])
+    assert seen >= 10
