@@ -40,7 +40,7 @@ struct PipeParams {
     Epilogue epi;
     LnFuse ln;                          // EPI_BIAS_RES_LN only
     unsigned long long* stamps;         // diagnostic (ac_gemm_debug_stamps): 4 shader-clock stamps per workgroup, or null
-    int krot;                           // XCD x starts its k-loop at stage x nk / 8 and wraps (ac_gemm_set_krot; default on)
+    int krot;                           // experiment: XCD x starts its k-loop at stage x nk / 8 and wraps (ac_gemm_set_krot)
 };
 
 // shader-clock stamp `i` of this workgroup (wave 0 only; a wave-uniform branch on a kernel argument)
@@ -252,12 +252,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
         }
     }
     int iss = 0;                                                        // next stage to issue
-    // Rotated k order (round 4): in a one-round launch all workgroups run their k-loops in lockstep, so the 8 XCDs' L2s would miss
-    // on the SAME slice of W at the same moment, every stage.  XCD x starts at stage x nk / 8 and wraps: the XCDs ask the fabric
-    // for 8 different slices, and what one fetched is in the memory-side cache when the next gets there.  Measured in the encoder
-    // (profiles/r04/krot_ab_base.txt): 5.99 -> 5.51 ms bf16x3, 4.30 -> 3.83 ms fp16x2; no change for multi-round launches.
-    // A tile's fp32 accumulation order now depends on its XCD: deterministic per shape, rounding-level differences between
-    // shapes / batch positions (tests: integer operands, where every order is exact, must give the exact product).
+    // Rotated k order (experiment, ac_gemm_set_krot(1), default off): workgroups on XCD x start at stage x nk / 8 and wrap, so the
+    // 8 XCDs fetch different slices of the operands at any moment.  Measured in the encoder (profiles/r04/krot_ab_base.txt):
+    // 4.89 vs 4.91 ms bf16x3, 3.23 vs 3.24 ms fp16x2 -- nothing, once the ring really runs ahead (it had looked like -8 % on a
+    // build whose ring was drained every stage by a compiler-inserted vmcnt(0): DESIGN 2.3g).  In-order keeps every output
+    // element the same sum in the same order whatever the tile or the batch.
     int a_cur = prm.krot ? ((int)(blockIdx.x & 7) * nk / 8) : 0;         // the stage the pointers are at (wave-uniform)
     if (a_cur) {
 #pragma unroll
@@ -402,12 +401,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
     if (prm.stamps) { wait_vm<0>(); stamp(prm, wave, 3); }
 }
 
-std::atomic<int> g_krot{-1};                  // ac_gemm_set_krot (-1 = environment AC_GEMM_KROT, default on)
+std::atomic<int> g_krot{-1};                  // ac_gemm_set_krot (-1 = environment AC_GEMM_KROT, default off)
 int krot_enabled() {
     int v = g_krot.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("AC_GEMM_KROT");
-        v = (e && atoi(e) == 0) ? 0 : 1;
+        v = (e && atoi(e) != 0) ? 1 : 0;
         g_krot.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -467,7 +466,7 @@ int launch_cfg(int cls, bool cp, const PipeParams& p, hipStream_t stream) {
 
 /* diagnostic: the ring-staged GEMM kernels write 4 shader-clock stamps per workgroup (start, ring filled, loop done, stores
  * drained) into d_buf[4 * workgroup] while d_buf is set and holds the grid (tools/gemm_bench.hip); null switches it off. */
-/* 1 (default) = the XCDs start their k-loops at different stages; 0 = all at stage 0 (bit-for-bit comparisons between kernels) */
+/* experiment switch: 1 = the XCDs start their k-loops at different stages; 0 (default) = all at stage 0 */
 extern "C" int ac_gemm_set_krot(int on) { g_krot.store(on ? 1 : 0, std::memory_order_relaxed); return AC_OK; }
 extern "C" int ac_gemm_debug_stamps(unsigned long long* d_buf, int64_t capacity_workgroups) {
     g_stamps = d_buf;

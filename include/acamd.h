@@ -248,13 +248,11 @@ int ac_gemm_debug_stamps(unsigned long long* d_buf, int64_t capacity_workgroups)
  * one ring configuration (cfg as in ac_gemm_set_variant) for planes GEMMs with N output columns and inner dimension K;
  * "" = two-buffer kernels everywhere; NULL restores the built-in table (tools/encode_ab.py). */
 int ac_gemm_set_pipe_table(const char* spec);
-/* k order of the ring-staged kernels.  1 (default): workgroups on XCD x start their k-loop at stage x * nk / 8 and wrap around,
- * so the 8 XCDs fetch 8 different slices of the operands at any moment instead of missing on the same lines together (one-round
- * launches run in lockstep): -8 % / -11 % encoder time at BASELINE configs[1] (bf16x3 / fp16x2).  The fp32 accumulation order of
- * a tile then depends on its XCD: results are deterministic for a given shape, and differ from the in-order ones -- and between
- * shapes, i.e. between batch compositions -- by fp32 rounding (~1e-7 on the unit-norm embedding).  0: every workgroup in order
- * (the same sums in the same order whatever the tile: what the bit-for-bit kernel comparisons of the tests use).  Env
- * AC_GEMM_KROT sets the initial value. */
+/* Experiment switch of the ring-staged kernels (default 0).  1: workgroups on XCD x start their k-loop at stage x * nk / 8 and
+ * wrap around, so the 8 XCDs fetch 8 different slices of the operands at any moment (one-round launches run in lockstep).  Measured
+ * in the encoder at BASELINE configs[1]: no difference (4.89 vs 4.91 ms) -- the ring already hides those misses; kept for the
+ * A/B (tools/encode_krot_ab.py).  With it a tile's fp32 accumulation order depends on its XCD (rounding-level differences
+ * between shapes); 0 keeps every output element the same sum in the same order.  Env AC_GEMM_KROT sets the initial value. */
 int ac_gemm_set_krot(int on);
 /* The same for the fp16x2 kernels of AC_GEMM_F16X2 (a shape the table does not name, or names with cfg 0, keeps the built-in
  * choice -- there is no two-buffer kernel for fp16x2 operands); the configurations built for fp16x2 only are listed in

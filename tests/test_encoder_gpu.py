@@ -222,8 +222,8 @@ def test_padding_free_path_equals_padded_path(regime, cuda_dev):
         if b == 37:
             check_peaked(regime, model, ids, mask, types)
         want = bert_oracle.encode_cls(model, ids, types, mask)
-        # in-order k walk (ac_gemm_set_krot(0)): the same sums in the same order in both layouts; the default rotated walk
-        # (a tile's k order depends on its XCD, i.e. on the layout): equal to fp32 rounding, which the peaked model amplifies
+        # in-order k walk (the default): the same sums in the same order in both layouts; the rotated walk (experiment switch:
+        # a tile's k order depends on its XCD, i.e. on the layout): equal to fp32 rounding, which the peaked model amplifies
         for krot, tol in ((0, 1e-6), (1, 2e-5 if regime == "peaked" else 2e-6)):
             nv.lib().ac_gemm_set_krot(krot)
             try:
@@ -232,7 +232,7 @@ def test_padding_free_path_equals_padded_path(regime, cuda_dev):
                 c = padded.encode_cls(ids, types, mask)
                 assert padded.last_tokens == b * S
             finally:
-                nv.lib().ac_gemm_set_krot(1)
+                nv.lib().ac_gemm_set_krot(0)
             assert (a - c).abs().max().item() <= tol, (krot, b, S, (a - c).abs().max().item())
             assert (a.cpu() - want).abs().max().item() < 1e-4
     # not right-padded -> padded path, same answer as transformers

@@ -28,7 +28,7 @@ def arith():
     yield lambda mode: nv.check(lib.ac_gemm_set_arith(mode), "ac_gemm_set_arith")
     lib.ac_gemm_set_arith(before)
     lib.ac_gemm_set_pipe_table_f16(None)
-    lib.ac_gemm_set_krot(1)
+    lib.ac_gemm_set_krot(0)
 
 
 def _planes_f16(nv, dev, Xd, log2):
@@ -147,7 +147,7 @@ def test_f16x2_gemm_every_ring_configuration_agrees(cuda_dev, arith):
     want = _ref(A, W, b, None, 0)
     S = np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T
     base = None
-    nv.lib().ac_gemm_set_krot(0)                                        # k in order for every workgroup: tile-independent sums
+    nv.lib().ac_gemm_set_krot(0)                                        # (the default) k in order: tile-independent sums
     for cfg in (222232, 124261, 124262, 224242, 234232, 322432, 244232, 244242, 234242, 224262, 124282):
         nv.check(nv.lib().ac_gemm_set_pipe_table_f16(f"{N}x{K}={cfg}".encode()), "ac_gemm_set_pipe_table_f16")
         got = _linear_f16(nv, cuda_dev, A, W, b, None, 0)
@@ -155,7 +155,7 @@ def test_f16x2_gemm_every_ring_configuration_agrees(cuda_dev, arith):
         if base is None:
             base = got
         assert np.array_equal(got, base), cfg                           # same products, same order, whatever the tile
-    # the default rotated k order (ac_gemm_set_krot(1)) with integer operands: every order is exact, so the exact product
+    # the rotated k order (ac_gemm_set_krot(1), experiment switch) with integer operands: every order is exact, so the exact product
     nv.lib().ac_gemm_set_krot(1)
     Ai = rng.integers(-3, 4, (M, K)).astype(np.float32)
     Wi = rng.integers(-3, 4, (N, K)).astype(np.float32)

@@ -18,7 +18,7 @@ def arith():
     before = lib.ac_gemm_get_arith()
     yield lambda mode: nv.check(lib.ac_gemm_set_arith(mode), "ac_gemm_set_arith")
     lib.ac_gemm_set_arith(before)
-    lib.ac_gemm_set_krot(1)
+    lib.ac_gemm_set_krot(0)
 
 
 def _planes(nv, dev, Xd):
@@ -235,7 +235,7 @@ def test_ring_staged_kernels_equal_the_two_buffer_kernels_bit_for_bit(M, N, K, a
     want = _ref(A, W, b, R, act)
     arith(BF16X3)
     lib = nv.lib()
-    lib.ac_gemm_set_krot(0)          # every workgroup walks k in order: the same sums in the same order whatever the tile
+    lib.ac_gemm_set_krot(0)          # (the default) every workgroup walks k in order: the same sums in the same order whatever the tile
     try:
         nv.check(lib.ac_gemm_set_variant(1), "ac_gemm_set_variant")
         base = _linear(nv, cuda_dev, A, W, b, R, act, "aw")
@@ -250,6 +250,7 @@ def test_ring_staged_kernels_equal_the_two_buffer_kernels_bit_for_bit(M, N, K, a
         assert np.array_equal(_linear(nv, cuda_dev, A, W, b, R, act, "aw"), base)
     finally:
         lib.ac_gemm_set_variant(0)
+        lib.ac_gemm_set_krot(0)
 
 
 @pytest.mark.parametrize("M,N,K,res", [
@@ -259,7 +260,7 @@ def test_ring_staged_kernels_equal_the_two_buffer_kernels_bit_for_bit(M, N, K, a
     (5141, 768, 3072, True),        # the long k-loop
 ])
 def test_rotated_k_order_sums_every_stage_exactly_once(M, N, K, res, cuda_dev, arith):
-    """ac_gemm_set_krot(1), the default: workgroups on XCD x walk the k stages x nk / 8 ... nk - 1, 0 ... x nk / 8 - 1.  With small
+    """ac_gemm_set_krot(1) (experiment switch, default off): workgroups on XCD x walk the k stages x nk / 8 ... nk - 1, 0 ... x nk / 8 - 1.  With small
     INTEGER operands every partial sum is exact in fp32 whatever the order, so each configuration must return the exact integer
     product bit for bit -- a stage skipped, repeated or read from the wrong ring slot after the wrap cannot pass.  On random
     operands the rotated result stays within fp32 rounding of the in-order one (and inside the a-priori bound)."""
@@ -291,3 +292,4 @@ def test_rotated_k_order_sums_every_stage_exactly_once(M, N, K, res, cuda_dev, a
             assert np.abs(got - inorder).max() <= 64 * 2.0 ** -24 * np.abs(wantr).max() + 1e-6, cfg
     finally:
         lib.ac_gemm_set_variant(0)
+        lib.ac_gemm_set_krot(0)

@@ -22,7 +22,6 @@ ids = torch.randint(1000, 30000, (B, S), generator=g); ids[:, 0] = 101
 lens = torch.randint(8, S + 1, (B,), generator=g); lens[0] = S
 mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64)
 ids = (ids * mask).to(dev); mask = mask.to(dev); types = torch.zeros_like(ids)
-nv.lib().ac_gemm_set_krot(0)          # k in order in every workgroup: the tables then compute the same bits (asserted below)
 tables = [a.split("=", 1) for a in args] or [["base", ""]]
 times = {n: [] for n, _ in tables}
 ref = None

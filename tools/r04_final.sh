@@ -18,7 +18,7 @@ AC_BENCH_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 5 --warmup 1 
   AC_KNN_PLANE=0 timeout 300 python -m pytest tests/test_knn_batch_gpu.py -q -m gpu -k "not plane and not load_rows and not second_search and not push_pressure" 2>&1 | tail -1
   AC_GEMM_ARITH=f32 timeout 400 python -m pytest tests/test_encoder_gpu.py -q -m gpu -k "not fused_into and not starved and not sticky" 2>&1 | tail -1
   AC_GEMM_ARITH=f16x2 timeout 400 python -m pytest tests/test_encoder_gpu.py tests/test_classifier_gpu.py tests/test_golden_gpu.py -q -m gpu 2>&1 | tail -1
-  AC_GEMM_KROT=0 timeout 400 python -m pytest tests/test_encoder_gpu.py tests/test_golden_gpu.py -q -m gpu 2>&1 | tail -1
+  AC_GEMM_KROT=1 timeout 400 python -m pytest tests/test_encoder_gpu.py tests/test_golden_gpu.py -q -m gpu 2>&1 | tail -1
   AC_LN_FUSION=0 timeout 400 python -m pytest tests/test_encoder_gpu.py tests/test_classifier_gpu.py -x -q -m gpu -k "not starved and not sticky and not fused_into and not gave_up" 2>&1 | tail -1 ) > $O/alternate_paths.txt 2>&1
 cat $O/alternate_paths.txt
 cd /tmp && export TMPDIR=/tmp; T=/tmp/prof_fin4; rm -rf $T
