@@ -27,9 +27,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // dst: the fp32 row; planes (optional): the same row as bf16x3 operand planes of a [rows, H] matrix
+template <bool F16 = false>      // (compile time: as a run-time flag the two plane forms cost embed_ln_kernel 18 -> 23 us)
 __device__ __forceinline__ void layernorm_store(f32x4 (&x)[kMaxVec], int H, int lane, const float* g,
                                                 const float* b, float eps, float* dst, uint16_t* planes = nullptr,
-                                                int64_t rows = 0, int64_t row = 0, int f16 = 0) {
+                                                int64_t rows = 0, int64_t row = 0) {
     const int nv = H >> 2;
     float s = 0.f;
 #pragma unroll
@@ -58,18 +59,19 @@ __device__ __forceinline__ void layernorm_store(f32x4 (&x)[kMaxVec], int H, int 
             y.w = (x[e].w - mean) * rstd * gg.w + bb.w;
             *reinterpret_cast<f32x4*>(dst + 4 * c4) = y;
             if (planes)       // lanes 2j, 2j+1 fill the two halves of k-slot j
-                ac::emit_planes4(planes + ac::plane_off(rows, row, 4 * c4), rows * (int64_t)H, y, f16);
+                ac::emit_planes4(planes + ac::plane_off(rows, row, 4 * c4), rows * (int64_t)H, y, F16);
         }
     }
 }
 
 // word + position + token_type embeddings -> LayerNorm (modeling_bert.py:85-107)
 // tok_src (packed / padding-free mode): row t of the output is token tok_src[t] = seq * S + pos of the [b, S] inputs
+template <bool F16>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const int64_t* type_ids, int T, int S,
                                                        int H, const float* word, const float* pos,
                                                        const float* type, const float* g, const float* b,
                                                        float eps, float* out, uint16_t* planes,
-                                                       const int32_t* __restrict__ tok_src = nullptr, int f16 = 0) {
+                                                       const int32_t* __restrict__ tok_src = nullptr) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -93,11 +95,12 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const
             }
         }
     }
-    layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t, f16);
+    layernorm_store<F16>(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t);
 }
 
-__global__ __launch_bounds__(256) void ln_kernel(const float* in, int T, int H, const float* g, const float* b,
-                                                 float eps, float* out, uint16_t* planes, int64_t in_stride, int f16 = 0) {
+template <bool F16>
+__global__ __launch_bounds__(256) void ln_kernel_t(const float* in, int T, int H, const float* g, const float* b,
+                                                   float eps, float* out, uint16_t* planes, int64_t in_stride) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -108,7 +111,13 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* in, int T, int H, 
         const int c4 = lane + 64 * e;
         if (c4 < nv) x[e] = *reinterpret_cast<const f32x4*>(in + (int64_t)t * in_stride + 4 * c4);
     }
-    layernorm_store(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t, f16);
+    layernorm_store<F16>(x, H, lane, g, b, eps, out + (int64_t)t * H, planes, T, t);
+}
+
+inline void launch_ln(bool f16, int blocks, hipStream_t stream, const float* in, int T, int H, const float* g, const float* b,
+                      float eps, float* out, uint16_t* planes, int64_t in_stride) {
+    if (f16) hipLaunchKernelGGL(ln_kernel_t<true>, dim3(blocks), dim3(256), 0, stream, in, T, H, g, b, eps, out, planes, in_stride);
+    else hipLaunchKernelGGL(ln_kernel_t<false>, dim3(blocks), dim3(256), 0, stream, in, T, H, g, b, eps, out, planes, in_stride);
 }
 
 // last_hidden_state[:, 0, :] -> F.normalize(p=2, dim=1, eps=1e-12)
@@ -572,9 +581,13 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
     const int ln_panels = ac::pipe_ln_panels(T);
     if (fuse_ln) AC_HIP_CHECK(hipMemsetAsync(base + ws.lnctl, 0, ws.lnctl_bytes, stream));
 
-    hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, T, S, H,
-                       w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x,
-                       pl ? xp : nullptr, tok_src, (int)f16);
+    if (f16)
+        hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, T, S, H,
+                           w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x, xp, tok_src);
+    else
+        hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, T, S, H,
+                           w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x,
+                           pl ? xp : nullptr, tok_src);
     AC_LAUNCH_CHECK();
     const int dh = c.hidden / c.heads;                // 64, or 32 (MiniLM family)
     const float scale = 1.0f / sqrtf((float)dh);
@@ -631,8 +644,7 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
                                               0.f, 0, ao_w3, lp ? ctxp : nullptr));
             if (rc) return rc;
             // (last layer: x is overwritten with b compact rows; its old contents are no longer needed)
-            hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln1_g[l], w->ln1_b[l],
-                               c.ln_eps, last ? ctx : x, lp ? xp : nullptr, (int64_t)H, (int)f16);
+            launch_ln(f16, lblocks, stream, y, Ml, H, w->ln1_g[l], w->ln1_b[l], c.ln_eps, last ? ctx : x, lp ? xp : nullptr, (int64_t)H);
             AC_LAUNCH_CHECK();
         }
         float* x1 = last ? ctx : x;                    // ctx is free again after the AO projection
@@ -655,8 +667,7 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
                                           ff2_w3, lp ? ffnp : nullptr));
         if (rc) return rc;
         // the next layer's QKV GEMM reads x as planes; the last layer's output (b compact rows) stays fp32
-        hipLaunchKernelGGL(ln_kernel, dim3(lblocks), dim3(256), 0, stream, y, Ml, H, w->ln2_g[l], w->ln2_b[l],
-                           c.ln_eps, x, lp ? xp : nullptr, (int64_t)H, (int)f16);
+        launch_ln(f16, lblocks, stream, y, Ml, H, w->ln2_g[l], w->ln2_b[l], c.ln_eps, x, lp ? xp : nullptr, (int64_t)H);
         AC_LAUNCH_CHECK();
     }
     // after the CLS-only last layer x holds b compact rows (sequence stride 1)
@@ -830,7 +841,7 @@ int modernbert_encode_impl(const ac_modernbert_config* cfg, const ac_modernbert_
     const bool pl = wplanes && ac::linear_takes_planes(T, H, H) && ac::linear_takes_planes(T, H, I) && (H % 8) == 0;
 
     // embeddings -> LayerNorm: this IS the input of layer 0's attention (attn_norm = Identity there)
-    hipLaunchKernelGGL(embed_ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, d_ids, (const int64_t*)nullptr, T, S, H,
+    hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(tok_blocks), dim3(256), 0, stream, d_ids, (const int64_t*)nullptr, T, S, H,
                        w->tok_emb, (const float*)nullptr, (const float*)nullptr, w->emb_norm_g,
                        w->emb_norm_b ? w->emb_norm_b : zb, c.norm_eps, x, pl ? xnp : nullptr, tok_src);
     AC_LAUNCH_CHECK();
@@ -839,7 +850,7 @@ int modernbert_encode_impl(const ac_modernbert_config* cfg, const ac_modernbert_
         const float* a_in = x;             // attention input rows (fp32) -- x itself for layer 0
         if (l > 0) {
             AC_REQUIRE(w->attn_norm_g[l] != nullptr, AC_EINVAL, "modernbert: attn_norm weight of layer %d is NULL", l);
-            hipLaunchKernelGGL(ln_kernel, dim3(tok_blocks), dim3(256), 0, stream, x, T, H, w->attn_norm_g[l],
+            hipLaunchKernelGGL(ln_kernel_t<false>, dim3(tok_blocks), dim3(256), 0, stream, x, T, H, w->attn_norm_g[l],
                                opt(w->attn_norm_b, l), c.norm_eps, xn, pl ? xnp : nullptr, (int64_t)H);
             AC_LAUNCH_CHECK();
             a_in = xn;
@@ -876,7 +887,7 @@ int modernbert_encode_impl(const ac_modernbert_config* cfg, const ac_modernbert_
         rc = ac::linear_f32(ctx, H, w->wo[l], H, opt(w->wo_b, l), resid, ldres, y, H, Ml, H, H, 0, nullptr, 1.f,
                             stream, 0.f, 0, wplanes ? w->wo3[l] : nullptr, (pl && !last) ? ctxp : nullptr);
         if (rc) return rc;
-        hipLaunchKernelGGL(ln_kernel, dim3((Ml + 3) / 4), dim3(256), 0, stream, y, Ml, H, w->mlp_norm_g[l],
+        hipLaunchKernelGGL(ln_kernel_t<false>, dim3((Ml + 3) / 4), dim3(256), 0, stream, y, Ml, H, w->mlp_norm_g[l],
                            opt(w->mlp_norm_b, l), c.norm_eps, xn, lp ? xnp : nullptr, (int64_t)H);
         AC_LAUNCH_CHECK();
         if (lp && w->wi_interleaved32) {
@@ -899,7 +910,7 @@ int modernbert_encode_impl(const ac_modernbert_config* cfg, const ac_modernbert_
         if (rc) return rc;
     }
     // after the CLS-only last layer x holds b compact rows: final LayerNorm, then L2-normalise
-    hipLaunchKernelGGL(ln_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, b, H, w->final_norm_g,
+    hipLaunchKernelGGL(ln_kernel_t<false>, dim3((b + 3) / 4), dim3(256), 0, stream, x, b, H, w->final_norm_g,
                        w->final_norm_b ? w->final_norm_b : zb, c.norm_eps, xn, (uint16_t*)nullptr, (int64_t)H);
     AC_LAUNCH_CHECK();
     hipLaunchKernelGGL(cls_normalize_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, xn, b, 1, H, d_out, ldo);
