@@ -2,6 +2,7 @@
 limit of their occupancy (256 VGPRs, two waves per SIMD), and a few more live values make hipcc spill -- a scratch reload with
 its s_waitcnt vmcnt(0) inside the k-loop drains the whole LDS-DMA ring every stage (seen twice while tuning: +8 .. 14 % time).
 The device listing must show no scratch for them."""
+import functools
 import os
 import re
 import subprocess
@@ -14,12 +15,18 @@ CSRC = os.path.join(ROOT, "adaptive-classifier_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-def kernel_resources(src):
+@functools.lru_cache(maxsize=None)
+def listing(src):
+    """device assembly of one source file (compiled once per test session)"""
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-S",
                                "--cuda-device-only", os.path.join(CSRC, src), "-o", out], stderr=subprocess.DEVNULL)
-        text = open(out).read()
+        return open(out).read()
+
+
+def kernel_resources(src):
+    text = listing(src)
     res = {}
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
         name, body = m.group(1), m.group(2)
@@ -45,11 +52,7 @@ def test_streaming_sweeps_keep_their_prefetch_queue():
     """The two bandwidth-bound sweeps wait on COUNTED vmcnt values in their k-loops.  A flat load there (a volatile access to
     LDS through a generic pointer compiles to one) counts on vmcnt as well and forces s_waitcnt vmcnt(0) -- the whole prefetch
     queue -- once per row tile: the listing of these kernels must hold no flat memory instruction at all."""
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-S",
-                               "--cuda-device-only", os.path.join(CSRC, "knn_l2.hip"), "-o", out], stderr=subprocess.DEVNULL)
-        text = open(out).read()
+    text = listing("knn_l2.hip")
     seen = 0
     for m in re.finditer(r"^(_ZN\S*(knn_sweep_ring|knn_plane_sweep)\S*):[^\n]*\n(.*?)\.Lfunc_end", text, re.S | re.M):
         seen += 1
@@ -65,11 +68,7 @@ def test_ring_gemm_loops_wait_on_counted_vmcnt_only():
     writes in flight -- it did when the fragments were loaded as uint4 and converted at the MFMA (round 4), right after every
     counted wait, and the encoder went from 4.96 to 6.09 ms.  For every instantiation with a ring of >= 4 slots the first three
     vmcnt waits of the listing must therefore be the counted, non-zero ones."""
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-S",
-                               "--cuda-device-only", os.path.join(CSRC, "gemm_pipe.hip"), "-o", out], stderr=subprocess.DEVNULL)
-        text = open(out).read()
+    text = listing("gemm_pipe.hip")
     seen = 0
     for m in re.finditer(r"^(_ZN\S*gemm_pipe_ntI(\S+?)EEvNS\S*):[^\n]*\n(.*?)\.Lfunc_end", text, re.S | re.M):
         args = [int(x) for x in re.findall(r"L[ib](\d+)", m.group(2) + "E")]  # EPI TM TN WMW WNW NS CP PIPE AR
