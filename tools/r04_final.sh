@@ -15,7 +15,7 @@ print(d['stages_ms'], d.get('parity'))"
 AC_BENCH_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 5 --warmup 1 > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2_gloo.err; echo "gpus2 rc=$? lines=$(grep -c '^{' $O/bench_gpus2_gloo.json)"
 # (tests that assert WHICH form ran are left out of the run that switches that form off)
 ( AC_KNN_RING=0 timeout 300 python -m pytest tests/test_knn_gpu.py -q -m gpu -k "not lds_ring" 2>&1 | tail -1
-  AC_KNN_PLANE=0 timeout 300 python -m pytest tests/test_knn_batch_gpu.py -q -m gpu -k "not plane and not load_rows and not second_search and not push_pressure" 2>&1 | tail -1
+  AC_KNN_PLANE=0 timeout 300 python -m pytest tests/test_knn_batch_gpu.py -q -m gpu -k "not plane and not load_rows and not second_search and not push_pressure and not incrementally" 2>&1 | tail -1
   AC_GEMM_ARITH=f32 timeout 400 python -m pytest tests/test_encoder_gpu.py -q -m gpu -k "not fused_into and not starved and not sticky" 2>&1 | tail -1
   AC_GEMM_ARITH=f16x2 timeout 400 python -m pytest tests/test_encoder_gpu.py tests/test_classifier_gpu.py tests/test_golden_gpu.py -q -m gpu 2>&1 | tail -1
   AC_GEMM_KROT=1 timeout 400 python -m pytest tests/test_encoder_gpu.py tests/test_golden_gpu.py -q -m gpu 2>&1 | tail -1
