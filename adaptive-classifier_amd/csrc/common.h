@@ -123,7 +123,7 @@ __device__ __forceinline__ void split8(const f32x4_t& x0, const f32x4_t& x1, uin
 // that range makes h = inf, l = -inf, hence NaN in every output it feeds: the caller sees non-finite rows and repeats the
 // call in bf16x3 (adaptive_classifier/encoder.py), it does not get a silently wrong number.
 constexpr int kF16ActLog2 = 6, kF16WLog2 = 10;
-constexpr float kF16ActScale = 64.0f, kF16OutScale = 1.0f / 65536.0f;
+constexpr float kF16ActScale = (float)(1 << kF16ActLog2), kF16OutScale = 1.0f / (float)(1 << (kF16ActLog2 + kF16WLog2));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h(float a, float b, float s, uint32_t& h, uint32_t& l) {
     a *= s; b *= s;

@@ -14,6 +14,10 @@
 // operand; six products smallest first, fp32 accumulate -- per output element the same products in the same order as
 // gemm_planes_nt (gemm.hip), hence bit-identical results (tests/test_gemm_split_gpu.py).
 //
+// AR (round 4) = operand planes per stage: 3 = the bf16x3 split above; 2 = the opt-in fp16x2 form (AC_GEMM_F16X2: two fp16 terms of
+// x 2^s per operand, three products l.h + h.l + h.h on v_mfma_f32_32x32x16_f16, accumulator x 2^-16 before the epilogue) -- same
+// ring, same loop, two thirds of the bytes and half the matrix-pipe work per stage.
+//
 // Measured and dropped (profiles/r03/gemm_sweep2.txt): a wave-specialised form (4 loader waves issuing the DMA, the others
 // only reading fragments and multiplying) -- equal or slower on every shape, i.e. the DMA issue cost inside the consumer
 // waves is not what limits the loop.
