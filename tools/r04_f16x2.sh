@@ -9,5 +9,5 @@ cut -c1-400 gpurun_out/f16x2/probe_base.txt | tail -10
 timeout 600 python tools/f16x2_probe.py --large --no-sweep > gpurun_out/f16x2/probe_large.txt 2>&1; tail -3 gpurun_out/f16x2/probe_large.txt
 python tools/encode_krot_ab.py --large > gpurun_out/f16x2/krot_ab_large.txt 2>&1; tail -4 gpurun_out/f16x2/krot_ab_large.txt
 if [ -d tools/ab/old_tree ]; then
-  (python tools/ab/time_encode.py tools/ab/old_tree "tree before the fp16x2 work (e5dd58b)"; python tools/ab/time_encode.py . "this tree") 2>&1 | grep encode | tee gpurun_out/f16x2/old_vs_new_same_box.txt
+  (python tools/time_encode_tree.py tools/ab/old_tree "tree before the fp16x2 work (e5dd58b)"; python tools/time_encode_tree.py . "this tree") 2>&1 | grep encode | tee gpurun_out/f16x2/old_vs_new_same_box.txt
 fi
