@@ -137,7 +137,11 @@ class HipBertEncoder:
         self._planes_f16 = None               # fp16x2 weight planes (enable_f16x2)
         self.f16x2_overflows = 0              # encode_cls calls repeated in bf16x3 because an activation left the fp16 range
         if nv.lib().ac_gemm_get_arith() == nv.AC_GEMM_F16X2:     # AC_GEMM_ARITH=f16x2 in the environment
-            self.enable_f16x2()
+            try:
+                self.enable_f16x2()
+            except nv.NativeError as e:                           # (an explicit enable_f16x2() call raises; a process-wide
+                import logging                                    #  preference does not stop a model from loading)
+                logging.getLogger(__name__).warning("%s -- this encoder stays in bf16x3", e)
 
     # -- opt-in fp16x2 arithmetic of the token-row GEMMs (include/acamd.h: AC_GEMM_F16X2) ------
     F16X2_MAX_WEIGHT = 63.9                   # |w| 2^10 must stay below fp16's 65504
