@@ -41,7 +41,9 @@ class ac_head_dims(ctypes.Structure):
 
 class ac_bert_config(ctypes.Structure):
     _fields_ = [("hidden", c_int), ("layers", c_int), ("heads", c_int), ("intermediate", c_int),
-                ("vocab", c_int), ("max_pos", c_int), ("type_vocab", c_int), ("ln_eps", c_float)]
+                ("vocab", c_int), ("max_pos", c_int), ("type_vocab", c_int), ("ln_eps", c_float),
+                # per-call options, 0 = process default, else value + 1 (include/acamd.h)
+                ("gemm_arith_opt", c_int), ("ln_fusion_opt", c_int), ("one_launch_opt", c_int)]
 
 
 class ac_prune_job(ctypes.Structure):
@@ -112,6 +114,7 @@ _SIGNATURES = {
     "ac_gemm_set_ln_fusion": (c_int, [c_int]),
     "ac_gemm_ln_fusion_launches": (c_int64, []),
     "ac_set_persistent_kernels": (c_int, [c_int]),
+    "ac_clock_stamp": (c_int, [c_void_p, c_void_p]),
     "ac_gemm_occupancy": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "ac_split_bf16x3": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "ac_split_f16x2": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),

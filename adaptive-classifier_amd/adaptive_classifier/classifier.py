@@ -82,12 +82,15 @@ class AdaptiveClassifier:
             if tokenizer is None:
                 tokenizer = AutoTokenizer.from_pretrained(model_name, trust_remote_code=trust_remote_code)
         self.model = encoder
+        # config["gemm_arith"]: "f32" | "bf16x3" | "f16x2" (opt-in, include/acamd.h) | absent = the process-wide default.
+        # PER OBJECT: it travels with every encoder call this classifier makes (encode_cls(arith=...) -> ac_bert_config.
+        # gemm_arith_opt); no process-wide switch is touched, other classifiers -- even on the same encoder -- keep theirs.
+        self._gemm_arith = None
         if (config or {}).get("gemm_arith") is not None:
-            # "f32" | "bf16x3" (the default) | "f16x2" (opt-in, include/acamd.h): process-wide, like the environment variable
-            mode = {"f32": nv.AC_GEMM_F32, "bf16x3": nv.AC_GEMM_BF16X3, "f16x2": nv.AC_GEMM_F16X2}[config["gemm_arith"]]
-            nv.check(nv.lib().ac_gemm_set_arith(mode), "ac_gemm_set_arith")
-            if mode == nv.AC_GEMM_F16X2 and hasattr(encoder, "enable_f16x2"):
-                encoder.enable_f16x2()
+            from .encoder import arith_mode
+            self._gemm_arith = arith_mode(config["gemm_arith"])                # ValueError on an unknown name
+            if self._gemm_arith == nv.AC_GEMM_F16X2 and hasattr(encoder, "enable_f16x2"):
+                encoder.enable_f16x2()                                           # (builds the fp16 weight planes once; range-checked)
         if tokenizer is not None and (config or {}).get("device_tokenizer", True):
             # BERT WordPiece vocabularies are tokenised on the device (ac_wordpiece_encode); anything else stays as given
             from .tokenizer import maybe_device_tokenizer
@@ -122,7 +125,7 @@ class AdaptiveClassifier:
             try:
                 params = inspect.signature(self.model.encode_cls).parameters
                 anykw = any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
-                opts = {name for name in ("verify", "force_layered") if anykw or name in params}
+                opts = {name for name in ("verify", "force_layered", "arith") if anykw or name in params}
             except (TypeError, ValueError):
                 opts = set()
             cached = self._enc_opts = (self.model, opts)
@@ -139,6 +142,8 @@ class AdaptiveClassifier:
             kw["verify"] = verify
         if "force_layered" in opts:
             kw["force_layered"] = force_layered
+        if "arith" in opts and getattr(self, "_gemm_arith", None) is not None:
+            kw["arith"] = self._gemm_arith
         return self.model.encode_cls(input_ids, token_type_ids, attention_mask, **kw)
 
     def _embed_device(self, texts: List[str], verify: bool = True, force_layered: bool = False) -> torch.Tensor:
@@ -521,9 +526,18 @@ class AdaptiveClassifier:
         encoder call and repeat it instead: _predict_with_retry.)"""
         gave_up = getattr(self.model, "ln_fusion_aborted", None)
         if gave_up is not None and gave_up():
-            nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
+            self._ln_fusion_off()
             raise nv.NativeError("encoder: the fused LayerNorm epilogue gave up waiting for the tiles of a row panel "
-                                 "(device shared or CU-masked?); the fusion is now off for this process -- repeat the call")
+                                 "(device shared or CU-masked?); the fusion is now off for this encoder -- repeat the call")
+
+    def _ln_fusion_off(self):
+        """LayerNorm fusion off for this classifier's encoder (per object; a user-supplied encoder without the option falls back to
+        the process-wide switch)."""
+        off = getattr(self.model, "disable_ln_fusion", None)
+        if off is not None:
+            off()
+        else:
+            nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
 
     def predict(self, text: str, k: int = 5) -> List[Tuple[str, float]]:
         if not text:
@@ -548,11 +562,11 @@ class AdaptiveClassifier:
             gave_up = getattr(self.model, "ln_fusion_aborted", None)
             if gave_up is not None and gave_up():
                 logger.warning("encoder: a fused LayerNorm epilogue gave up (device shared or CU-masked?); LayerNorm fusion is "
-                               "now off for this process and the batch is encoded again")
-                nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
+                               "now off for this encoder and the batch is encoded again")
+                self._ln_fusion_off()
                 res, nan = finish(encode(True, False))
             f16 = getattr(self.model, "f16x2_active", None)
-            if nan and f16 is not None and f16():
+            if nan and f16 is not None and self._f16x2_active():
                 # opt-in fp16x2 arithmetic: an activation beyond fp16's range turns its rows into NaN; back to bf16x3
                 logger.warning("encoder: non-finite result under fp16x2 arithmetic; the encoder goes back to bf16x3 and the "
                                "batch is encoded again")
@@ -560,6 +574,15 @@ class AdaptiveClassifier:
                 self.model.disable_f16x2()
                 res, nan = finish(encode(True, False))
         return res                      # (still NaN: non-finite inputs or weights -- the caller's data, returned as computed)
+
+    def _f16x2_active(self) -> bool:
+        f16 = getattr(self.model, "f16x2_active", None)
+        if f16 is None:
+            return False
+        try:
+            return bool(f16(getattr(self, "_gemm_arith", None)))
+        except TypeError:                       # (an encoder object with the older zero-argument form)
+            return bool(f16())
 
     def _predict_regular(self, text: str, k: int = 5) -> List[Tuple[str, float]]:
         """classifier.py:415-480: prototype scores over ALL classes, head probs over ALL classes,
@@ -576,17 +599,17 @@ class AdaptiveClassifier:
             return res, any(s != s for _, s in res)
         return self._predict_with_retry(encode, finish)
 
-    def predict_batch(self, texts: List[str], k: int = 5, batch_size: int = 32) -> List[List[Tuple[str, float]]]:
+    def predict_batch(self, texts: List[str], k: int = 5, batch_size: Optional[int] = None) -> List[List[Tuple[str, float]]]:
         """classifier.py:1308-1388: top-k prototypes + top-k head classes, fixed 0.7/0.3 weights.
-        `batch_size` bounds the reference's CPU memory (default 32); here it is a LOWER bound on the device batch: a text's result
-        does not depend on which texts share its batch beyond fp32 rounding of the encoder's sums (padding-free forward, exact
-        search; the reference's own batched matmuls are batch-dependent in the same way), and 32 texts are ~600 token rows --
-        a launch-bound encoder call -- so lists are walked in chunks of max(batch_size, config["min_device_batch"]) texts
-        (default 256, what BASELINE configs[1] is quoted on; set it to 1 to get the reference's chunking)."""
+        `batch_size` is the UPPER bound on the texts per encoder call, as in the reference (which defaults it to 32 to bound CPU
+        memory).  Left at None, the device default applies: config["min_device_batch"] (256, what BASELINE configs[1] is quoted
+        on) -- 32 texts are ~600 token rows, a launch-bound encoder call.  A text's result does not depend on which texts share
+        its batch beyond fp32 rounding of the encoder's sums (padding-free forward, exact search; the reference's own batched
+        matmuls are batch-dependent in the same way)."""
         if not texts:
             raise ValueError("Empty input batch")
         out = []
-        batch_size = max(int(batch_size), int(self.config.config.get("min_device_batch", 256)), 1)
+        batch_size = max(int(self.config.config.get("min_device_batch", 256)), 1) if batch_size is None else max(int(batch_size), 1)
         for i in range(0, len(texts), batch_size):
             batch = texts[i:i + batch_size]
             out.extend(self._predict_batch_core(lambda verify, force_layered: self._embed_device(
@@ -776,6 +799,12 @@ class AdaptiveClassifier:
             for key, value in self.adaptive_head.state_dict().items():
                 tensors[f"adaptive_head_{key}"] = value.detach().cpu().contiguous()
         save_file(tensors, str(d / "model.safetensors"))
+        card = d / "README.md"
+        if not card.exists():        # classifier.py:594-599 writes a generated model card here; a minimal one keeps the file set equal
+            card.write_text("---\nlibrary_name: adaptive-classifier\n---\n\n# Adaptive classifier\n\nEncoder: `%s`; %d classes: %s; "
+                            "%d stored examples.\nLoad with `AdaptiveClassifier.load(<this directory>)`.\n"
+                            % (cfg["model_name"], len(self.label_to_id), ", ".join(sorted(self.label_to_id)),
+                               sum(len(v) for v in self.memory.examples.values())))
 
     _save_pretrained = save
 

@@ -35,6 +35,21 @@ ROBERTA_TYPES = ("roberta", "xlm-roberta", "camembert")
 
 SMALL_TOKENS = 32     # up to here ac_bert_encode_cls runs the whole forward as one persistent launch (bert_small.hip): no packing
 
+ARITH_MODES = {"f32": nv.AC_GEMM_F32, "bf16x3": nv.AC_GEMM_BF16X3, "f16x2": nv.AC_GEMM_F16X2}
+
+
+def arith_mode(value):
+    """"f32" | "bf16x3" | "f16x2" | AC_GEMM_* | None (the process-wide default) -> AC_GEMM_* or None; anything else: ValueError."""
+    if value is None:
+        return None
+    if isinstance(value, str):
+        if value not in ARITH_MODES:
+            raise ValueError(f"gemm_arith must be one of {sorted(ARITH_MODES)} (or None for the process default), got {value!r}")
+        return ARITH_MODES[value]
+    if int(value) not in ARITH_MODES.values():
+        raise ValueError(f"gemm_arith: unknown mode {value!r}")
+    return int(value)
+
 
 class HipBertEncoder:
     def __init__(self, hf_bert, device=None, unpad=True):
@@ -45,6 +60,11 @@ class HipBertEncoder:
         self.last_tokens = 0                  # token rows the last encode_cls call actually ran (roofline accounting)
         self.last_one_launch = False          # the last native call ran as the one persistent launch (bert_small.hip)
         self.ln_gave_up = 0                   # encode_cls calls repeated because a fused-LayerNorm exchange gave up
+        # PER-OBJECT options (None = the process-wide default of include/acamd.h): they travel to the native calls inside
+        # ac_bert_config (gemm_arith_opt / ln_fusion_opt) and hold for THIS encoder's calls only; encode_cls(arith=...) overrides
+        # the arithmetic per call (how two classifiers sharing one encoder keep their own).
+        self.arith = None                     # AC_GEMM_* or None
+        self.ln_fusion = None                 # True / False / None; set to False by this encoder once an exchange gave up
         cfg = hf_bert.config
         mtype = getattr(cfg, "model_type", "bert")
         if mtype not in ("bert", "distilbert", "electra") + ROBERTA_TYPES:
@@ -136,7 +156,7 @@ class HipBertEncoder:
         self._gemm_w = {k: per[k] for k in ("qkv_w", "ao_w", "ff1_w", "ff2_w")}
         self._planes_f16 = None               # fp16x2 weight planes (enable_f16x2)
         self.f16x2_overflows = 0              # encode_cls calls repeated in bf16x3 because an activation left the fp16 range
-        if nv.lib().ac_gemm_get_arith() == nv.AC_GEMM_F16X2:     # AC_GEMM_ARITH=f16x2 in the environment
+        if nv.lib().ac_gemm_get_arith() == nv.AC_GEMM_F16X2:     # AC_GEMM_ARITH=f16x2 in the environment (process-wide default)
             try:
                 self.enable_f16x2()
             except nv.NativeError as e:                           # (an explicit enable_f16x2() call raises; a process-wide
@@ -148,8 +168,9 @@ class HipBertEncoder:
 
     def enable_f16x2(self):
         """Build the fp16x2 planes of the four GEMM weights per layer (ac_split_f16x2, once) and hand them to the native
-        encoder.  They are USED while the process-wide arithmetic is AC_GEMM_F16X2 (ac_gemm_set_arith(2) or the environment
-        variable AC_GEMM_ARITH=f16x2) and the call has >= 192 token rows; see include/acamd.h for what the mode trades."""
+        encoder.  They are USED by calls whose arithmetic is AC_GEMM_F16X2 -- the call's `arith`, this encoder's `set_arith`, or
+        the process-wide default (ac_gemm_set_arith(2) / AC_GEMM_ARITH=f16x2) -- with >= 192 token rows; see include/acamd.h for
+        what the mode trades."""
         if self._planes_f16 is None:
             big = max(float(t.abs().max()) for ts in self._gemm_w.values() for t in ts)
             if not big < self.F16X2_MAX_WEIGHT:
@@ -169,8 +190,39 @@ class HipBertEncoder:
             setattr(self.weights, k, None)
         return self
 
-    def f16x2_active(self) -> bool:
-        return bool(self.weights.qkv_wh) and nv.lib().ac_gemm_get_arith() == nv.AC_GEMM_F16X2
+    def effective_arith(self, arith=None) -> int:
+        """The arithmetic a call with per-call option `arith` runs in: the call's, else this encoder's, else the process's."""
+        a = arith_mode(arith)
+        if a is None:
+            a = self.arith
+        return nv.lib().ac_gemm_get_arith() if a is None else a
+
+    def f16x2_active(self, arith=None) -> bool:
+        return bool(self.weights.qkv_wh) and self.effective_arith(arith) == nv.AC_GEMM_F16X2
+
+    def set_arith(self, arith):
+        """This encoder's arithmetic for calls that do not name one ("f32" | "bf16x3" | "f16x2" | None = process default).
+        "f16x2" builds the fp16 weight planes (raises NativeError for weights outside the fp16 range)."""
+        a = arith_mode(arith)
+        if a == nv.AC_GEMM_F16X2:
+            self.enable_f16x2()
+        self.arith = a
+        return self
+
+    def disable_ln_fusion(self):
+        """LayerNorms as separate launches for THIS encoder from now on (what it does itself after an exchange gave up)."""
+        self.ln_fusion = False
+        return self
+
+    def _call_cfg(self, arith=None):
+        """ac_bert_config of one native call: the architecture + this call's options (0 = process default, else value + 1)."""
+        a = arith_mode(arith)
+        if a is None:
+            a = self.arith
+        c = self.ccfg
+        return nv.ac_bert_config(c.hidden, c.layers, c.heads, c.intermediate, c.vocab, c.max_pos, c.type_vocab, c.ln_eps,
+                                 0 if a is None else a + 1,
+                                 0 if self.ln_fusion is None else (2 if self.ln_fusion else 1), 0)
 
     # -- the nn.Module-ish surface classifier.py touches (:1253-1255,1278-1279,1215) ----------
     def eval(self):
@@ -192,8 +244,10 @@ class HipBertEncoder:
         return need.value
 
     def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None, verify=True, force_layered=False,
-                   verify_small=None):
+                   verify_small=None, arith=None):
         """int64 [b, S] ids (+ optional type ids / mask) -> unit-norm CLS embeddings [b, H] on device.
+        arith: this call's GEMM arithmetic ("f32" | "bf16x3" | "f16x2"; None = this encoder's `arith`, else the process default) --
+        a per-call option inside ac_bert_config, no process-wide state is touched.
 
         Two kernels of this forward wait for other workgroups with a BOUNDED wait and poison their rows with NaN when they
         give up (a device shared with another compute process, or under a CU mask): the one persistent launch that runs
@@ -220,24 +274,30 @@ class HipBertEncoder:
         need = self.workspace_bytes(min(b, cb), S)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            # a FRESH workspace starts with clean verdict words (acamd.h: the first 256 bytes): a <= 32-row call that ends up
+            # layer by layer (bert-large: no one-launch kernel; a one-launch abort retried layered) reads them below without
+            # having cleared them, and torch.empty memory is garbage -- a spurious "gave up" would switch the fusion off
+            self._ws[:256].zero_()
+        cfg = self._call_cfg(arith)
         with torch.cuda.device(self.device):
             # the fused-LayerNorm verdict of this call starts clean (sticky over the chunks below; include/acamd.h); a call
             # that runs as the one persistent launch has no such epilogue (and is the latency path: no extra launch)
             if b * S > SMALL_TOKENS or force_layered:
                 nv.check(nv.lib().ac_bert_ln_fusion_clear(nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
                          "ac_bert_ln_fusion_clear")
-            layered = self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered)
+            layered = self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg)
             if verify and layered and self.ln_fusion_aborted():
                 import logging
                 logging.getLogger(__name__).warning(
                     "encoder: a fused LayerNorm epilogue gave up waiting for the tiles of a row panel (device shared or "
-                    "CU-masked?); LayerNorm fusion is now off for this process and the batch is encoded again")
+                    "CU-masked?); LayerNorm fusion is now off for this encoder and the batch is encoded again")
                 self.ln_gave_up += 1
-                nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
+                self.disable_ln_fusion()
+                cfg = self._call_cfg(arith)
                 nv.check(nv.lib().ac_bert_ln_fusion_clear(nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
                          "ac_bert_ln_fusion_clear")
-                self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered)
-            if verify and layered and self.f16x2_active() and not bool(torch.isfinite(out).all()):
+                self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg)
+            if verify and layered and self.f16x2_active(arith) and not bool(torch.isfinite(out).all()):
                 # an activation beyond fp16's range at scale 2^6 turned its rows into NaN (never into a wrong number)
                 import logging
                 logging.getLogger(__name__).warning(
@@ -245,14 +305,15 @@ class HipBertEncoder:
                     "goes back to bf16x3 and the batch is encoded again")
                 self.f16x2_overflows += 1
                 self.disable_f16x2()
-                self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered)
+                self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg)
         return out
 
-    def _run_chunks(self, ids, tt, mk, b, S, cb, out, verify, force_layered):
+    def _run_chunks(self, ids, tt, mk, b, S, cb, out, verify, force_layered, cfg=None):
         """The native calls of one encode_cls: row chunks of <= cb sequences.  Returns True when at least one chunk ran layer
         by layer (the path whose GEMM epilogues may carry the fused LayerNorm)."""
         self.last_tokens = 0
         layered = False
+        cfg = self.ccfg if cfg is None else cfg
         for r0 in range(0, b, cb):
             r1 = min(b, r0 + cb)
             nb = r1 - r0
@@ -268,7 +329,7 @@ class HipBertEncoder:
                     self.last_one_launch = False
                     layered = True
                     nv.check(nv.lib().ac_bert_encode_cls_packed(
-                        ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
+                        ctypes.byref(cfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
                         nv.ptr(None if tt is None else tt[r0:r1]), nb, S, nv.ptr(cu), nv.ptr(src), total, longest,
                         nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(),
                         nv.stream_ptr(self.device)), "ac_bert_encode_cls_packed")
@@ -278,7 +339,7 @@ class HipBertEncoder:
 
             def call(opts):
                 nv.check(nv.lib().ac_bert_encode_cls_opts(
-                    ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
+                    ctypes.byref(cfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
                     nv.ptr(None if tt is None else tt[r0:r1]), nv.ptr(None if mk is None else mk[r0:r1]), nb, S,
                     nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(), opts, ctypes.byref(used),
                     nv.stream_ptr(self.device)), "ac_bert_encode_cls_opts")

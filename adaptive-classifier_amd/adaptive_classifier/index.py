@@ -296,17 +296,24 @@ class HipFlatL2Index:
             raise IndexError("update_rows: row id out of range")
         self._materialize()
         vals = self._as_rows(values).to(self.device)
-        self._store[rows.to(self.device), : self.d] = vals
+        # (the runs are computed BEFORE the store is touched: nothing below can fail between the write and the plane's update)
+        runs = None
         if self._prepared is not None:
-            ids = np.unique(rows.numpy())
+            ids = np.unique(rows.detach().cpu().numpy())
             runs = np.split(ids, np.nonzero(np.diff(ids) != 1)[0] + 1)       # contiguous runs of row ids
+        self._store[rows.to(self.device), : self.d] = vals
+        if runs is not None:
             if len(runs) > 16:
                 self._rows_changed()                                      # many scattered rows: a fresh preparation is cheaper
             else:
-                for run in runs:
-                    if self._prepared is None:
-                        break
-                    self._rows_written(self._n, int(run[0]), int(run.size))
+                try:
+                    for run in runs:
+                        if self._prepared is None:
+                            break
+                        self._rows_written(self._n, int(run[0]), int(run.size))
+                except Exception:
+                    self._rows_changed()                                  # never leave a plane that no longer matches the rows
+                    raise
 
     def search_device(self, q, k):
         """q: [nq, d] fp32 tensor (any device) -> (dist, ids) CUDA tensors; no host sync."""
@@ -322,7 +329,9 @@ class HipFlatL2Index:
             # the call); for a small batch only when the store has already served a search since it was last rebuilt / compacted
             # (appends and in-place updates do not count: once prepared, the plane follows them incrementally)
             if q.shape[0] >= BATCH_MIN_QUERIES or self._searches_since_change >= 1:
-                self._prepared = prepare_store(self._store, self._n, self.d)      # once per store content
+                # (sized for the store's CAPACITY: the first append after the preparation then updates the plane in place
+                #  instead of allocating capacity-sized buffers and copying the whole old plane beside them)
+                self._prepared = prepare_store(self._store, self._n, self.d, capacity=self._store.shape[0])
             else:
                 batch = False
         self._searches_since_change += 1

@@ -525,6 +525,10 @@ int check_cfg(const ac_bert_config* c) {
                "bert: hidden=%d unsupported (must be a multiple of 4 and <= %d)", c->hidden, 64 * 4 * kMaxVec);
     AC_REQUIRE(c->hidden == c->heads * 64 || c->hidden == c->heads * 32, AC_EUNSUPPORTED,
                "bert: head dim %d unsupported (64 or 32)", c->hidden / c->heads);
+    AC_REQUIRE(c->gemm_arith_opt >= 0 && c->gemm_arith_opt <= 3 && c->ln_fusion_opt >= 0 && c->ln_fusion_opt <= 3 &&
+                   c->one_launch_opt >= 0 && c->one_launch_opt <= 2, AC_EINVAL,
+               "bert: per-call options out of range (gemm_arith_opt %d, ln_fusion_opt %d, one_launch_opt %d)", c->gemm_arith_opt,
+               c->ln_fusion_opt, c->one_launch_opt);
     return AC_OK;
 }
 
@@ -686,6 +690,7 @@ extern "C" int ac_bert_encode_cls_opts(const ac_bert_config* cfg, const ac_bert_
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (b == 0) return AC_OK;
+    const ac::CallScope scope(cfg->gemm_arith_opt, cfg->ln_fusion_opt, cfg->one_launch_opt);
     AC_REQUIRE(w && d_ids && d_out && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden, AC_EINVAL,
                "bert_encode_cls: bad arguments (b=%d S=%d max_pos=%d)", b, S, cfg->max_pos);
     if (b * S <= 32 && !(opts & AC_BERT_LAYERED)) {   // a handful of token rows (single-query predict): every layer in ONE persistent launch
@@ -756,6 +761,7 @@ extern "C" int ac_bert_encode_cls_packed(const ac_bert_config* cfg, const ac_ber
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (b == 0) return AC_OK;
+    const ac::CallScope scope(cfg->gemm_arith_opt, cfg->ln_fusion_opt, cfg->one_launch_opt);
     AC_REQUIRE(w && d_ids && d_out && d_cu && d_tok_src && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden &&
                    total_tokens >= b && total_tokens <= b * S && longest >= 1 && longest <= S,
                AC_EINVAL, "bert_encode_cls_packed: bad arguments (b=%d S=%d tokens=%d longest=%d)", b, S, total_tokens, longest);

@@ -193,7 +193,21 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
                      const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int segs, int64_t row_stride,
                      int best_only, hipStream_t stream, int32_t* clear_ctr = nullptr, int32_t* clear_stats = nullptr);
 
-// arithmetic of the LDS-tiled GEMMs (ac_gemm_set_arith / env AC_GEMM_ARITH = f32 | bf16x3 | f16x2)
+// Per-call options (ac_bert_config.gemm_arith_opt / ln_fusion_opt / one_launch_opt): for the duration of ONE native call on the
+// calling thread they take precedence over the process-wide switches (ac_gemm_set_arith, ac_gemm_set_ln_fusion,
+// ac_set_persistent_kernels), which remain as test / A-B hooks and as the default of calls that do not say.  Thread-local and
+// scoped (RAII): no state outlives the call, two objects with different options interleave freely on one or on several threads.
+struct CallOpts { int arith = -1, ln_fusion = -1, one_launch = -1; };     // -1 = not given: the process-wide value
+CallOpts& call_opts();
+struct CallScope {
+    CallOpts saved;
+    CallScope(int arith_opt, int ln_fusion_opt, int one_launch_opt);       // *_opt encoding of acamd.h: 0 = default, value + 1
+    ~CallScope();
+    CallScope(const CallScope&) = delete;
+    CallScope& operator=(const CallScope&) = delete;
+};
+
+// arithmetic of the LDS-tiled GEMMs (per-call option, else ac_gemm_set_arith / env AC_GEMM_ARITH = f32 | bf16x3 | f16x2)
 int gemm_arith();
 void set_gemm_arith(int mode);
 inline bool arith_split() { return gemm_arith() != AC_GEMM_F32; }   // bf16x3, or f16x2 (= bf16x3 wherever no fp16 planes exist)

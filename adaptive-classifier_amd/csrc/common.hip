@@ -20,7 +20,21 @@ static int g_persistent = [] {
     if (const char* e = getenv("AC_BERT_SMALL")) if (atoi(e) == 0) m &= ~2;
     return m;
 }();
-int persistent_mask() { return g_persistent; }
+CallOpts& call_opts() {
+    static thread_local CallOpts o;
+    return o;
+}
+CallScope::CallScope(int arith_opt, int ln_fusion_opt, int one_launch_opt) : saved(call_opts()) {
+    CallOpts& o = call_opts();
+    if (arith_opt > 0) o.arith = arith_opt - 1;
+    if (ln_fusion_opt > 0) o.ln_fusion = ln_fusion_opt - 1;
+    if (one_launch_opt > 0) o.one_launch = one_launch_opt - 1;
+}
+CallScope::~CallScope() { call_opts() = saved; }
+int persistent_mask() {
+    const int o = call_opts().one_launch;              // per-call: bit 1 (bert_small.hip) only
+    return o < 0 ? g_persistent : ((g_persistent & ~2) | (o ? 2 : 0));
+}
 int set_persistent_mask(int m) { const int old = g_persistent; if (m >= 0) g_persistent = m & 3; return old; }
 
 const DevInfo& dev_info() {
@@ -68,3 +82,26 @@ extern "C" int ac_device_info(int* cu_count, int* lds_bytes_per_block, size_t* h
 }
 
 extern "C" int ac_set_persistent_kernels(int mask) { return ac::set_persistent_mask(mask); }
+
+// ---- ac_clock_stamp: (shader clock, 100 MHz real-time clock) of every XCD, for "what clock did this timed region run at" ----
+namespace {
+__global__ void clock_stamp_kernel(unsigned long long* out) {
+    // HW_REG_XCC_ID (hwreg 20), bits [3:0] = the XCD this workgroup runs on (MI355X_MICROARCH.md); 64 workgroups cover all 8
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;
+    if (threadIdx.x == 0) {
+        const unsigned long long c = __builtin_readcyclecounter();      // s_memtime: one tick per shader cycle
+        const unsigned long long r = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
+        out[2 * xcc] = c;                                               // (several workgroups of an XCD write near-equal pairs;
+        out[2 * xcc + 1] = r;                                           //  a torn pair would need two writers 2^32 ticks apart)
+    }
+}
+}  // namespace
+
+extern "C" int ac_clock_stamp(unsigned long long* d_out16, ac_stream_t stream_) {
+    AC_REQUIRE(d_out16 != nullptr, AC_EINVAL, "clock_stamp: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    AC_HIP_CHECK(hipMemsetAsync(d_out16, 0, 16 * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(64), dim3(64), 0, stream, d_out16);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}

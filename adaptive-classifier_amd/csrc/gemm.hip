@@ -858,6 +858,7 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
 namespace ac {
 static std::atomic<int> g_gemm_arith{-1};
 int gemm_arith() {
+    if (const int o = call_opts().arith; o >= 0) return o;          // the running call's own option (ac_bert_config.gemm_arith_opt)
     int v = g_gemm_arith.load(std::memory_order_relaxed);
     if (v < 0) {
         v = AC_GEMM_BF16X3;

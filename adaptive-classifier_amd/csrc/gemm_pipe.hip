@@ -587,6 +587,7 @@ constexpr int kLnCfg = 124262, kLnBM = 128, kLnBN = 128;     // the one tile the
 static std::atomic<int> g_ln_fusion{-1};
 static std::atomic<long long> g_ln_launches{0};
 bool ln_fusion_enabled() {
+    if (const int o = call_opts().ln_fusion; o >= 0) return o != 0;  // the running call's own option (ac_bert_config.ln_fusion_opt)
     int v = g_ln_fusion.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("AC_LN_FUSION");
@@ -619,7 +620,7 @@ int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, 
     e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;
     p.epi = e;
     p.ln.gamma = gamma; p.ln.beta = beta; p.ln.eps = eps; p.ln.part = (float2*)part; p.ln.count = count; p.ln.abort_ = abort_flag;
-    p.ln.planes = planes; p.ln.starve = g_ln_fusion.load(std::memory_order_relaxed) == 2 ? 1 : 0;
+    p.ln.planes = planes; p.ln.starve = (call_opts().ln_fusion >= 0 ? call_opts().ln_fusion : g_ln_fusion.load(std::memory_order_relaxed)) == 2 ? 1 : 0;
     p.stamps = nullptr;
     g_ln_launches.fetch_add(1, std::memory_order_relaxed);
     return f16 ? launch_cfg_f16<1, 2, 4, 2, 6, 2>(EPI_BIAS_RES_LN, false, p, stream)

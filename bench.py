@@ -477,7 +477,7 @@ def measure_cfg4(dev, args, steps=None, warmup=None, parity_queries=16):
     from adaptive_classifier import _native as nv
     if nv.lib().ac_gemm_get_arith() == 1:          # the opt-in fp16x2 arithmetic on the same batch (see main(): value_f16x2_opt_in)
         enc.enable_f16x2()
-        nv.check(nv.lib().ac_gemm_set_arith(2), "ac_gemm_set_arith")
+        clf._gemm_arith = nv.AC_GEMM_F16X2          # per-object option
         step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -485,8 +485,8 @@ def measure_cfg4(dev, args, steps=None, warmup=None, parity_queries=16):
             step()
         torch.cuda.synchronize()
         dt16 = (time.perf_counter() - t0) / max(2, steps // 2)
-        emb16 = clf.model.encode_cls(ids, types, mask)
-        nv.check(nv.lib().ac_gemm_set_arith(1), "ac_gemm_set_arith")
+        emb16 = clf.model.encode_cls(ids, types, mask, arith="f16x2")
+        clf._gemm_arith = None
         enc.disable_f16x2()
         f16 = {"value": B / dt16, "unit": "queries/s", "ms_per_step": dt16 * 1e3, "overflow_fallbacks": int(enc.f16x2_overflows),
                "max_abs_embedding_diff_vs_bf16x3": float((emb16 - emb).abs().max()), "note": "OPT-IN arithmetic, not `value`"}
@@ -973,9 +973,9 @@ def main():
     # the same loop with the fp32-input MFMA arithmetic for the large GEMMs (reported next to `value`)
     from adaptive_classifier import _native as nv
     arith = nv.lib().ac_gemm_get_arith()
-    nv.check(nv.lib().ac_gemm_set_arith(0), "ac_gemm_set_arith")
+    clf._gemm_arith = nv.AC_GEMM_F32              # per-object option (config["gemm_arith"]): no process-wide switch is touched
     dt32 = timed_predict(clf, ids, types, mask, args.steps, 2)
-    nv.check(nv.lib().ac_gemm_set_arith(arith), "ac_gemm_set_arith")
+    clf._gemm_arith = None
     # ... and with the OPT-IN fp16x2 arithmetic (include/acamd.h AC_GEMM_F16X2: operands rounded to two fp16 terms = 22 bits,
     # three fp16 MFMA products; NOT the arithmetic of `value`): the same loop, its embeddings measured against the bf16x3 ones
     # of the same batch and against transformers fp32, the predicted labels against the headline's
@@ -985,19 +985,19 @@ def main():
             emb3 = clf.model.encode_cls(ids, types, mask).clone()
             res3 = predict_step(clf, ids, types, mask)
             clf.model.enable_f16x2()
-            nv.check(nv.lib().ac_gemm_set_arith(2), "ac_gemm_set_arith")
+            clf._gemm_arith = nv.AC_GEMM_F16X2
             dt16 = timed_predict(clf, ids, types, mask, args.steps, 2)
-            active = bool(clf.model.f16x2_active())
-            emb16 = clf.model.encode_cls(ids, types, mask).clone()
+            active = bool(clf.model.f16x2_active("f16x2"))
+            emb16 = clf.model.encode_cls(ids, types, mask, arith="f16x2").clone()
             res16 = predict_step(clf, ids, types, mask)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                clf.model.encode_cls(ids, types, mask, verify=False)
+                clf.model.encode_cls(ids, types, mask, verify=False, arith="f16x2")
             e1.record(); torch.cuda.synchronize()
             want = torch.nn.functional.normalize(
                 hf(input_ids=ids[:8].cpu(), token_type_ids=types[:8].cpu(), attention_mask=mask[:8].cpu()).last_hidden_state[:, 0, :], dim=1)
-            nv.check(nv.lib().ac_gemm_set_arith(arith), "ac_gemm_set_arith")
+            clf._gemm_arith = None
             clf.model.disable_f16x2()
         f16 = {"value": BATCH * args.steps / dt16, "unit": "queries/s", "ms_per_step": dt16 / args.steps * 1e3,
                "encode_ms": e0.elapsed_time(e1) / 5, "ran_fp16x2": active, "overflow_fallbacks": int(clf.model.f16x2_overflows),

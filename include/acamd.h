@@ -273,6 +273,12 @@ int64_t ac_gemm_ln_fusion_launches(void);      /* fused launches of this process
  * Initial value 3, or env AC_HEAD_PERSISTENT / AC_BERT_SMALL = 0 to clear a bit. */
 int ac_set_persistent_kernels(int mask);
 
+/* Measurement aid (bench.py `value_sustained`): one stamp per XCD of (shader clock counter s_memtime, 100 MHz real-time counter
+ * s_memrealtime) into d_out16[2 * xcd + {0, 1}] (16 x uint64, zeroed first; an XCD no workgroup landed on stays 0).  Two stamps
+ * on one stream bracket a region: its average shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz -- what the DVFS of
+ * MI355X_MICROARCH.md ("give-back") left of the nominal 2.4 GHz while the region ran.  Nothing of the hot path calls it. */
+int ac_clock_stamp(unsigned long long* d_out16, ac_stream_t stream);
+
 /* Diagnostic: resident workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor) of the LDS-tiled
  * GEMM kernels.  kernel: 0 = fp32-MFMA tile, 1 = bf16x3 split-in-kernel, 2 = bf16x3 planes; tm: 1 = 64-row,
  * 2 = 128-row tile. */
@@ -458,6 +464,15 @@ typedef struct {
     int max_pos;
     int type_vocab;
     float ln_eps;      /* 1e-12 */
+    /* Per-call options: 0 = the process-wide default (ac_gemm_set_arith / ac_gemm_set_ln_fusion / ac_set_persistent_kernels
+     * and their environment variables), otherwise the value + 1.  They hold for the calls this config is passed to and for
+     * nothing else -- two encoders (or two classifiers on one encoder) with different options interleave freely in one
+     * process (tests/test_encoder_gpu.py::test_per_call_options_do_not_leak_between_objects); the process-wide setters remain
+     * as test / A-B hooks.  A zero-initialised struct means "defaults". */
+    int gemm_arith_opt;   /* 1 + AC_GEMM_F32 | 1 + AC_GEMM_BF16X3 | 1 + AC_GEMM_F16X2 (fp16x2 additionally needs the *_wh planes) */
+    int ln_fusion_opt;    /* 1 = LayerNorms as separate launches, 2 = fused into the GEMM epilogues where the launch allows it
+                           * (3 = fused with a starved exchange: tests of the give-up path only) */
+    int one_launch_opt;   /* 1 = never the one persistent launch for <= 32 token rows (like AC_BERT_LAYERED), 2 = allowed */
 } ac_bert_config;
 
 /* Device pointers to the weights, nn.Linear [out,in] layout, fp32.

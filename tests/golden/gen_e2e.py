@@ -1,0 +1,126 @@
+"""Generate tests/golden/e2e_bert_mini/: the END-TO-END differential fixture (VERDICT r04 "Next round" item 2).
+
+    python tests/golden/gen_e2e.py          # in the build container (/root/reference present); CPU only
+
+Runs the UNMODIFIED reference (/root/reference/src/adaptive_classifier) FROM TEXT, encoder and tokenizer in the loop:
+`AdaptiveClassifier(name)` (classifier.py:28-114) -> `add_examples` twice (:132-200; the second call adds a class, i.e. goes
+through `_train_new_classes` :202-367) -> `save` (:524-628) -> `predict(text, k)` (:392-480) and `predict_batch(texts, k)`
+(:1308-1388) for 48 texts.  Nothing is patched except the two things that cannot exist offline:
+  * the Hub: oracle/hub_standin.py returns a seeded random-init BertModel ("standin/bert-mini-4l": 4 layers, H = 128, 2 heads)
+    and a real transformers BertTokenizer over a synthetic WordPiece vocabulary;
+  * faiss: oracle/faiss_shim.py (exact L2; the stored index has one row per class, so no near-tie question arises here).
+
+Written: the directory the reference's own save() wrote (config.json, examples.json, model.safetensors -- README.md removed)
+and expected.json = {texts, the reference's unit-norm CLS embeddings of every text (`_get_embeddings`, :1249-1282), predict
+k = 2 / 5, predict_batch k = 1 / 3, the training texts / labels of both add_examples calls, the prototypes after them}.
+tests/test_e2e_reference_gpu.py builds the PRODUCT on the same name (same stand-in -> bit-identical weights and vocabulary) and
+must reproduce label order exactly and every score to 1e-4 (the bar of the reference's tests/test_classifier.py:151-167 is
+1e-5 between its own CPU and GPU runs).  Texts whose reference scores hold a near-tie (gap < 2e-4 between neighbours in the
+returned order) are dropped here -- an order flip there would be rounding, not a defect -- and counted in expected.json.
+"""
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import faiss_shim, hub_standin  # noqa: E402
+
+faiss_shim.install()
+hub_standin.install()
+sys.path.insert(0, "/root/reference/src")
+import adaptive_classifier as ref  # noqa: E402
+
+assert ref.__file__.startswith("/root/reference"), ref.__file__
+
+NAME = "standin/bert-mini-4l"
+
+TRAIN_1 = [
+    ("this product is amazing and works great", "positive"), ("i love it so much best purchase", "positive"),
+    ("excellent quality very happy with the service", "positive"), ("fantastic experience would recommend", "positive"),
+    ("wonderful support team really nice people", "positive"), ("great price and fast delivery", "positive"),
+    ("i am delighted and impressed", "positive"), ("the best order i made this year", "positive"),
+    ("very pleased works fine every time", "positive"), ("good deal happy customer", "positive"),
+    ("love the new update it is great", "positive"), ("amazing game love the music", "positive"),
+    ("terrible experience the product is broken", "negative"), ("i hate it worst purchase ever", "negative"),
+    ("awful service and late delivery", "negative"), ("horrible quality do not buy", "negative"),
+    ("very disappointing and expensive", "negative"), ("the app crash every time i open it", "negative"),
+    ("poor support nobody answer my email", "negative"), ("refund my money this is bad", "negative"),
+    ("it is okay nothing special", "neutral"), ("average product does the job", "neutral"),
+    ("just fine not good not bad", "neutral"), ("mediocre but decent for the price", "neutral"),
+]
+TRAIN_2 = [
+    ("null pointer exception in the login function", "technical"), ("the server crash when i upload a file", "technical"),
+    ("database error after the software update", "technical"), ("python code bug in the loop variable", "technical"),
+    ("how do i reset my password", "technical"), ("memory error on the network server", "technical"),
+    ("this is still a great product", "positive"), ("still bad and still broken", "negative"),
+]
+QUERIES = [
+    "this is fantastic", "this is terrible", "just okay i think", "system crash occurred", "i love this product",
+    "worst service ever", "the delivery was late and the product was broken", "nothing special but fine",
+    "error in the python code", "how do i cancel my subscription", "great price", "bad", "good", "Null Pointer Exception!",
+    "The BEST purchase I have made.", "refund please, this is awful...", "password reset does not work",
+    "the music in this movie is wonderful", "stock market news today", "my doctor recommend this medicine",
+    "quality is poor and the price is high", "very happy with the support team", "cannot login to my account",
+    "is it worth the money?", "average", "the game is okay", "server is slow today", "i am not satisfied at all",
+    "delighted with the fast shipping", "why is the app so slow", "an unremarkable zxqv experience", "42",
+    "it works", "it does not work", "love hate love hate", "customer service never answer the phone",
+    "the update broke the search button", "decent product for a cheap price", "what a waste of time and money",
+    "best team best coach best season", "café naïve résumé is good", "upload download upload download error",
+    "please help me", "thank you this was very useful and kind of you", "no", "yes", "neutral opinion really",
+    "technical question about the database", "x", "the the the the the the the the the the the the the the the the",
+]
+
+
+def near_tie(pred, gap=2e-4):
+    s = [v for _, v in pred]
+    return any(abs(a - b) < gap for a, b in zip(s, s[1:]))
+
+
+def main():
+    out_dir = os.path.join(HERE, "e2e_bert_mini")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    clf = ref.AdaptiveClassifier(NAME, device="cpu", use_onnx=False)
+    assert type(clf.tokenizer).__name__ == "BertTokenizer" and clf.model.config.num_hidden_layers == 4
+    clf.add_examples([t for t, _ in TRAIN_1], [l for _, l in TRAIN_1])
+    clf.add_examples([t for t, _ in TRAIN_2], [l for _, l in TRAIN_2])          # new class -> _train_new_classes
+    clf._save_pretrained(out_dir, include_onnx=False)
+    os.remove(os.path.join(out_dir, "README.md"))
+    # the reference as a user would get it back: load() -> _from_pretrained (prototypes + head + training_history restored)
+    loaded = ref.AdaptiveClassifier.load(out_dir, device="cpu", use_onnx=False)
+    emb = torch.stack(loaded._get_embeddings(QUERIES)).numpy()
+    exp_all = {
+        "predict_k2": [loaded.predict(t, k=2) for t in QUERIES],
+        "predict_k5": [loaded.predict(t, k=5) for t in QUERIES],
+        "predict_batch_k1": loaded.predict_batch(QUERIES, k=1),
+        "predict_batch_k3": loaded.predict_batch(QUERIES, k=3, batch_size=16),
+    }
+    # the live (not reloaded) classifier must agree with the reloaded one: same prototypes, same head, same history
+    live = [clf.predict(t, k=5) for t in QUERIES[:8]]
+    for a, b in zip(live, exp_all["predict_k5"][:8]):
+        assert [l for l, _ in a] == [l for l, _ in b] and np.allclose([s for _, s in a], [s for _, s in b], atol=1e-6)
+    keep = [i for i in range(len(QUERIES)) if not any(near_tie(exp_all[k][i]) for k in exp_all)]
+    assert len(keep) >= 32, len(keep)
+    exp = {"model_name": NAME, "texts": [QUERIES[i] for i in keep], "dropped_near_ties": len(QUERIES) - len(keep),
+           "embeddings": emb[keep].astype(np.float64).round(9).tolist(),
+           "train_1": TRAIN_1, "train_2": TRAIN_2,
+           "label_to_id": clf.label_to_id, "training_history": clf.training_history,
+           "prototypes": {l: p.double().numpy().round(9).tolist() for l, p in clf.memory.prototypes.items()}}
+    for k, v in exp_all.items():
+        exp[k] = [v[i] for i in keep]
+    json.dump(exp, open(os.path.join(out_dir, "expected.json"), "w"))
+    print("kept", len(keep), "of", len(QUERIES), "texts; labels", clf.label_to_id, "history", clf.training_history)
+    for f in sorted(os.listdir(out_dir)):
+        print(f"  {f:24s} {os.path.getsize(os.path.join(out_dir, f)):8d} B")
+    print("example:", QUERIES[keep[0]], "->", exp["predict_k5"][0])
+
+
+if __name__ == "__main__":
+    main()

@@ -511,7 +511,8 @@ def test_void_persistent_launches_are_repeated_launch_by_launch(cuda_dev, monkey
 def test_gave_up_layernorm_exchange_is_reported_loudly(clf, monkeypatch):
     """The fused-LayerNorm GEMM epilogues poison their rows with NaN when the tiles of a row panel do not all arrive (a
     device that cannot hold one workgroup per CU at once); predict paths must then raise, naming the cause, and switch the
-    fusion off for the process -- never hand out NaN scores silently.  Simulated: NaN embeddings + the encoder's verdict."""
+    fusion off for that encoder (a per-object option since round 5) -- never hand out NaN scores silently.  Simulated: NaN
+    embeddings + the encoder's verdict."""
     from adaptive_classifier import _native as nv
     emb = clf._embed_device(["great product", "awful thing"])
     monkeypatch.setattr(clf.model, "ln_fusion_aborted", lambda: True, raising=False)
@@ -522,8 +523,9 @@ def test_gave_up_layernorm_exchange_is_reported_loudly(clf, monkeypatch):
         # the switch is off now: an encoder call at a fusable shape launches no fused GEMM
         clf.model.encode_cls(torch.randint(1000, 2000, (24, 16)), None, torch.ones(24, 16, dtype=torch.int64))
         assert nv.lib().ac_gemm_ln_fusion_launches() == before
+        assert clf.model.ln_fusion is False                  # ... for THIS encoder; no process-wide switch was touched
     finally:
-        nv.check(nv.lib().ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
+        clf.model.ln_fusion = None
 
 
 def _long_texts(n, words=14):
@@ -560,8 +562,10 @@ def test_starved_layernorm_exchange_never_reaches_memory_or_caller(cuda_dev, cap
             assert torch.isfinite(p).all() and torch.allclose(p, want_clf.memory.prototypes[l], atol=1e-5)
         assert all(torch.isfinite(e.embedding).all() for exs in got_clf.memory.examples.values() for e in exs)
         # predict paths: verify=False inside, NaN scores noticed at the result copy, batch repeated, no exception
+        assert enc.ln_fusion is False                      # the encoder switched ITS fusion off (per object) ...
         for call in (lambda: got_clf.predict_batch(texts, k=3, batch_size=24),
                      lambda: got_clf.predict_tokens(**HashTokenizer()(texts), k=3)):
+            enc.ln_fusion = None                           # ... re-armed here: back to the (starved) process-wide test hook
             nv.check(lib.ac_gemm_set_ln_fusion(2), "ac_gemm_set_ln_fusion")
             caplog.clear()
             with caplog.at_level(logging.WARNING):

@@ -1,0 +1,122 @@
+"""GPU suite: END-TO-END differential against the reference's own classifier.py, FROM TEXT.
+
+tests/golden/e2e_bert_mini/ was written by tests/golden/gen_e2e.py running the UNMODIFIED reference on CPU -- tokenizer,
+encoder, memory, head and blend all in the loop: `AdaptiveClassifier(name)`, two `add_examples` calls (the second adds a class),
+`save`, then `predict` (/root/reference/src/adaptive_classifier/classifier.py:392-480) and `predict_batch` (:1308-1388).
+Here the PRODUCT is built on the same checkpoint name through the same offline Hub stand-in (oracle/hub_standin.py: seeded
+random-init 4-layer BERT, synthetic WordPiece vocabulary -> bit-identical weights and ids on both sides) and must return the
+same labels in the same order with every score within 1e-4 (the reference's own CPU-vs-GPU bar is 1e-5,
+tests/test_classifier.py:151-167; the 1e-4 is SURVEY 8c's fp32 tolerance).  The product's chain is the shipping one: device
+WordPiece (ac_wordpiece_encode) -> padding-free encoder -> device kNN / scores -> head -> ac_blend_topk.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden", "e2e_bert_mini")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def standin():
+    from oracle import hub_standin
+    hub_standin.install()
+    yield hub_standin
+    hub_standin.uninstall()
+
+
+@pytest.fixture(scope="module")
+def exp():
+    return json.load(open(os.path.join(G, "expected.json")))
+
+
+def _same(got, want, what):
+    assert [l for l, _ in got] == [l for l, _ in want], (what, got, want)
+    assert all(isinstance(s, float) for _, s in got)
+    d = max(abs(a - b) for (_, a), (_, b) in zip(got, want)) if want else 0.0
+    assert d <= TOL, (what, d, got, want)
+    return d
+
+
+def test_hub_standin_is_in_the_loop(standin, cuda_dev, exp):
+    """The product builds its encoder and tokenizer from the NAME, exactly as the reference does (classifier.py:83-85)."""
+    from adaptive_classifier import AdaptiveClassifier
+    from adaptive_classifier.tokenizer import HipWordPieceTokenizer
+    clf = AdaptiveClassifier(exp["model_name"], device="cuda:0")
+    assert type(clf.model).__name__ == "HipBertEncoder" and clf.embedding_dim == 128
+    assert isinstance(clf.tokenizer, HipWordPieceTokenizer)            # the device tokenizer took the BERT vocabulary
+    ref_tok = standin.make_tokenizer(exp["model_name"])
+    texts = exp["texts"]
+    want = ref_tok(texts, max_length=512, truncation=True, padding=True, return_tensors="pt")
+    got = clf.tokenizer(texts, max_length=512, truncation=True, padding=True, return_tensors="pt")
+    assert torch.equal(got["input_ids"].cpu(), want["input_ids"]) and torch.equal(got["attention_mask"].cpu(), want["attention_mask"])
+    assert clf.tokenizer.host_texts >= 1 and clf.tokenizer.device_texts >= len(texts) - 2     # (the accented text goes to the host)
+
+
+def test_embeddings_from_text_equal_the_references(standin, cuda_dev, exp):
+    """_get_embeddings (classifier.py:1249-1282): tokenizer + encoder + CLS + normalise, list of CPU tensors."""
+    from adaptive_classifier import AdaptiveClassifier
+    clf = AdaptiveClassifier(exp["model_name"], device="cuda:0")
+    want = np.asarray(exp["embeddings"])
+    got = clf._get_embeddings(exp["texts"])
+    assert isinstance(got, list) and all(e.device.type == "cpu" and e.shape == (128,) for e in got)
+    d = np.abs(torch.stack(got).double().numpy() - want).max()
+    assert d <= 1e-5, d
+    one = np.stack([clf._get_embeddings([t])[0].double().numpy() for t in exp["texts"][:6]])      # the one-launch path (<= 32 rows)
+    assert np.abs(one - want[:6]).max() <= 1e-5
+
+
+def test_load_then_predict_and_predict_batch_equal_the_reference(standin, cuda_dev, exp):
+    """The directory the reference wrote -> AdaptiveClassifier.load -> predict / predict_batch from text."""
+    from adaptive_classifier import AdaptiveClassifier
+    clf = AdaptiveClassifier.load(G, device="cuda:0")
+    assert clf.label_to_id == exp["label_to_id"] and clf.training_history == exp["training_history"]
+    texts = exp["texts"]
+    assert len(texts) >= 32
+    worst = 0.0
+    for i, t in enumerate(texts):
+        worst = max(worst, _same(clf.predict(t, k=2), [tuple(p) for p in exp["predict_k2"][i]], ("predict k=2", t)))
+        worst = max(worst, _same(clf.predict(t, k=5), [tuple(p) for p in exp["predict_k5"][i]], ("predict k=5", t)))
+    for key, k, kw in (("predict_batch_k1", 1, {}), ("predict_batch_k3", 3, {"batch_size": 16})):
+        got = clf.predict_batch(texts, k=k, **kw)
+        assert len(got) == len(texts)
+        for i, t in enumerate(texts):
+            worst = max(worst, _same(got[i], [tuple(p) for p in exp[key][i]], (key, t)))
+    print("e2e from text: %d texts, 4 entry points, max |dscore| = %.2e" % (len(texts), worst))
+    # and with the reference's chunking (min_device_batch = 1 -> batches of `batch_size` texts, classifier.py:1320-1322)
+    clf.config.config["min_device_batch"] = 1
+    got = clf.predict_batch(texts, k=3, batch_size=16)
+    for i, t in enumerate(texts):
+        _same(got[i], [tuple(p) for p in exp["predict_batch_k3"][i]], ("predict_batch k=3, 16-text chunks", t))
+
+
+def test_add_examples_from_text_builds_the_references_memory(standin, cuda_dev, exp):
+    """add_examples (classifier.py:132-200) from the same texts: same label ids, same training history, same prototypes
+    (means of the encoder's embeddings, memory.py:138-159); then, with the REFERENCE's trained head loaded into the product's
+    classifier (head training draws dropout masks from a different generator), the same predictions from text."""
+    from safetensors.torch import load_file
+    from adaptive_classifier import AdaptiveClassifier
+    clf = AdaptiveClassifier(exp["model_name"], device="cuda:0")
+    for part in ("train_1", "train_2"):
+        clf.add_examples([t for t, _ in exp[part]], [l for _, l in exp[part]])
+    assert clf.label_to_id == exp["label_to_id"] and clf.training_history == exp["training_history"]
+    assert clf.adaptive_head.model[-1].out_features == 4
+    for label, want in exp["prototypes"].items():
+        d = np.abs(clf.memory.prototypes[label].double().cpu().numpy() - np.asarray(want)).max()
+        assert d <= 1e-5, (label, d)
+    # the product's own head (trained here) must already classify its training texts sensibly: scores sum to 1, all finite
+    for t, _ in exp["train_2"][:3]:
+        p = clf.predict(t, k=4)
+        assert abs(sum(s for _, s in p) - 1.0) < 1e-6 and len(p) == 4
+    tensors = load_file(os.path.join(G, "model.safetensors"))
+    clf.adaptive_head.load_state_dict({k[len("adaptive_head_"):]: v for k, v in tensors.items() if k.startswith("adaptive_head_")})
+    clf.adaptive_head = clf.adaptive_head.to(clf.device)
+    for i, t in enumerate(exp["texts"]):
+        _same(clf.predict(t, k=5), [tuple(p) for p in exp["predict_k5"][i]], ("predict after add_examples", t))
+    got = clf.predict_batch(exp["texts"], k=3)
+    for i, t in enumerate(exp["texts"]):
+        _same(got[i], [tuple(p) for p in exp["predict_batch_k3"][i]], ("predict_batch after add_examples", t))

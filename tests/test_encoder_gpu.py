@@ -342,11 +342,19 @@ def test_starved_layernorm_exchange_gives_up_loudly(cuda_dev):
         assert enc.ln_gave_up == n_gave_up + 1 and lib.ac_gemm_ln_fusion_launches() > n_fused
         assert torch.isfinite(healed).all() and (healed - want).abs().max().item() < 1e-4
         n_fused = lib.ac_gemm_ln_fusion_launches()
-        enc.encode_cls(ids, types, mask)                         # the fusion is off for the process now
-        assert lib.ac_gemm_ln_fusion_launches() == n_fused and enc.ln_gave_up == n_gave_up + 1
+        enc.encode_cls(ids, types, mask)                         # the fusion is off for THIS encoder now (per-object option)
+        assert lib.ac_gemm_ln_fusion_launches() == n_fused and enc.ln_gave_up == n_gave_up + 1 and enc.ln_fusion is False
     finally:
         nv.check(lib.ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
     assert (enc.encode_cls(ids, types, mask).cpu() - want).abs().max().item() < 1e-4
+    # ... and for nobody else: a second encoder in the same process still fuses (round 4 switched the whole process off)
+    other = HipBertEncoder(model, device=cuda_dev)
+    n_fused = lib.ac_gemm_ln_fusion_launches()
+    assert (other.encode_cls(ids, types, mask).cpu() - want).abs().max().item() < 1e-4
+    assert lib.ac_gemm_ln_fusion_launches() == n_fused + 4 and other.ln_fusion is None
+    n_fused = lib.ac_gemm_ln_fusion_launches()
+    enc.encode_cls(ids, types, mask)
+    assert lib.ac_gemm_ln_fusion_launches() == n_fused
 
 
 @pytest.mark.parametrize("model_type,hidden,layers,heads,inter,b,S,ragged", [
@@ -420,3 +428,65 @@ def test_layernorm_verdict_is_sticky_over_the_chunks_of_a_call(cuda_dev, monkeyp
         assert torch.isfinite(healed).all() and (healed - want).abs().max().item() < 1e-4
     finally:
         nv.check(lib.ac_gemm_set_ln_fusion(1), "ac_gemm_set_ln_fusion")
+
+
+def test_per_call_options_do_not_leak_between_objects(cuda_dev):
+    """VERDICT r04 item 6 / SURVEY 8b "no global mutable state": arithmetic and LayerNorm fusion are PER-CALL options inside
+    ac_bert_config.  Three classifiers of three arithmetics on ONE shared encoder plus an encoder with its own option, alive in
+    one process, calls interleaved: each returns, bit for bit, what a process running only that arithmetic returns (the
+    process-wide hook ac_gemm_set_arith is used here only to produce those single-arithmetic references), and the process-wide
+    value is never touched by any of them."""
+    from adaptive_classifier import AdaptiveClassifier, _native as nv
+    from adaptive_classifier.encoder import HipBertEncoder
+    from helpers import HashTokenizer
+    from oracle import bert_oracle
+    lib = nv.lib()
+    model = bert_oracle.make_bert(128, 3, 2, 512, vocab=2000, seed=11)
+    ids, types, mask = bert_oracle.synthetic_batch(24, 16, vocab=2000, seed=12, ragged=False)    # 384 rows: ring kernels, planes, fp16x2 applies
+    enc = HipBertEncoder(model, device=cuda_dev)
+    enc.enable_f16x2()                                     # planes present; USED only by calls whose arithmetic says so
+    before = lib.ac_gemm_get_arith()
+    assert before == nv.AC_GEMM_BF16X3
+    ref = {}
+    try:                                                   # single-arithmetic references through the process-wide hook
+        for name, mode in (("f32", 0), ("bf16x3", 1), ("f16x2", 2)):
+            nv.check(lib.ac_gemm_set_arith(mode), "ac_gemm_set_arith")
+            ref[name] = enc.encode_cls(ids, types, mask).clone()
+    finally:
+        nv.check(lib.ac_gemm_set_arith(before), "ac_gemm_set_arith")
+    assert not torch.equal(ref["f32"], ref["bf16x3"]) and not torch.equal(ref["bf16x3"], ref["f16x2"])   # three arithmetics indeed
+    # per-call option on the shared encoder, interleaved
+    for _ in range(2):
+        for name in ("f16x2", "f32", "bf16x3", "f32", "f16x2"):
+            assert torch.equal(enc.encode_cls(ids, types, mask, arith=name), ref[name]), name
+            assert lib.ac_gemm_get_arith() == before
+    assert torch.equal(enc.encode_cls(ids, types, mask), ref["bf16x3"])           # no option: the process default
+    # classifiers: config["gemm_arith"] is per object, even on a shared encoder
+    clfs = {name: AdaptiveClassifier("synthetic", device="cuda:0", config={"gemm_arith": name}, encoder=enc, tokenizer=HashTokenizer())
+            for name in ("f32", "bf16x3", "f16x2")}
+    plain = AdaptiveClassifier("synthetic", device="cuda:0", encoder=enc, tokenizer=HashTokenizer())
+    for _ in range(2):
+        for name in ("f32", "f16x2", "bf16x3"):
+            assert torch.equal(clfs[name]._encode_tokens(ids, types, mask), ref[name]), name
+        assert torch.equal(plain._encode_tokens(ids, types, mask), ref["bf16x3"])
+    assert lib.ac_gemm_get_arith() == before
+    with pytest.raises(ValueError, match="gemm_arith"):
+        AdaptiveClassifier("synthetic", device="cuda:0", config={"gemm_arith": "fp8"}, encoder=enc, tokenizer=HashTokenizer())
+    # an encoder-level option, and the LayerNorm fusion per encoder
+    enc2 = HipBertEncoder(model, device=cuda_dev).set_arith("f32")
+    assert torch.equal(enc2.encode_cls(ids, types, mask), ref["f32"]) and torch.equal(enc.encode_cls(ids, types, mask), ref["bf16x3"])
+    n0 = lib.ac_gemm_ln_fusion_launches()
+    fused = enc.encode_cls(ids, types, mask)
+    n1 = lib.ac_gemm_ln_fusion_launches()
+    enc3 = HipBertEncoder(model, device=cuda_dev).disable_ln_fusion()
+    unfused = enc3.encode_cls(ids, types, mask)
+    assert n1 > n0 and lib.ac_gemm_ln_fusion_launches() == n1                      # enc fuses, enc3 does not, same process
+    assert (fused - unfused).abs().max().item() < 5e-6
+    enc.encode_cls(ids, types, mask)
+    assert lib.ac_gemm_ln_fusion_launches() == n1 + (n1 - n0)                      # ... and enc still does
+    # a C caller's zero-initialised option words mean "defaults"; out-of-range words are refused
+    import ctypes
+    bad = enc._call_cfg()
+    bad.gemm_arith_opt = 9
+    need = ctypes.c_size_t(0)
+    assert lib.ac_bert_workspace(ctypes.byref(bad), 4, 16, ctypes.byref(need)) != 0 and b"options" in lib.ac_last_error()
