@@ -426,7 +426,13 @@ class HipModernBertEncoder:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         H, L, A, I = cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.intermediate_size
         types = list(cfg.layer_types)
-        every = int(cfg.global_attn_every_n_layers)
+        # the period of the global layers: `global_attn_every_n_layers` where the config carries it (checkpoints' config.json do),
+        # else read off `layer_types` (a default-constructed transformers >= 5 ModernBertConfig only has the list)
+        every = getattr(cfg, "global_attn_every_n_layers", None)
+        if every is None:
+            glob = [l for l, t in enumerate(types) if t == "full_attention"]
+            every = (glob[1] - glob[0]) if len(glob) > 1 else max(L, 1)
+        every = int(every)
         if any((t == "full_attention") != (l % every == 0) for l, t in enumerate(types)):
             raise nv.NativeError("HipModernBertEncoder: layer_types must be global every global_attn_every_n_layers")
         self.config = _Cfg(H, getattr(cfg, "_name_or_path", ""))

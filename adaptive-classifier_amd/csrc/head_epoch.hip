@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
 
         // ================= P2: a2[:, own2] = drop(relu(a1 W2r^T + b2)) =================
         if (n2 > 0) {
-            const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(prm->a1g, (unsigned)(kMaxB * H1 * sizeof(float)));
+            const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(prm->a1g, (unsigned)(nb * H1 * sizeof(float)));      // rows past the batch were never written (workspace garbage, NaN x 0): bounded -> they read as zero
             float acc[4][R2];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kT) void head_epoch_kernel(const EpochParams prm_) 
             }
         } else {
             if (gw_active) {
-                const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(prm->a1g, (unsigned)(kMaxB * H1 * sizeof(float)));
+                const __amdgpu_buffer_rsrc_t ra1 = make_rsrc(prm->a1g, (unsigned)(nb * H1 * sizeof(float)));      // rows past the batch were never written (workspace garbage, NaN x 0): bounded -> they read as zero
 #pragma unroll 1
                 for (int h = 0; h < 2; ++h) {
                     float4 x[kMaxB / 2];
