@@ -383,13 +383,16 @@ class HipBertEncoder:
             per_tok = 2.0 * (4.0 * H * H + 2.0 * H * I)
             ssq = float(sum_len_sq if sum_len_sq is not None else tokens * tokens / max(b, 1))
             attn_layer = 4.0 * c.heads * ssq * (H // c.heads)
-            last = 2.0 * tokens * 3.0 * H * H + 2.0 * b * (H * H + 2.0 * H * I) + 4.0 * c.heads * tokens * (H // c.heads)
+            qkv_last = (2.0 * tokens * 2.0 * H * H + 2.0 * b * H * H) if tokens >= 4 * b else 2.0 * tokens * 3.0 * H * H
+            last = qkv_last + 2.0 * b * (H * H + 2.0 * H * I) + 4.0 * c.heads * tokens * (H // c.heads)
             return per_tok * tokens * (L - 1) + attn_layer * (L - 1) + last
         per_tok = 2.0 * (4.0 * H * H + 2.0 * H * I)
         attn_layer = 4.0 * b * c.heads * S * S * (H // c.heads)
         if not executed:
             return per_tok * T * L + attn_layer * L
-        last = 2.0 * T * 3.0 * H * H + 2.0 * b * (H * H + 2.0 * H * I) + attn_layer / S
+        # (last layer: K and V of every token, Q of the b CLS rows only when the batch has >= 4 token rows per sequence)
+        qkv_last = (2.0 * T * 2.0 * H * H + 2.0 * b * H * H) if T >= 4 * b else 2.0 * T * 3.0 * H * H
+        last = qkv_last + 2.0 * b * (H * H + 2.0 * H * I) + attn_layer / S
         return per_tok * T * (L - 1) + attn_layer * (L - 1) + last
 
 

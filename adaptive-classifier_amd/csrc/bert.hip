@@ -308,7 +308,9 @@ template <bool ROPE, int DHT = 64>
 __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, const int64_t* mask, int S_, int H,
                                                            float scale, float* ctx_cls, const float* rope_cos,
                                                            const float* rope_sin, int window,
-                                                           const int32_t* __restrict__ cu = nullptr) {
+                                                           const int32_t* __restrict__ cu = nullptr,
+                                                           const float* __restrict__ q_cls = nullptr) {
+    // q_cls: the b CLS queries as compact [b, H] rows (BERT's last layer projects Q for those rows only); else column block 0 of qkv
     static_assert(DHT == 64 || (DHT == 32 && !ROPE), "head dim 64, or 32 without RoPE");
     __shared__ float Ks[KT][DHT + 1];
     __shared__ __attribute__((aligned(16))) float Vs[KT][DHT];
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
     const int64_t row0 = cu ? (int64_t)cu[bi] : (int64_t)bi * S_;
     const int S = cu ? cu[bi + 1] - cu[bi] : S_;
     const float* base = qkv + row0 * ld + head * DHT;
-    if (lane < DHT) qs[lane] = base[lane] * scale;     // CLS token = row 0 of the sequence
+    if (lane < DHT) qs[lane] = (q_cls ? q_cls[(int64_t)bi * H + head * DHT + lane] : base[lane]) * scale;     // CLS token = row 0 of the sequence
     float m = -INFINITY, l = 0.f, o = 0.f;      // o: output dim `lane`
     const int Svis = (window >= 0 && window + 1 < S) ? window + 1 : S;     // keys the CLS query can see
     for (int k0 = 0; k0 < Svis; k0 += KT) {
@@ -600,10 +602,6 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         const uint16_t* ao_w3 = wplanes ? w->ao_w3[l] : nullptr;
         const uint16_t* ff1_w3 = wplanes ? w->ff1_w3[l] : nullptr;
         const uint16_t* ff2_w3 = wplanes ? w->ff2_w3[l] : nullptr;
-        rc = f16 ? ac::linear_f16x2(xp, w->qkv_wh[l], w->qkv_b[l], nullptr, 0, qkv, 3 * H, nullptr, T, 3 * H, H, 0, stream)
-                 : ac::linear_f32(x, H, w->qkv_w[l], H, w->qkv_b[l], nullptr, 0, qkv, 3 * H, T, 3 * H, H, 0, nullptr, 1.f,
-                                  stream, 0.f, 0, qkv_w3, pl ? xp : nullptr);
-        if (rc) return rc;
         const bool last = (l == c.layers - 1);
         // After the last layer's attention only the CLS row of each sequence is consumed, so the
         // output projection, both LayerNorms and the FFN run on b rows instead of b*S.
@@ -611,19 +609,39 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         const bool lp = pl && !last;                   // this layer's post-attention GEMMs run on planes
         const float* resid = x;                        // residual = layer input
         int64_t ldres = last ? (int64_t)S * H : H;     // CLS rows of x are S*H apart (padded layout)
+        // ... and BEFORE it only K and V of every token and the Q of the CLS rows (round 5): the last QKV projection becomes a
+        // [T, 2H] GEMM over the K | V rows of the fused weight (a third fewer flops of that GEMM) + a [b, H] one for Q
+        const bool q_cls_only = last && T >= 4 * b;    // (short sequences: the split saves nothing worth two launches)
+        if (last && cu) {                              // packed layout: the CLS rows sit at cu[s]; gather them
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, cu, b, H, ffn);
+            AC_LAUNCH_CHECK();
+            resid = ffn;                               // compact CLS rows, staged in ffn (free until FFN1 writes it)
+            ldres = H;
+        }
+        if (q_cls_only) {
+            const int64_t HH = (int64_t)H * H;
+            rc = f16 ? ac::linear_f16x2(xp, w->qkv_wh[l] + (int64_t)H * 8, w->qkv_b[l] + H, nullptr, 0, qkv + H, 3 * H, nullptr, T, 2 * H, H, 0,
+                                        stream, 3 * H)
+                     : ac::linear_f32(x, H, w->qkv_w[l] + HH, H, w->qkv_b[l] + H, nullptr, 0, qkv + H, 3 * H, T, 2 * H, H, 0, nullptr, 1.f,
+                                      stream, 0.f, 0, qkv_w3 ? qkv_w3 + (int64_t)H * 8 : nullptr, pl ? xp : nullptr, nullptr, 3 * H);
+            if (rc) return rc;
+            // Q of the CLS rows -> y (compact [b, H]; free until the output projection writes it)
+            rc = ac::linear_f32_splitk(resid, ldres, w->qkv_w[l], H, w->qkv_b[l], nullptr, 0, y, H, b, H, H, 0, qkv_w3, ctx,
+                                       (size_t)T * H * sizeof(float), stream, 3 * H);
+        } else {
+            rc = f16 ? ac::linear_f16x2(xp, w->qkv_wh[l], w->qkv_b[l], nullptr, 0, qkv, 3 * H, nullptr, T, 3 * H, H, 0, stream)
+                     : ac::linear_f32(x, H, w->qkv_w[l], H, w->qkv_b[l], nullptr, 0, qkv, 3 * H, T, 3 * H, H, 0, nullptr, 1.f,
+                                      stream, 0.f, 0, qkv_w3, pl ? xp : nullptr);
+        }
+        if (rc) return rc;
         if (last) {
+            const float* qc = q_cls_only ? y : nullptr;
             if (dh == 64)
                 hipLaunchKernelGGL((attention_cls_kernel<false, 64>), dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale,
-                                   ctx, nullptr, nullptr, -1, cu);
+                                   ctx, nullptr, nullptr, -1, cu, qc);
             else
                 hipLaunchKernelGGL((attention_cls_kernel<false, 32>), dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale,
-                                   ctx, nullptr, nullptr, -1, cu);
-            if (cu) {                                  // packed layout: the CLS rows sit at cu[s]; gather them
-                AC_LAUNCH_CHECK();
-                hipLaunchKernelGGL(gather_rows_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, cu, b, H, ffn);
-                resid = ffn;                           // compact CLS rows, staged in ffn (free until FFN1 writes it)
-                ldres = H;
-            }
+                                   ctx, nullptr, nullptr, -1, cu, qc);
         } else {
             if (dh == 64)
                 hipLaunchKernelGGL((attention_mfma_kernel<false, 64>), dim3((Smax + 31) / 32, c.heads, b), dim3(64), 0, stream, qkv,

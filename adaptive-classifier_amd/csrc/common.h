@@ -61,11 +61,13 @@ int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const f
                const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
                const uint8_t* mask, float mask_scale, hipStream_t stream, float drop_p = 0.f,
                uint64_t drop_seed = 0, const uint16_t* W_planes = nullptr, const uint16_t* A_planes = nullptr,
-               uint16_t* C_planes = nullptr);
+               uint16_t* C_planes = nullptr, int64_t w_plane_rows = 0);
+// w_plane_rows (here and below): rows of the [rows, K] matrix whose planes W_planes points INTO (0 = N): a GEMM over a block
+// of N consecutive output rows of a larger weight (the K | V rows of a fused QKV matrix) passes W_planes + 8 * first_row
 // split-K form of linear_f32 for GEMMs with few output tiles (W planes required, scratch = ksplit * M * N floats)
 int linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,
                       int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act, const uint16_t* W_planes, float* scratch,
-                      size_t scratch_bytes, hipStream_t stream);
+                      size_t scratch_bytes, hipStream_t stream, int64_t w_plane_rows = 0);
 // gemm_pipe.hip:
 // bias + residual + LayerNorm fused into the epilogue (one-round launches of the 128 x 128 tile only: see gemm_pipe.hip);
 // `count` = one zeroed word per 128-row panel, `part` = pipe_ln_part_bytes() of scratch, C may alias the residual
@@ -215,7 +217,7 @@ inline bool arith_split() { return gemm_arith() != AC_GEMM_F32; }   // bf16x3, o
 // C fp32 rows, or (Cp) the fp16x2 activation planes of the next GEMM.  act: 0 none, 2 gelu (planes output only).
 bool linear_f16x2_takes(int M, int N, int K);
 int linear_f16x2(const uint16_t* Ap, const uint16_t* Wp, const float* bias, const float* residual, int64_t ldr, float* C,
-                 int64_t ldc, uint16_t* Cp, int M, int N, int K, int act, hipStream_t stream);
+                 int64_t ldc, uint16_t* Cp, int M, int N, int K, int act, hipStream_t stream, int64_t w_plane_rows = 0);
 //   C = alpha * op(A) op(B) + beta * C; if gate != null: C = gate[m,n] != 0 ? C * gate_scale : 0
 int gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
              const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* gate,

@@ -887,12 +887,12 @@ bool linear_takes_planes(int M, int N, int K) {
 int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act,
                const uint8_t* mask, float mask_scale, hipStream_t stream, float drop_p, uint64_t drop_seed,
-               const uint16_t* Wp, const uint16_t* Ap, uint16_t* Cp) {
+               const uint16_t* Wp, const uint16_t* Ap, uint16_t* Cp, int64_t w_plane_rows) {
     Epilogue e;
     e.bias = bias; e.residual = residual; e.ldr = ldr; e.act = act; e.alpha = 1.f; e.beta = 0.f;
     e.mask = mask; e.mask_scale = mask_scale; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f;
     e.drop_p = mask ? 0.f : drop_p; e.drop_seed = drop_seed;
-    return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream, Wp, N, Ap, M, Cp);
+    return launch_gemm(true, true, A, lda, W, ldw, C, ldc, M, N, K, e, stream, Wp, w_plane_rows > 0 ? w_plane_rows : N, Ap, M, Cp);
 }
 // fp16x2 planes in, ring-staged kernels only (the BERT encoder under AC_GEMM_F16X2; ac_linear_f16x2)
 bool linear_f16x2_takes(int M, int N, int K) {
@@ -900,7 +900,7 @@ bool linear_f16x2_takes(int M, int N, int K) {
     return (v == 0 || v >= 1000) && M >= 192 && N >= 8 && (N % 8) == 0 && (K % 32) == 0 && K >= 64;
 }
 int linear_f16x2(const uint16_t* Ap, const uint16_t* Wp, const float* bias, const float* residual, int64_t ldr, float* C,
-                 int64_t ldc, uint16_t* Cp, int M, int N, int K, int act, hipStream_t stream) {
+                 int64_t ldc, uint16_t* Cp, int M, int N, int K, int act, hipStream_t stream, int64_t w_plane_rows) {
     AC_REQUIRE(Ap && Wp && bias && (C || Cp), AC_EINVAL, "linear_f16x2: null pointer");
     AC_REQUIRE(linear_f16x2_takes(M, N, K), AC_EUNSUPPORTED, "linear_f16x2: %d x %d x %d does not take the ring-staged kernel", M, N, K);
     AC_REQUIRE((act == ACT_NONE || (act == ACT_GELU && Cp)) && !(Cp && residual), AC_EUNSUPPORTED,
@@ -911,13 +911,13 @@ int linear_f16x2(const uint16_t* Ap, const uint16_t* Wp, const float* bias, cons
     const int cls = act == ACT_GELU ? EPI_BIAS_GELU : (residual ? EPI_BIAS_RES : EPI_BIAS);
     const int v = gemm_variant();
     const int cfg = v >= 1000 ? v : pipe_choose_f16(M, N, K);
-    return launch_gemm_pipe(cfg, Ap, M, Wp, N, C, ldc, Cp, M, N, K, cls, e, stream, 1);
+    return launch_gemm_pipe(cfg, Ap, M, Wp, w_plane_rows > 0 ? w_plane_rows : N, C, ldc, Cp, M, N, K, cls, e, stream, 1);
 }
 // linear_f32 for shapes with few output tiles: split-K over `scratch` (see gemm_planes_splitk_nt); falls back to
 // linear_f32 when the shape has enough tiles, the arithmetic is not bf16x3, or the scratch is too small.
 int linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,
                       int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act, const uint16_t* Wp, float* scratch,
-                      size_t scratch_bytes, hipStream_t stream) {
+                      size_t scratch_bytes, hipStream_t stream, int64_t w_plane_rows) {
     const int cus = dev_info().cus;
     const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + BN - 1) / BN);
     int ksplit = 1;
@@ -929,8 +929,9 @@ int linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, 
             if (nk % c == 0 && nk / c >= 6 && tiles * c <= (int64_t)cus * 3 / 2 && (size_t)c * M * N * sizeof(float) <= scratch_bytes) ksplit = c;
     }
     if (ksplit == 1)
-        return linear_f32(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, nullptr, 1.f, stream, 0.f, 0, Wp);
-    hipLaunchKernelGGL(gemm_planes_splitk_nt, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, stream, A, lda, Wp, (int64_t)N, scratch, M, N, K, ksplit);
+        return linear_f32(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, nullptr, 1.f, stream, 0.f, 0, Wp, nullptr, nullptr, w_plane_rows);
+    hipLaunchKernelGGL(gemm_planes_splitk_nt, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, stream, A, lda, Wp,
+                       w_plane_rows > 0 ? w_plane_rows : (int64_t)N, scratch, M, N, K, ksplit);
     AC_LAUNCH_CHECK();
     Epilogue e;
     e.bias = bias; e.residual = residual; e.ldr = ldr; e.act = act; e.alpha = 1.f; e.beta = 0.f;

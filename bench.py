@@ -1176,6 +1176,14 @@ def main():
 
     clf, hf = make_classifier(dev, rank, world)
     ids, types, mask = synthetic_tokens(dev, rank)
+    # Serving hygiene, not a kernel trick: a step returns 256 lists of 16 (label, score) tuples, i.e. ~4 k tracked objects, so
+    # CPython starts a FULL (generation-2) collection every ~16 steps -- and with transformers + two BERT models imported that
+    # walk over ~10^6 long-lived objects takes 30 - 40 ms, longer than six steps (seen as sporadic 37 k / 36 k queries/s lines
+    # among 48 k ones in round 5).  gc.freeze() moves everything allocated so far into the permanent generation (what serving
+    # stacks do after model load); the per-step garbage is still collected.
+    import gc
+    gc.collect()
+    gc.freeze()
     dt = timed_predict(clf, ids, types, mask, args.steps, args.warmup)
     stages = time_stages(clf, ids, types, mask)
 

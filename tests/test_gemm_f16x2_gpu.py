@@ -309,7 +309,7 @@ def test_predict_under_f16x2_agrees_with_bf16x3_and_recovers_from_overflow(cuda_
     ids, types, mask = bert_oracle.synthetic_batch(64, 32, vocab=2000, seed=5, ragged=True)
     a = build(model, "bf16x3").predict_tokens(ids, types, mask, k=3)
     clf = build(model, "f16x2")
-    assert clf.model.f16x2_active()
+    assert clf._f16x2_active() and not clf.model.f16x2_active()       # per OBJECT: the classifier's calls, not the encoder's default
     bres = clf.predict_tokens(ids, types, mask, k=3)
     assert [[l for l, _ in p] for p in a] == [[l for l, _ in p] for p in bres]
     assert max(abs(x[1] - y[1]) for p, q in zip(a, bres) for x, y in zip(p, q)) < 1e-5
@@ -317,5 +317,5 @@ def test_predict_under_f16x2_agrees_with_bf16x3_and_recovers_from_overflow(cuda_
         model.encoder.layer[0].output.LayerNorm.weight[5] = 400.0
     clf = build(model, "f16x2")
     res = clf.predict_tokens(ids, types, mask, k=3)
-    assert clf.model.f16x2_overflows == 1 and not clf.model.f16x2_active()
+    assert clf.model.f16x2_overflows == 1 and not clf._f16x2_active()
     assert all(s == s for p in res for _, s in p)
