@@ -558,7 +558,9 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
     // up to 4 query tiles share an XCD (their plane stays in its L2); at most 8 such sets per launch
     for (int t0 = 0; t0 < nqt_all; t0 += 32) {
         const int nqt = nqt_all - t0 < 32 ? nqt_all - t0 : 32;
+        static const int b_env = getenv("AC_KNN_BATCH_B") ? atoi(getenv("AC_KNN_BATCH_B")) : 0;      // A/B: query tiles per XCD
         int b = nqt >= 4 ? 4 : (nqt >= 2 ? 2 : 1);
+        if (b_env == 8 && nqt >= 8) b = 8;
         while (per_xcd % b) b >>= 1;
         int sets = 1;
         while (sets * b < nqt) sets <<= 1;
