@@ -471,6 +471,18 @@ def sustained_predict(step, batch, seconds=2.5, min_steps=50):
                     "(ac_clock_stamp), nominal 2400 MHz" % dt}
 
 
+def _guarded(what, fn, *a, **k):
+    """An EXTRA of the line (anything but `value` / `roofline`) must never cost the line itself: on an exception the key carries
+    the error text instead of a number."""
+    try:
+        return fn(*a, **k)
+    except Exception as e:                      # noqa: BLE001 -- reported, not swallowed
+        import traceback
+        print("bench.py: %s failed: %r" % (what, e), file=sys.stderr)
+        traceback.print_exc()
+        return {"error": "%s: %r" % (what, e)}
+
+
 def _max_over_ranks(x, dev):
     t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -597,7 +609,7 @@ def measure_cfg4(dev, args, steps=None, warmup=None, parity_queries=16):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert len(preds) == B
-    sus = sustained_predict(step, B, seconds=2.5, min_steps=20)
+    sus = _guarded("cfg4 value_sustained", sustained_predict, step, B, seconds=2.5, min_steps=20)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     ev[0].record(); emb = clf.model.encode_cls(ids, types, mask, verify=False); ev[1].record()
     S_, I_, D_ = clf.memory.search_batch(emb, K_); ev[2].record(); torch.cuda.synchronize()
@@ -1289,17 +1301,17 @@ def main():
     if not args.no_parity:
         line["parity"] = step_parity(clf, hf, ids, types, mask)
     # the same loop for >= 2.5 s (the headline's 20 steps are ~0.1 s at boost clock), with the observed shader clock
-    sus = sustained_predict(lambda: predict_step(clf, ids, types, mask), BATCH)
-    line["config"]["value_sustained"] = sus
+    line["config"]["value_sustained"] = _guarded("value_sustained", sustained_predict, lambda: predict_step(clf, ids, types, mask), BATCH)
     # (the 20-step number again AFTER the sustained run, i.e. on a warm chip: what a caller in steady state sees)
     if not args.no_cpu_baseline:
         port = cpu_baseline(hf, clf, clf.memory.index._store[:NPROTO])
-        ref = cpu_baseline_reference(ids, mask, clf.memory.index._store[:NPROTO])
-        if ref is not None:
+        ref = _guarded("cpu_baseline (reference)", cpu_baseline_reference, ids, mask, clf.memory.index._store[:NPROTO])
+        if ref is not None and "error" not in ref:
             line["cpu_baseline"] = ref
             line["cpu_baseline_port"] = port
         else:
-            port["note"] = "oracle/_ref is not staged on this box: the oracle port stands in for the reference run"
+            port["note"] = ("oracle/_ref is not staged on this box" if ref is None else ref["error"]) + \
+                           ": the oracle port stands in for the reference run"
             line["cpu_baseline"] = port
     if not args.no_extras:
         # the other BASELINE configs, measured by the same run (outside the timed region of `value`), reduced so the whole
@@ -1318,7 +1330,7 @@ def main():
         line["add_examples"] = {"value": ae["value"], "unit": ae["unit"], "examples": m["examples"], "train_steps": m["train_steps"],
                                 "steps_per_s": m["steps_per_s"], "host_seconds_by_phase": m["host_seconds_by_phase"],
                                 "accuracy_5way": m["accuracy_5way"], "config": ae["config"]}
-        line["add_examples_with_encoder"] = measure_add_examples_text(dev, args, n=6000)
+        line["add_examples_with_encoder"] = _guarded("add_examples_with_encoder", measure_add_examples_text, dev, args, n=6000)
     print(json.dumps(line), flush=True)
 
 
