@@ -54,6 +54,12 @@ ARCHITECTURES = {
     "standin/bert-small-2l-d64": ("bert", {"vocab_size": 3000, "hidden_size": 64, "num_hidden_layers": 2,
                                            "num_attention_heads": 1, "intermediate_size": 256,
                                            "max_position_embeddings": 128}, True),
+    "standin/distilbert-mini-3l": ("distilbert", {"vocab_size": 4000, "dim": 128, "n_layers": 3, "n_heads": 2, "hidden_dim": 512,
+                                                  "max_position_embeddings": 128}, True),
+    "standin/modernbert-mini-4l": ("modernbert", {"vocab_size": 4000, "hidden_size": 128, "num_hidden_layers": 4,
+                                                  "num_attention_heads": 2, "intermediate_size": 192,
+                                                  "max_position_embeddings": 256, "pad_token_id": 0, "bos_token_id": 101,
+                                                  "cls_token_id": 101, "eos_token_id": 102, "sep_token_id": 102}, True),
 }
 
 WORDS = """the of and to in is that for it as was with be by on not he this are or his from at which but have an had they you

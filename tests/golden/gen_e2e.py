@@ -1,6 +1,7 @@
-"""Generate tests/golden/e2e_bert_mini/: the END-TO-END differential fixture (VERDICT r04 "Next round" item 2).
+"""Generate tests/golden/e2e_*: the END-TO-END differential fixtures (VERDICT r04 "Next round" item 2).
 
-    python tests/golden/gen_e2e.py          # in the build container (/root/reference present); CPU only
+    python tests/golden/gen_e2e.py [case ...]     # in the build container (/root/reference present); CPU only
+                                                  # cases: bert_mini (default set: all four) distilbert_mini modernbert_mini multilabel_mini
 
 Runs the UNMODIFIED reference (/root/reference/src/adaptive_classifier) FROM TEXT, encoder and tokenizer in the loop:
 `AdaptiveClassifier(name)` (classifier.py:28-114) -> `add_examples` twice (:132-200; the second call adds a class, i.e. goes
@@ -9,6 +10,13 @@ through `_train_new_classes` :202-367) -> `save` (:524-628) -> `predict(text, k)
   * the Hub: oracle/hub_standin.py returns a seeded random-init BertModel ("standin/bert-mini-4l": 4 layers, H = 128, 2 heads)
     and a real transformers BertTokenizer over a synthetic WordPiece vocabulary;
   * faiss: oracle/faiss_shim.py (exact L2; the stored index has one row per class, so no near-tie question arises here).
+
+Further cases (same recipe, 24 texts each): `e2e_distilbert_mini` ("standin/distilbert-mini-3l": the reference's tests/test_ewc.py
+and test_multilabel.py name DistilBERT checkpoints), `e2e_modernbert_mini` ("standin/modernbert-mini-4l": its default encoder in
+tests/test_order_independence.py / test_confidence_consistency.py), and `e2e_multilabel_mini`: the reference's
+MultiLabelAdaptiveClassifier (multilabel.py:70-413) from text -- add_examples with label LISTS, then predict_multilabel (default,
+explicit threshold, max_labels) and predict; its load() is broken in the reference
+(TypeError: use_onnx), so the trained head travels as model.safetensors + the state in expected.json instead of through save/load.
 
 Written: the directory the reference's own save() wrote (config.json, examples.json, model.safetensors -- README.md removed)
 and expected.json = {texts, the reference's unit-norm CLS embeddings of every text (`_get_embeddings`, :1249-1282), predict
@@ -82,33 +90,39 @@ def near_tie(pred, gap=2e-4):
     return any(abs(a - b) < gap for a, b in zip(s, s[1:]))
 
 
-def main():
-    out_dir = os.path.join(HERE, "e2e_bert_mini")
+CASES = {"bert_mini": (NAME, len(QUERIES)), "distilbert_mini": ("standin/distilbert-mini-3l", 24),
+         "modernbert_mini": ("standin/modernbert-mini-4l", 24)}
+
+
+def gen_single_label(case):
+    name, nq = CASES[case]
+    queries = QUERIES[:nq]
+    out_dir = os.path.join(HERE, "e2e_" + case)
     shutil.rmtree(out_dir, ignore_errors=True)
     torch.manual_seed(0)
     np.random.seed(0)
-    clf = ref.AdaptiveClassifier(NAME, device="cpu", use_onnx=False)
-    assert type(clf.tokenizer).__name__ == "BertTokenizer" and clf.model.config.num_hidden_layers == 4
+    clf = ref.AdaptiveClassifier(name, device="cpu", use_onnx=False)
+    assert type(clf.tokenizer).__name__ == "BertTokenizer"
     clf.add_examples([t for t, _ in TRAIN_1], [l for _, l in TRAIN_1])
     clf.add_examples([t for t, _ in TRAIN_2], [l for _, l in TRAIN_2])          # new class -> _train_new_classes
     clf._save_pretrained(out_dir, include_onnx=False)
     os.remove(os.path.join(out_dir, "README.md"))
     # the reference as a user would get it back: load() -> _from_pretrained (prototypes + head + training_history restored)
     loaded = ref.AdaptiveClassifier.load(out_dir, device="cpu", use_onnx=False)
-    emb = torch.stack(loaded._get_embeddings(QUERIES)).numpy()
+    emb = torch.stack(loaded._get_embeddings(queries)).numpy()
     exp_all = {
-        "predict_k2": [loaded.predict(t, k=2) for t in QUERIES],
-        "predict_k5": [loaded.predict(t, k=5) for t in QUERIES],
-        "predict_batch_k1": loaded.predict_batch(QUERIES, k=1),
-        "predict_batch_k3": loaded.predict_batch(QUERIES, k=3, batch_size=16),
+        "predict_k2": [loaded.predict(t, k=2) for t in queries],
+        "predict_k5": [loaded.predict(t, k=5) for t in queries],
+        "predict_batch_k1": loaded.predict_batch(queries, k=1),
+        "predict_batch_k3": loaded.predict_batch(queries, k=3, batch_size=16),
     }
     # the live (not reloaded) classifier must agree with the reloaded one: same prototypes, same head, same history
-    live = [clf.predict(t, k=5) for t in QUERIES[:8]]
+    live = [clf.predict(t, k=5) for t in queries[:8]]
     for a, b in zip(live, exp_all["predict_k5"][:8]):
         assert [l for l, _ in a] == [l for l, _ in b] and np.allclose([s for _, s in a], [s for _, s in b], atol=1e-6)
-    keep = [i for i in range(len(QUERIES)) if not any(near_tie(exp_all[k][i]) for k in exp_all)]
-    assert len(keep) >= 32, len(keep)
-    exp = {"model_name": NAME, "texts": [QUERIES[i] for i in keep], "dropped_near_ties": len(QUERIES) - len(keep),
+    keep = [i for i in range(len(queries)) if not any(near_tie(exp_all[k][i]) for k in exp_all)]
+    assert len(keep) >= (32 if case == "bert_mini" else 16), len(keep)
+    exp = {"model_name": name, "texts": [queries[i] for i in keep], "dropped_near_ties": len(queries) - len(keep),
            "embeddings": emb[keep].astype(np.float64).round(9).tolist(),
            "train_1": TRAIN_1, "train_2": TRAIN_2,
            "label_to_id": clf.label_to_id, "training_history": clf.training_history,
@@ -116,11 +130,79 @@ def main():
     for k, v in exp_all.items():
         exp[k] = [v[i] for i in keep]
     json.dump(exp, open(os.path.join(out_dir, "expected.json"), "w"))
-    print("kept", len(keep), "of", len(QUERIES), "texts; labels", clf.label_to_id, "history", clf.training_history)
+    print(case, ": kept", len(keep), "of", len(queries), "texts; labels", clf.label_to_id, "history", clf.training_history)
     for f in sorted(os.listdir(out_dir)):
         print(f"  {f:24s} {os.path.getsize(os.path.join(out_dir, f)):8d} B")
-    print("example:", QUERIES[keep[0]], "->", exp["predict_k5"][0])
+    print("  example:", queries[keep[0]], "->", exp["predict_k5"][0])
+
+
+ML_TRAIN = [
+    ("the doctor recommend this medicine for the disease", ["health"]), ("new research on climate and energy", ["science", "environment"]),
+    ("the company profit and sales growth this year", ["business"]), ("scientists discovered a new planet in space", ["science"]),
+    ("hospital treatment study for the patient", ["health", "science"]), ("stock market news and the economy", ["business"]),
+    ("the government policy on climate", ["politics", "environment"]), ("election news and the court law", ["politics"]),
+    ("software company sells a new mobile app", ["business", "technology"]), ("python code for the database server", ["technology"]),
+    ("computer network and hardware research", ["technology", "science"]), ("energy market and the economy of the country", ["business", "environment"]),
+    ("the team win the match this season", ["sports"]), ("the coach and the player lose the game", ["sports"]),
+    ("health policy of the government for the hospital", ["health", "politics"]), ("river and mountain in a warm climate", ["environment"]),
+    ("medicine research study by scientists", ["health", "science"]), ("the player score in the match", ["sports"]),
+    ("law and policy for the technology company", ["politics", "technology", "business"]), ("space energy research", ["science"]),
+]
+
+
+def gen_multilabel():
+    from adaptive_classifier import MultiLabelAdaptiveClassifier
+    from safetensors.torch import save_file
+    out_dir = os.path.join(HERE, "e2e_multilabel_mini")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    queries = QUERIES[:24] + ["the doctor and the hospital", "climate research by scientists", "the team and the coach", "company sales and profit",
+                              "government election", "server database code", "energy and the river", "a study of the stock market"]
+    torch.manual_seed(0)
+    np.random.seed(0)
+    clf = MultiLabelAdaptiveClassifier(NAME, device="cpu", default_threshold=0.4, min_predictions=1, max_predictions=4)
+    clf.use_onnx = False
+    texts, labels = [t for t, _ in ML_TRAIN], [l for _, l in ML_TRAIN]
+    clf.add_examples(texts, labels)
+    clf.add_examples(texts[:6], labels[:6])             # (a second call: retrains on everything stored, thresholds recomputed)
+    emb = torch.stack(clf._get_embeddings(queries)).numpy()
+    exp_all = {
+        "multilabel_default": [clf.predict_multilabel(t) for t in queries],
+        "multilabel_thr_0.51": [clf.predict_multilabel(t, threshold=0.51) for t in queries],
+        "multilabel_thr_0.9_max2": [clf.predict_multilabel(t, threshold=0.9, max_labels=2) for t in queries],
+        "predict_k3": [clf.predict(t, k=3) for t in queries],
+    }
+    # (the inherited predict_batch is not part of this fixture: with a random-init encoder all embeddings are close, the prototype
+    #  scores of seven classes are flat to 1e-5 and its top-3 is decided by rounding; its blend on a sigmoid head is pinned with a
+    #  stub encoder in tests/golden/multilabel_predict.json)
+    def near_threshold(i):              # a probability within 2e-4 of the threshold it is compared with: a flip would be rounding
+        clf.adaptive_head.eval()
+        with torch.no_grad():
+            p = clf.adaptive_head(torch.from_numpy(emb[i:i + 1])).squeeze(0).tolist()
+        for c, v in enumerate(p):
+            lab = clf.id_to_label[c]
+            for thr in (clf.label_thresholds.get(lab, clf._get_adaptive_threshold(len(clf.label_to_id))), clf.label_thresholds.get(lab, 0.51),
+                        clf.label_thresholds.get(lab, 0.9)):
+                if abs(v - thr) < 2e-4:
+                    return True
+        return False
+    keep = [i for i in range(len(queries)) if not any(near_tie(exp_all[k][i]) for k in exp_all) and not near_threshold(i)]
+    assert len(keep) >= 20, len(keep)
+    save_file({f"adaptive_head_{k}": v.detach().contiguous() for k, v in clf.adaptive_head.state_dict().items()},
+              os.path.join(out_dir, "model.safetensors"))
+    exp = {"model_name": NAME, "texts": [queries[i] for i in keep], "dropped": len(queries) - len(keep),
+           "train": ML_TRAIN, "ctor": {"default_threshold": 0.4, "min_predictions": 1, "max_predictions": 4},
+           "label_to_id": clf.label_to_id, "training_history": clf.training_history, "label_thresholds": clf.label_thresholds,
+           "examples_per_class": {l: len(v) for l, v in clf.memory.examples.items()},
+           "prototypes": {l: p.double().numpy().round(9).tolist() for l, p in clf.memory.prototypes.items()}}
+    for k, v in exp_all.items():
+        exp[k] = [v[i] for i in keep]
+    json.dump(exp, open(os.path.join(out_dir, "expected.json"), "w"))
+    print("multilabel_mini : kept", len(keep), "of", len(queries), "; labels", clf.label_to_id, "thresholds", clf.label_thresholds)
+    print("  example:", queries[keep[-1]], "->", exp["multilabel_default"][-1], "| thr 0.51:", exp["multilabel_thr_0.51"][-1])
 
 
 if __name__ == "__main__":
-    main()
+    want = sys.argv[1:] or ["bert_mini", "distilbert_mini", "modernbert_mini", "multilabel_mini"]
+    for case in want:
+        gen_multilabel() if case == "multilabel_mini" else gen_single_label(case)

@@ -17,8 +17,11 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-G = os.path.join(os.path.dirname(__file__), "golden", "e2e_bert_mini")
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+G = os.path.join(GOLD, "e2e_bert_mini")
 TOL = 1e-4
+# further architectures through the same recipe (24 texts each): the encoders the reference's own tests name
+CASES = {"bert": "e2e_bert_mini", "distilbert": "e2e_distilbert_mini", "modernbert": "e2e_modernbert_mini"}
 
 
 @pytest.fixture(scope="module")
@@ -120,3 +123,65 @@ def test_add_examples_from_text_builds_the_references_memory(standin, cuda_dev, 
     got = clf.predict_batch(exp["texts"], k=3)
     for i, t in enumerate(exp["texts"]):
         _same(got[i], [tuple(p) for p in exp["predict_batch_k3"][i]], ("predict_batch after add_examples", t))
+
+
+@pytest.mark.parametrize("family", ["distilbert", "modernbert"])
+def test_other_encoder_families_from_text_equal_the_reference(standin, cuda_dev, family):
+    """The same differential for the two other encoder families the reference's tests use (DistilBERT: tests/test_ewc.py:94,
+    test_multilabel.py:35; ModernBERT: test_order_independence.py:10, test_confidence_consistency.py:14): directory written by the
+    reference -> load -> embeddings, predict, predict_batch from text; then the product's own add_examples -> the reference's
+    label ids, history and prototypes."""
+    from adaptive_classifier import AdaptiveClassifier
+    g = os.path.join(GOLD, CASES[family])
+    ex = json.load(open(os.path.join(g, "expected.json")))
+    clf = AdaptiveClassifier.load(g, device="cuda:0")
+    assert type(clf.model).__name__ == {"distilbert": "HipBertEncoder", "modernbert": "HipModernBertEncoder"}[family]
+    texts = ex["texts"]
+    assert len(texts) >= 16
+    d = np.abs(torch.stack(clf._get_embeddings(texts)).double().numpy() - np.asarray(ex["embeddings"])).max()
+    assert d <= 1e-5, d
+    for i, t in enumerate(texts):
+        _same(clf.predict(t, k=2), [tuple(p) for p in ex["predict_k2"][i]], ("predict k=2", family, t))
+        _same(clf.predict(t, k=5), [tuple(p) for p in ex["predict_k5"][i]], ("predict k=5", family, t))
+    for key, k, kw in (("predict_batch_k1", 1, {}), ("predict_batch_k3", 3, {"batch_size": 16})):
+        got = clf.predict_batch(texts, k=k, **kw)
+        for i, t in enumerate(texts):
+            _same(got[i], [tuple(p) for p in ex[key][i]], (key, family, t))
+    fresh = AdaptiveClassifier(ex["model_name"], device="cuda:0")
+    for part in ("train_1", "train_2"):
+        fresh.add_examples([t for t, _ in ex[part]], [l for _, l in ex[part]])
+    assert fresh.label_to_id == ex["label_to_id"] and fresh.training_history == ex["training_history"]
+    for label, want in ex["prototypes"].items():
+        assert np.abs(fresh.memory.prototypes[label].double().cpu().numpy() - np.asarray(want)).max() <= 1e-5, (family, label)
+
+
+def test_multilabel_classifier_from_text_equals_the_reference(standin, cuda_dev):
+    """MultiLabelAdaptiveClassifier (multilabel.py:70-413) from text: add_examples with label lists (flattened pairs, memory, label
+    thresholds by frequency), then -- with the reference's trained sigmoid head loaded (its BCE training draws dropout masks from
+    another generator) -- predict_multilabel with the default / an explicit threshold / max_labels and the min_predictions fill,
+    and predict().  (The reference's own load() raises a TypeError, so the head travels as model.safetensors: gen_e2e.py.)"""
+    from safetensors.torch import load_file
+    from adaptive_classifier import MultiLabelAdaptiveClassifier
+    g = os.path.join(GOLD, "e2e_multilabel_mini")
+    ex = json.load(open(os.path.join(g, "expected.json")))
+    clf = MultiLabelAdaptiveClassifier(ex["model_name"], device="cuda:0", **ex["ctor"])
+    texts, labels = [t for t, _ in ex["train"]], [l for _, l in ex["train"]]
+    clf.add_examples(texts, labels)
+    clf.add_examples(texts[:6], labels[:6])
+    assert clf.label_to_id == ex["label_to_id"] and clf.training_history == ex["training_history"]
+    assert clf.label_thresholds == pytest.approx(ex["label_thresholds"])
+    assert {l: len(v) for l, v in clf.memory.examples.items()} == ex["examples_per_class"]
+    for label, want in ex["prototypes"].items():
+        assert np.abs(clf.memory.prototypes[label].double().cpu().numpy() - np.asarray(want)).max() <= 1e-5, label
+    tensors = load_file(os.path.join(g, "model.safetensors"))
+    clf.adaptive_head.load_state_dict({k[len("adaptive_head_"):]: v for k, v in tensors.items()})
+    clf.adaptive_head = clf.adaptive_head.to(clf.device)
+    assert len(ex["texts"]) >= 20
+    for i, t in enumerate(ex["texts"]):
+        _same(clf.predict_multilabel(t), [tuple(p) for p in ex["multilabel_default"][i]], ("default", t))
+        _same(clf.predict_multilabel(t, threshold=0.51), [tuple(p) for p in ex["multilabel_thr_0.51"][i]], ("thr 0.51", t))
+        _same(clf.predict_multilabel(t, threshold=0.9, max_labels=2), [tuple(p) for p in ex["multilabel_thr_0.9_max2"][i]], ("thr 0.9 max 2", t))
+        _same(clf.predict(t, k=3), [tuple(p) for p in ex["predict_k3"][i]], ("predict k=3", t))
+    batch = clf.predict_multilabel_batch(ex["texts"])
+    for i, t in enumerate(ex["texts"]):
+        _same(batch[i], [tuple(p) for p in ex["multilabel_default"][i]], ("batched default", t))
