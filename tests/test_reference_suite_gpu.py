@@ -107,9 +107,9 @@ def _product_must_pass_what_the_reference_passes(test_file):
     excluded = EXCLUDED.get(test_file, {})
     assert set(excluded) <= set(ref_pass), "an exclusion names a test the reference does not pass"
     required = [t for t in ref_pass if t not in excluded]
-    # (the whole file runs; the tests that fail on the reference itself -- semantic thresholds that need pretrained weights -- and
-    #  the excluded ones run too, their outcome is not part of the verdict)
-    res, out = _run_reference_tests(test_file)
+    # only the required tests are selected (by name, `-k`): the ones that fail on the reference itself -- semantic thresholds that
+    # need pretrained weights, each training on hundreds of texts -- and the excluded ones are not part of the verdict
+    res, out = _run_reference_tests(test_file, select=" or ".join(required))
     bad = {t: res.get(t, "not run") for t in required if res.get(t) != "passed"}
     assert not bad, "%s: %d of %d required tests did not pass on the product: %s\n%s" % (test_file, len(bad), len(required), bad, out[-6000:])
     return len(required), len(excluded), len(base) - len(ref_pass)
