@@ -319,6 +319,11 @@ class AdaptiveClassifier:
                     logger.debug(f"Early stopping at epoch {epoch + 1}")
                     break
         self.last_train_info = {"steps": steps, "epochs": epoch + 1, "final_loss": avg_loss}
+        if avg_loss != avg_loss:
+            # (the reference would hand out NaN scores silently after a diverged training run; say so once, where it happened)
+            logger.warning("head training ended with a non-finite loss after %d steps: the head's probabilities will be NaN "
+                           "until the next add_examples() retrains it (non-finite embeddings are refused earlier, so this is a "
+                           "diverged run or a defect)", steps)
         self.train_steps += 1
 
     def _train_adaptive_head(self, epochs: int = 10):
