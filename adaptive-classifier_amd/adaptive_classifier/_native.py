@@ -53,7 +53,8 @@ class ac_prune_job(ctypes.Structure):
 
 class ac_modernbert_config(ctypes.Structure):
     _fields_ = [("hidden", c_int), ("layers", c_int), ("heads", c_int), ("intermediate", c_int), ("vocab", c_int),
-                ("max_pos", c_int), ("global_every", c_int), ("local_window", c_int), ("norm_eps", c_float)]
+                ("max_pos", c_int), ("global_every", c_int), ("local_window", c_int), ("norm_eps", c_float),
+                ("gemm_arith_opt", c_int)]       # per-call option, 0 = process default, else AC_GEMM_* + 1
 
 
 class ac_modernbert_weights(ctypes.Structure):

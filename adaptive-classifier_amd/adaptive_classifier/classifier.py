@@ -23,6 +23,7 @@ Each method documents where it intentionally deviates.
 import copy
 import json
 import logging
+import math
 from pathlib import Path
 from typing import Any, Dict, List, Optional, Set, Tuple, Union
 
@@ -298,7 +299,7 @@ class AdaptiveClassifier:
                                            targets_all=te, stepwise=stepwise)
             done = run_epoch()
             avg_loss = float(trainer.loss_accum.item()) / steps_per_epoch    # the only host sync of the epoch
-            if avg_loss != avg_loss and (nv.lib().ac_set_persistent_kernels(-1) & 1):
+            if not math.isfinite(avg_loss) and (nv.lib().ac_set_persistent_kernels(-1) & 1):
                 # a NaN epoch loss with the persistent kernel on: either the run diverged or a grid barrier gave up (device
                 # shared with another process).  Put parameters and moments back and repeat the epoch launch by launch, once
                 # (per-call flag: no process-wide switch is touched).
@@ -319,7 +320,7 @@ class AdaptiveClassifier:
                     logger.debug(f"Early stopping at epoch {epoch + 1}")
                     break
         self.last_train_info = {"steps": steps, "epochs": epoch + 1, "final_loss": avg_loss}
-        if avg_loss != avg_loss:
+        if not math.isfinite(avg_loss):
             # (the reference would hand out NaN scores silently after a diverged training run; say so once, where it happened)
             logger.warning("head training ended with a non-finite loss after %d steps: the head's probabilities will be NaN "
                            "until the next add_examples() retrains it (non-finite embeddings are refused earlier, so this is a "
@@ -573,10 +574,15 @@ class AdaptiveClassifier:
             f16 = getattr(self.model, "f16x2_active", None)
             if nan and f16 is not None and self._f16x2_active():
                 # opt-in fp16x2 arithmetic: an activation beyond fp16's range turns its rows into NaN; back to bf16x3
-                logger.warning("encoder: non-finite result under fp16x2 arithmetic; the encoder goes back to bf16x3 and the "
+                logger.warning("encoder: non-finite result under fp16x2 arithmetic; this classifier goes back to bf16x3 and the "
                                "batch is encoded again")
                 self.model.f16x2_overflows += 1
-                self.model.disable_f16x2()
+                if getattr(self, "_gemm_arith", None) == nv.AC_GEMM_F16X2:
+                    self._gemm_arith = nv.AC_GEMM_BF16X3      # per object: other classifiers on this encoder keep their fp16x2
+                elif hasattr(self.model, "set_arith"):
+                    self.model.set_arith(nv.AC_GEMM_BF16X3)   # the choice was the encoder's (or the process's): the encoder's now
+                else:
+                    self.model.disable_f16x2()                # (an encoder object with the older interface)
                 res, nan = finish(encode(True, False))
         return res                      # (still NaN: non-finite inputs or weights -- the caller's data, returned as computed)
 

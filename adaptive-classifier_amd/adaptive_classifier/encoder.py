@@ -301,10 +301,16 @@ class HipBertEncoder:
                 # an activation beyond fp16's range at scale 2^6 turned its rows into NaN (never into a wrong number)
                 import logging
                 logging.getLogger(__name__).warning(
-                    "encoder: non-finite embeddings under fp16x2 arithmetic (an activation beyond +-1023?); this encoder "
-                    "goes back to bf16x3 and the batch is encoded again")
+                    "encoder: non-finite embeddings under fp16x2 arithmetic (an activation beyond +-1023?); the batch is "
+                    "encoded again in bf16x3%s", "" if arith_mode(arith) is not None else
+                    ", which is this encoder's arithmetic from now on")
                 self.f16x2_overflows += 1
-                self.disable_f16x2()
+                # per object: the fp16 planes stay for other users of this encoder (classifiers that pass arith="f16x2");
+                # only the owner of the choice changes -- the call's `arith` is the caller's (the classifier demotes itself),
+                # an encoder-level or process-level f16x2 becomes an encoder-level bf16x3
+                if arith_mode(arith) is None:
+                    self.arith = nv.AC_GEMM_BF16X3
+                cfg = self._call_cfg(nv.AC_GEMM_BF16X3)
                 self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg)
         return out
 
@@ -441,7 +447,8 @@ class HipModernBertEncoder:
         self.config = _Cfg(H, getattr(cfg, "_name_or_path", ""))
         self.training = False
         self.ccfg = nv.ac_modernbert_config(H, L, A, I, cfg.vocab_size, cfg.max_position_embeddings, every,
-                                            int(cfg.sliding_window), float(cfg.norm_eps))
+                                            int(cfg.sliding_window), float(cfg.norm_eps), 0)
+        self.arith = None               # this encoder's GEMM arithmetic (None = the process default); per call: encode_cls(arith=)
         sd = {k: v.detach() for k, v in hf_model.state_dict().items()}
         self._keep, self._arrays = [], {}
 
@@ -533,11 +540,24 @@ class HipModernBertEncoder:
                  "ac_modernbert_workspace")
         return need.value
 
+    def _call_cfg(self, arith=None):
+        """ac_modernbert_config of one native call: the architecture + this call's arithmetic (0 = process default, else value + 1)."""
+        a = arith_mode(arith)
+        if a is None:
+            a = self.arith
+        c = self.ccfg
+        return nv.ac_modernbert_config(c.hidden, c.layers, c.heads, c.intermediate, c.vocab, c.max_pos, c.global_every,
+                                       c.local_window, c.norm_eps, 0 if a is None else a + 1)
+
     def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None, verify=True, force_layered=False,
-                   verify_small=None):
+                   verify_small=None, arith=None):
         """int64 [b, S] ids (+ optional mask; token types do not exist in ModernBERT) -> unit-norm CLS [b, H].
+        arith: this call's GEMM arithmetic ("f32" | "bf16x3" | "f16x2"; None = this encoder's `arith`, else the process default),
+        a per-call option inside ac_modernbert_config as for HipBertEncoder; "f16x2" runs as bf16x3 here (no fp16 weight planes
+        are built for this family).
         (verify / force_layered: interface parity with HipBertEncoder; this encoder has neither a one-launch path nor
         LayerNorm-fused GEMM epilogues, i.e. no kernel that can give up.)"""
+        ccfg = self._call_cfg(arith)
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         b, S = ids.shape
         mk = None if attention_mask is None else attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
@@ -563,14 +583,14 @@ class HipModernBertEncoder:
                     total, not_prefix, longest, _ = info.tolist()
                     if not not_prefix and total < nb * S:
                         nv.check(nv.lib().ac_modernbert_encode_cls_packed(
-                            ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]), nb, S, nv.ptr(cu),
+                            ctypes.byref(ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]), nb, S, nv.ptr(cu),
                             nv.ptr(src), total, longest, nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws),
                             self._ws.numel(), nv.stream_ptr(self.device)), "ac_modernbert_encode_cls_packed")
                         self.last_tokens += total
                         continue
                 self.last_tokens += nb * S
                 nv.check(nv.lib().ac_modernbert_encode_cls(
-                    ctypes.byref(self.ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
+                    ctypes.byref(ccfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
                     nv.ptr(None if mk is None else mk[r0:r1]), r1 - r0, S, nv.ptr(out[r0:r1]), out.stride(0),
                     nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)), "ac_modernbert_encode_cls")
         return out

@@ -818,6 +818,7 @@ int check_mb(const ac_modernbert_config* c) {
                "modernbert: hidden=%d / intermediate=%d unsupported", c->hidden, c->intermediate);
     AC_REQUIRE(c->hidden == c->heads * DH, AC_EUNSUPPORTED, "modernbert: head dim %d unsupported (only %d)",
                c->hidden / c->heads, DH);
+    AC_REQUIRE(c->gemm_arith_opt >= 0 && c->gemm_arith_opt <= 3, AC_EINVAL, "modernbert: gemm_arith_opt %d out of range", c->gemm_arith_opt);
     return AC_OK;
 }
 
@@ -950,6 +951,7 @@ extern "C" int ac_modernbert_encode_cls(const ac_modernbert_config* cfg, const a
     int rc = check_mb(cfg);
     if (rc) return rc;
     if (b == 0) return AC_OK;
+    const ac::CallScope scope(cfg->gemm_arith_opt, 0, 0);
     AC_REQUIRE(w && d_ids && d_out && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden, AC_EINVAL,
                "modernbert_encode_cls: bad arguments (b=%d S=%d max_pos=%d)", b, S, cfg->max_pos);
     return modernbert_encode_impl(cfg, w, d_ids, d_mask, b, S, nullptr, nullptr, b * S, S, d_out, ldo, d_ws, ws_bytes,
@@ -963,6 +965,7 @@ extern "C" int ac_modernbert_encode_cls_packed(const ac_modernbert_config* cfg, 
     int rc = check_mb(cfg);
     if (rc) return rc;
     if (b == 0) return AC_OK;
+    const ac::CallScope scope(cfg->gemm_arith_opt, 0, 0);
     AC_REQUIRE(w && d_ids && d_out && d_cu && d_tok_src && b > 0 && S >= 1 && S <= cfg->max_pos && ldo >= cfg->hidden &&
                    total_tokens >= b && total_tokens <= b * S && longest >= 1 && longest <= S,
                AC_EINVAL, "modernbert_encode_cls_packed: bad arguments (b=%d S=%d tokens=%d longest=%d)", b, S, total_tokens, longest);

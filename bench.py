@@ -1194,8 +1194,9 @@ def main():
     # among 48 k ones in round 5).  gc.freeze() moves everything allocated so far into the permanent generation (what serving
     # stacks do after model load); the per-step garbage is still collected.
     import gc
+    dt_unfrozen = timed_predict(clf, ids, types, mask, args.steps, args.warmup)     # the same loop BEFORE the freeze, reported beside `value`
     gc.collect()
-    gc.freeze()
+    gc.freeze()                                   # (stays in force for the rest of the process: the cpu_baseline legs run frozen too)
     dt = timed_predict(clf, ids, types, mask, args.steps, args.warmup)
     stages = time_stages(clf, ids, types, mask)
 
@@ -1269,6 +1270,8 @@ def main():
                    "length_distribution": {"kind": "uniform integer [8, 32], first text 32", "min": int(lens_h.min()),
                                            "mean": float(lens_h.mean()), "max": int(lens_h.max())},
                    "padding_free": bool(unpadded),
+                   "gc_frozen": True,
+                   "value_gc_unfrozen": BATCH * args.steps / dt_unfrozen,
                    "prototypes": NPROTO, "dim": DIM, "k": KNN_K, "classes": NCLASS, "parallelism": "dp1",
                    "gemm_arith": ("bf16x3 split: fp32 operands = h+m+l exactly, 6 bf16 MFMA products, fp32 "
                                   "accumulate (fp32-grade; tests/test_gemm_split_gpu.py)" if arith == 1

@@ -632,6 +632,8 @@ typedef struct {
     int global_every;     /* global_attn_every_n_layers (3) */
     int local_window;     /* config.sliding_window = local_attention / 2 (64): |q - k| <= local_window */
     float norm_eps;       /* 1e-5 */
+    int gemm_arith_opt;   /* per-call GEMM arithmetic as in ac_bert_config: 0 = process default, else AC_GEMM_* + 1 (AC_GEMM_F16X2
+                           * runs as bf16x3 here: this encoder builds no fp16 weight planes) */
 } ac_modernbert_config;
 
 typedef struct {

@@ -552,6 +552,16 @@ def test_predict_retry_contract_without_a_gpu():
 
         def disable_f16x2(self):
             self._f16 = False
+
+    class EncF16New(EncF16):                                        # ... and the current interface: the choice is demoted, planes stay
+        def set_arith(self, a):
+            self._f16 = False
+            self.arith_set = a
+
+        def disable_f16x2(self):
+            raise AssertionError("the planes of a shared encoder must not be dropped")
+    c, res, seen = run(EncF16New(), 1)
+    assert res == ["result of emb2"] and c.model.f16x2_overflows == 1 and not c.model.f16x2_active() and c.model.arith_set == 1
     c, res, seen = run(EncF16(), 1)                                 # -> the encoder goes back to bf16x3, the batch is encoded again
     assert res == ["result of emb2"] and c.model.calls == [(False, False), (True, False)]
     assert c.model.f16x2_overflows == 1 and not c.model.f16x2_active()
