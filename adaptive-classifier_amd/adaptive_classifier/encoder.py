@@ -323,6 +323,7 @@ class HipBertEncoder:
         for r0 in range(0, b, cb):
             r1 = min(b, r0 + cb)
             nb = r1 - r0
+            mk_all_ones = False
             if self.unpad and mk is not None and S > 1 and nb * S > SMALL_TOKENS:
                 # padding-free path: pack on the device, read back {rows, prefix flag, longest} (one 16-byte D2H)
                 cu = torch.empty(nb + 1, dtype=torch.int32, device=self.device)
@@ -341,12 +342,14 @@ class HipBertEncoder:
                         nv.stream_ptr(self.device)), "ac_bert_encode_cls_packed")
                     self.last_tokens += total
                     continue
+                if not not_prefix and total == nb * S:
+                    mk_all_ones = True          # nothing to leave out: the unpacked forward needs no mask (and may fuse its attention)
             used = ctypes.c_int(0)
 
             def call(opts):
                 nv.check(nv.lib().ac_bert_encode_cls_opts(
                     ctypes.byref(cfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]),
-                    nv.ptr(None if tt is None else tt[r0:r1]), nv.ptr(None if mk is None else mk[r0:r1]), nb, S,
+                    nv.ptr(None if tt is None else tt[r0:r1]), nv.ptr(None if (mk is None or mk_all_ones) else mk[r0:r1]), nb, S,
                     nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(), opts, ctypes.byref(used),
                     nv.stream_ptr(self.device)), "ac_bert_encode_cls_opts")
             call(nv.AC_BERT_LAYERED if force_layered else 0)

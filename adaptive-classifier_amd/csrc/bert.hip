@@ -11,6 +11,7 @@
 // fused fp32 attention kernel (one wave per (sequence, head, 64-query tile); K/V tiles staged
 // through LDS, online softmax, scores never touch HBM).
 #include "common.h"
+#include "attention_core.h"
 
 #include <math.h>
 
@@ -137,166 +138,44 @@ __global__ __launch_bounds__(256) void cls_normalize_kernel(const float* x, int 
 constexpr int DH = 64;        // head dim (checked in ac_bert_encode_cls)
 constexpr int KT = 64;        // keys per LDS tile of the CLS-only kernel
 
-// ---- fused attention on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), head dim 64 ----
-// One wave per (sequence, head, 32-query tile); grid = (ceil(S/32), heads, batch).
-//   S^T tile = K_tile . Q^T  : A = K rows (lane (key j, k-slice h) holds float4 K[j][8kb+4h..]),
-//                              B = Q rows (same shape, pre-scaled, resident in registers)
-//                              -> C layout: lane & 31 = QUERY, registers = the tile's 32 keys
-//   so the online softmax (max / sum over keys) is per-lane register work plus ONE exchange with the
-//   partner lane (lane ^ 32) -- no LDS, no row reductions across the wave.
-//   O^T += V_tile^T . P^T    : B = P, which is ALREADY in B-operand layout (lane = query, k = lane >> 5:
-//                              MFMA step r consumes keys row(r,0) and row(r,1)); A = V^T read as
-//                              V[key][32t + (lane & 31)] (128-B coalesced rows).  C layout again has
-//                              lane & 31 = query, so the rescale by exp(m_old - m_new) is per lane.
-// The k-order inside a tile is whatever the C layout dictates -- a dot product does not care.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using acattn::f32x16;
+using acattn::rope_rotate;
 
-__device__ __forceinline__ int crow32(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// ctx_planes (optional): emit the context as bf16x3 operand planes of the [batch*S, H] output-projection input
-// instead of fp32 rows.
-__device__ __forceinline__ void rope_rotate(f32x4 (&x)[8], const float* cs, const float* sn, int pos, int h) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        const f32x4 c = *reinterpret_cast<const f32x4*>(cs + (int64_t)pos * 32 + 8 * kb + 4 * h);
-        const f32x4 s = *reinterpret_cast<const f32x4*>(sn + (int64_t)pos * 32 + 8 * kb + 4 * h);
-        const f32x4 lo = x[kb], hi = x[kb + 4];
-        x[kb] = lo * c + (-hi) * s;          // q * cos + rotate_half(q) * sin, two roundings per term like torch
-        x[kb + 4] = hi * c + lo * s;
-    }
-}
-
-// ROPE (ModernBERT, modeling_modernbert.py:188-219): q, k rotated by the position's angle before the scores,
-//   x'[d] = x[d] cos[d] - x[d+32] sin[d],  x'[d+32] = x[d+32] cos[d] + x[d] sin[d]   (d < 32; cos/sin tables
-//   [position][32] computed on the host exactly as transformers does).  Both halves of a pair sit in the same
-//   lane (fragment k-blocks kb and kb + 4), so the rotation is register-local.
-// window >= 0 (sliding-window layers, masking_utils.py:141-151): key k is visible to query q iff |q - k| <= window.
+// One wave per (sequence, head, 32-query tile); grid = (ceil(S/32), heads, batch); the arithmetic is acattn::attention_tile
+// (attention_core.h).  ctx_planes (optional): emit the context as bf16x3 operand planes of the [batch*S, H] output-projection
+// input instead of fp32 rows.
 // cu (packed / padding-free mode): sequence bi owns rows [cu[bi], cu[bi+1]) of qkv / ctx, all of them real tokens
 // (no mask); total_rows = cu[batch] is the row count of the planes output.  cu == nullptr: rows bi*S .. bi*S+S-1.
 // DHT = head dimension: 64 (BERT-base / large, DistilBERT, RoBERTa, ModernBERT) or 32 (the MiniLM family: 384 = 12 x 32).
+// boundary_stride > 0 (packed mode, after the QKV GEMM with the fused attention epilogue, gemm_pipe.hip EPI_QKV_ATTN): grid z
+// walks the row-tile boundaries boundary_stride * (z + 1) instead of the sequences; the wave serves the sequence that STRADDLES
+// its boundary (whose rows two GEMM tiles share, so neither could finish it) and leaves when a sequence starts exactly there.
 template <bool ROPE, int DHT = 64>
 __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, const int64_t* mask, int S_, int H,
                                                             float scale, float* ctx, uint16_t* ctx_planes,
                                                             const float* rope_cos, const float* rope_sin,
                                                             int window, const int32_t* __restrict__ cu = nullptr,
-                                                            int64_t total_rows = 0, int f16 = 0) {
-    static_assert(DHT == 64 || (DHT == 32 && !ROPE), "head dim 64, or 32 without RoPE");
-    constexpr int NKB = DHT / 8;                                     // 8-dim k-blocks of the QK^T product
+                                                            int64_t total_rows = 0, int f16 = 0, int boundary_stride = 0,
+                                                            int nseq = 0) {
     const int lane = threadIdx.x;
-    const int qt = blockIdx.x, head = blockIdx.y, bi = blockIdx.z;
+    const int qt = blockIdx.x, head = blockIdx.y;
+    int bi = blockIdx.z;
+    if (boundary_stride > 0) {
+        const int brow = boundary_stride * ((int)blockIdx.z + 1);
+        int lo = 0, hi = nseq;                                       // the sequence holding row `brow`: largest s with cu[s] <= brow
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cu[mid] <= brow) lo = mid; else hi = mid; }
+        if (cu[lo] == brow || brow >= cu[nseq]) return;              // a sequence starts at the boundary: nothing straddles it
+        bi = lo;
+    }
     const int64_t ld = 3 * (int64_t)H;
     const int64_t row0 = cu ? (int64_t)cu[bi] : (int64_t)bi * S_;
     const int S = cu ? cu[bi + 1] - cu[bi] : S_;
     if (qt * 32 >= S) return;                                        // (packed mode: short sequence)
     const float* base = qkv + row0 * ld + head * DHT;
-    const int j = lane & 31, h = lane >> 5;
-    const int qi = qt * 32 + j;
-    const bool qvalid = qi < S;
-
-    f32x4 Qf[NKB];
-    {
-        const float* qp = base + (int64_t)(qvalid ? qi : S - 1) * ld + 4 * h;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) Qf[kb] = *reinterpret_cast<const f32x4*>(qp + 8 * kb);
-        if constexpr (ROPE) rope_rotate(Qf, rope_cos, rope_sin, qvalid ? qi : S - 1, h);
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) Qf[kb] = Qf[kb] * scale;
-    }
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m = -INFINITY, l = 0.f;
-
-    // K fragment of a tile (keys past S are clamped; they are masked below).  The next tile's fragment is
-    // requested right after the QK^T MFMAs have consumed this one, so its latency hides under softmax + PV.
-    f32x4 Kf[NKB];
-    auto load_k = [&](int k0) {
-        int kr = k0 + j; if (kr > S - 1) kr = S - 1;
-        const float* kp = base + (int64_t)kr * ld + H + 4 * h;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) Kf[kb] = *reinterpret_cast<const f32x4*>(kp + 8 * kb);
-        if constexpr (ROPE) rope_rotate(Kf, rope_cos, rope_sin, kr, h);
-    };
-    // key tiles that can hold a visible key for any of this tile's 32 queries (wave-uniform bounds)
-    int kbeg = 0, kend = S;
-    if (window >= 0) {
-        kbeg = qt * 32 - window; kbeg = kbeg < 0 ? 0 : (kbeg / 32) * 32;
-        const int last = qt * 32 + 31 + window;
-        if (last + 1 < kend) kend = last + 1;
-    }
-    load_k(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
-        // key validity as a 32-bit mask shared by the wave
-        const int kj = k0 + j;
-        const bool kv = kj < S && (!mask || mask[(int64_t)bi * S_ + kj] != 0);
-        const unsigned vmask = (unsigned)(__ballot(kv && h == 0) & 0xffffffffull);
-        if (vmask == 0u) { load_k(k0 + 32); continue; }              // wave-uniform
-        f32x16 st;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-                st = __builtin_amdgcn_mfma_f32_32x32x2f32(Kf[kb][s4], Qf[kb][s4], st, 0, 0, 0);
-        load_k(k0 + 32);                                             // clamped past the end: harmless re-read
-        // online softmax for query `j` (this lane + partner lane hold its 32 keys)
-        float cmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            bool ok = (vmask >> crow32(r, h)) & 1u;
-            if (window >= 0) { const int dk = qi - (k0 + crow32(r, h)); ok = ok && dk <= window && -dk <= window; }
-            st[r] = ok ? st[r] : -INFINITY;
-            cmax = fmaxf(cmax, st[r]);
-        }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const float m_new = fmaxf(m, cmax);
-        // with a window a tile may hold no visible key for THIS query: nothing accumulated yet -> keep zeros
-        const bool none = m_new == -INFINITY;
-        const float corr = none ? 1.f : expf(m - m_new);            // m = -inf -> 0
-        float psum = 0.f;
-        float p[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = none ? 0.f : expf(st[r] - m_new); psum += p[r]; }
-        psum += __shfl_xor(psum, 32);
-        l = l * corr + psum;
-        m = m_new;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
-        // O^T += V^T P^T
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int vr = k0 + crow32(r, h); if (vr > S - 1) vr = S - 1;
-            const float* vp = base + (int64_t)vr * ld + 2 * H + j;
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], p[r], o0, 0, 0, 0);
-            if constexpr (DHT == 64) o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], p[r], o1, 0, 0, 0);
-        }
-    }
-    if (qvalid) {
-        const float inv = l > 0.f ? 1.f / l : 0.f;
-        // C layout of O^T: lane & 31 = query (this lane), register r = output dim crow32(r, h) (+32 for o1)
-        if (ctx_planes) {
-            // registers 4g .. 4g+3 are dims 8g + 4h .. +3: half of k-slot (head * 8 + 4t + g); the partner lane
-            // (h ^ 1) writes the other half
-            const int64_t rows = cu ? total_rows : (int64_t)gridDim.z * S, row = row0 + qi, plane = rows * H;
-#pragma unroll
-            for (int t = 0; t < DHT / 32; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (t ? o1[4 * g + e] : o0[4 * g + e]) * inv;
-                    ac::emit_planes4(ctx_planes + ac::plane_off(rows, row, head * DHT + 32 * t + 8 * g + 4 * h), plane, v, f16);
-                }
-        } else {
-            float* dst = ctx + (row0 + qi) * H + head * DHT;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dst[crow32(r, h)] = o0[r] * inv;
-                if constexpr (DHT == 64) dst[32 + crow32(r, h)] = o1[r] * inv;
-            }
-        }
-    }
+    const int64_t rows = cu ? total_rows : (int64_t)gridDim.z * S_;
+    acattn::attention_tile<ROPE, DHT>(base, base + H, base + 2 * H, ld, S, qt, lane, scale, mask ? mask + (int64_t)bi * S_ : nullptr,
+                                      rope_cos, rope_sin, window, ctx ? ctx + row0 * H + head * DHT : nullptr, H, ctx_planes, rows,
+                                      row0, head * DHT, f16);
 }
 
 // Last layer: only the CLS query of every sequence feeds the output (classifier.py:1272), so its
@@ -399,7 +278,7 @@ __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ u,
         const f32x4 x = *reinterpret_cast<const f32x4*>(a + 4 * e);
         const f32x4 gate = *reinterpret_cast<const f32x4*>(a + goff + 4 * e);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) o[e][c] = 0.5f * x[c] * (1.f + erff(x[c] * 0.70710678118654752440f)) * gate[c];
+        for (int c = 0; c < 4; ++c) o[e][c] = ac::gelu_erf(x[c]) * gate[c];
         *reinterpret_cast<f32x4*>(g + row * I + 8 * q + 4 * e) = o[e];
     }
     if (planes) {
@@ -478,9 +357,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 struct BertWs {
-    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
+    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, cu, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
     size_t lnctl_bytes;
 };
+// cu of an UNPACKED batch without a mask (every sequence has S real tokens): what ac_bert_pack would have produced
+__global__ __launch_bounds__(256) void iota_cu_kernel(int32_t* cu, int b, int S) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i <= b) cu[i] = i * S;
+}
 // The verdict of the fused-LayerNorm GEMM epilogues sits at offset 0 of the workspace WHATEVER (b, S) the workspace is used
 // with: word 0 = "a panel of the CURRENT call gave up" (set by the kernels; later launches of the call stop waiting at their first
 // look at it), word 1 = the same for EARLIER calls since the last ac_bert_ln_fusion_clear.  Every call starts by rolling word 0
@@ -515,6 +399,8 @@ BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     off += w.lnctl_bytes;
     w.lnpart = off;
     off += ac::align_up(ac::pipe_ln_part_bytes((int)T, c.hidden), 256);
+    w.cu = off;                       // sequence offsets of an unpacked, unmasked batch (fused attention epilogue)
+    off += ac::align_up((size_t)(b + 1) * sizeof(int32_t), 256);
     w.total = off;
     return w;
 }
@@ -597,6 +483,16 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
     AC_LAUNCH_CHECK();
     const int dh = c.hidden / c.heads;                // 64, or 32 (MiniLM family)
     const float scale = 1.0f / sqrtf((float)dh);
+    // Self-attention inside the QKV GEMM's epilogue (gemm_pipe.hip EPI_QKV_ATTN): sequences laid out row after row (packed, or
+    // unpacked without a mask = every sequence S real tokens), head dim 64, longest sequence <= 64, layers 0 .. L-2 on planes
+    const int32_t* cu_at = cu;
+    const bool fuse_attn = pl && c.layers > 1 && dh == 64 && (cu || !d_mask) && ac::qkv_attn_applies(T, H, c.heads, Smax);
+    if (fuse_attn && !cu) {
+        int32_t* cuw = (int32_t*)(base + ws.cu);
+        hipLaunchKernelGGL(iota_cu_kernel, dim3((b + 256) / 256), dim3(256), 0, stream, cuw, b, S);
+        AC_LAUNCH_CHECK();
+        cu_at = cuw;
+    }
     for (int l = 0; l < c.layers; ++l) {
         const uint16_t* qkv_w3 = wplanes ? w->qkv_w3[l] : nullptr;
         const uint16_t* ao_w3 = wplanes ? w->ao_w3[l] : nullptr;
@@ -618,7 +514,18 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
             resid = ffn;                               // compact CLS rows, staged in ffn (free until FFN1 writes it)
             ldres = H;
         }
-        if (q_cls_only) {
+        if (fuse_attn && !last) {
+            rc = ac::launch_gemm_pipe_qkv_attn(xp, T, f16 ? w->qkv_wh[l] : qkv_w3, 3 * H, w->qkv_b[l], T, H, c.heads, cu_at, b, Smax, scale,
+                                               ctxp, qkv, stream, (int)f16);
+            if (rc) return rc;
+            // the sequences that straddle a 256-row tile boundary (their q | k | v rows are in qkv): one wave per boundary
+            const int nbound = (T - 1) / ac::kQkvAttnRows;
+            if (nbound > 0) {
+                hipLaunchKernelGGL((attention_mfma_kernel<false, 64>), dim3((Smax + 31) / 32, c.heads, nbound), dim3(64), 0, stream, qkv,
+                                   nullptr, S, H, scale, ctx, ctxp, nullptr, nullptr, -1, cu_at, (int64_t)T, (int)f16, ac::kQkvAttnRows, b);
+                AC_LAUNCH_CHECK();
+            }
+        } else if (q_cls_only) {
             const int64_t HH = (int64_t)H * H;
             rc = f16 ? ac::linear_f16x2(xp, w->qkv_wh[l] + (int64_t)H * 8, w->qkv_b[l] + H, nullptr, 0, qkv + H, 3 * H, nullptr, T, 2 * H, H, 0,
                                         stream, 3 * H)
@@ -634,7 +541,9 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
                                       stream, 0.f, 0, qkv_w3, pl ? xp : nullptr);
         }
         if (rc) return rc;
-        if (last) {
+        if (fuse_attn && !last) {
+            // (context rows are already in ctxp)
+        } else if (last) {
             const float* qc = q_cls_only ? y : nullptr;
             if (dh == 64)
                 hipLaunchKernelGGL((attention_cls_kernel<false, 64>), dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale,

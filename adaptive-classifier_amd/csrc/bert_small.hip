@@ -256,7 +256,7 @@ __device__ __forceinline__ void gemm_phase(const float* A, int K, const float* g
         for (int w8 = 0; w8 < 8; ++w8) v += L.red[(w8 * 2 + e_tt) * 256 + e_e];
         if (token < T) {
             v += bv;
-            if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+            if (ACT == 2) v = ac::gelu_erf(v);
             if (RES) v += rv;
             st_sc1(out + (size_t)token * N + gi * 16 + ecol, v);
         }

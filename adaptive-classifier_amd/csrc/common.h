@@ -78,6 +78,14 @@ int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, 
                         const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, const float* gamma,
                         const float* beta, float eps, void* part, unsigned* count, unsigned* abort_flag, uint16_t* planes,
                         hipStream_t stream, int f16 = 0);      // f16: operands AND emitted planes are fp16x2
+// the [T, 3H] QKV projection of a PACKED batch with the self-attention in its epilogue (gemm_pipe.hip EPI_QKV_ATTN): context rows
+// go straight to `ctx_planes`; `qkv` (fp32 [T, 3H]) only receives the rows of sequences that straddle a 256-row tile boundary,
+// which the caller then serves with attention_mfma_kernel's boundary mode (boundary_stride = kQkvAttnRows)
+constexpr int kQkvAttnRows = 256;
+bool qkv_attn_applies(int M, int H, int heads, int smax);
+int launch_gemm_pipe_qkv_attn(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias, int M, int H,
+                              int heads, const int32_t* cu, int b, int smax, float scale, uint16_t* ctx_planes, float* qkv,
+                              hipStream_t stream, int f16 = 0);
 // true when linear_f32(M, N, K) with W planes takes the pre-split kernel (only then may A / C planes be passed)
 bool linear_takes_planes(int M, int N, int K);
 
@@ -174,6 +182,30 @@ __device__ __forceinline__ void emit_planes8(uint16_t* p, int64_t plane, const f
         *reinterpret_cast<uint4*>(p + 2 * plane) = L;
     }
 }
+// ---- GELU (erf form, transformers' "gelu": modeling_bert.py:325-337 via ACT2FN) ----
+// gelu(x) = x/2 (1 + erf(x / sqrt 2)) with a BRANCH-FREE erf: erf(|t|) = 1 - 2^(-|t| P(|t|)), P a degree-8 polynomial fitted
+// (weighted minimax on the error of erf, fp64 fit error 2.2e-9) to -log2(erfc(t)) / t on (0, 4]; beyond 4 the result rounds to 1
+// in fp32 anyway.  17 VALU instructions with one v_exp_f32 instead of the ~45 of ocml's two-branch erff (both branches execute in
+// a divergent wave) -- the FFN1 epilogue evaluates it 128 times per lane with the matrix pipe idle.  Accuracy in
+// fp32 against the exact function (6M points on [-8, 8], tools/gelu_check.py): |erf| error <= 8.5e-8, |gelu| error <= 4.6e-7 --
+// torch's own fp32 CPU gelu sits at 1.2e-6 on the same points.  NaN in, NaN out; gelu(+inf) = +inf.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float t = x * 0.70710678118654752440f;
+    const float a = fminf(__builtin_fabsf(t), 4.0f);
+    float p = -1.160484225692926e-05f;
+    p = __builtin_fmaf(p, a, 0.00015296465426217765f);
+    p = __builtin_fmaf(p, a, -0.0008482354460284114f);
+    p = __builtin_fmaf(p, a, 0.002274787751957774f);
+    p = __builtin_fmaf(p, a, -8.480761607643217e-05f);
+    p = __builtin_fmaf(p, a, -0.027724474668502808f);
+    p = __builtin_fmaf(p, a, 0.1483079046010971f);
+    p = __builtin_fmaf(p, a, 0.9184429049491882f);
+    p = __builtin_fmaf(p, a, 1.6279072761535645f);
+    const float e = __builtin_amdgcn_exp2f(-(p * a));          // v_exp_f32: 2^-E, E in [0, 26.2]
+    const float r = __builtin_copysignf(1.0f - e, t);
+    return 0.5f * x * (1.0f + r);
+}
+
 // element offset (uint16 units) of (row, k) inside one plane of a [rows, K] operand: planes[p][k/8][row][k%8]
 __device__ __forceinline__ int64_t plane_off(int64_t rows, int64_t row, int k) {
     return ((int64_t)(k >> 3) * rows + row) * 8 + (k & 7);

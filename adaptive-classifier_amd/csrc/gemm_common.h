@@ -47,13 +47,26 @@ struct LnFuse {
     int starve;             // test hook (ac_gemm_set_ln_fusion(2)): wait for one arrival more than will ever come
 };
 
+// EPI_QKV_ATTN (gemm_pipe.hip): the [T, 3H] QKV projection with the self-attention of the packed sequences computed in the
+// epilogue.  A 256 x 192 output tile is (256 token rows) x (one head's q | k | v): the W rows of tile `head` are q rows
+// [64 head, 64 head + 64) of the fused [3H, H] weight, then the same rows of its k and v blocks.  Sequences that lie inside the
+// tile's rows are finished there (context rows straight into the operand planes of the output projection); the q | k | v rows of
+// a sequence that straddles a row-tile boundary go to `qkv` (fp32 [T, 3H]) for attention_mfma_kernel's boundary mode.
+struct AttnFuse {
+    const int32_t* cu;      // [b + 1] first row of every sequence, cu[b] = T (ac_bert_pack)
+    int b, H, smax;         // sequences, hidden size (= heads * 64), longest sequence (<= 64)
+    float scale;            // 1 / sqrt(head dim)
+    uint16_t* ctx_planes;   // [planes][H / 8][T][8]
+    float* qkv;             // [T, 3H]: only rows of straddling sequences are written
+};
+
 __device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, int64_t row, int col,
                                                 const float* C, int64_t ldc, int N) {
     float v = e.alpha * acc;
     if (e.beta != 0.f) v = fmaf(e.beta, C[row * ldc + col], v);
     if (e.bias) v += e.bias[col];
     if (e.act == ACT_RELU) v = v < 0.f ? 0.f : v;            // (torch.relu semantics: NaN stays NaN, unlike fmaxf)
-    else if (e.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    else if (e.act == ACT_GELU) v = ac::gelu_erf(v);
     if (e.mask) v = e.mask[row * (int64_t)N + col] ? v * e.mask_scale : 0.f;
     else if (e.drop_p > 0.f) v = ac::dropout_keep(e.drop_seed, (uint64_t)(row * (int64_t)N + col), e.drop_p) ? v * e.mask_scale : 0.f;
     if (e.residual) v += e.residual[row * e.ldr + col];
@@ -67,13 +80,14 @@ enum { EPI_GENERIC = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_RES = 3, EPI_B
        // result columns [32t, 32t+32) -- a wave's two 32x32 tiles hold input_j and gate_j in the same lane/register
        EPI_GEGLU32 = 5,
        EPI_IDENT = 6,          // store the accumulators as they are (second half of the fused-LayerNorm epilogue)
-       EPI_BIAS_RES_LN = 7 };  // bias + residual, then LayerNorm over the whole row (gemm_pipe.hip)
+       EPI_BIAS_RES_LN = 7,    // bias + residual, then LayerNorm over the whole row (gemm_pipe.hip)
+       EPI_QKV_ATTN = 8 };     // the fused QKV projection's tile = one head's q | k | v: self-attention in the epilogue (gemm_pipe.hip)
 
 template <int EPI>
 __device__ __forceinline__ float fast_epilogue(float acc, float bias, float res) {
     if (EPI == EPI_IDENT) return acc;
     float v = acc + bias;
-    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (EPI == EPI_BIAS_GELU) v = ac::gelu_erf(v);
     if (EPI == EPI_BIAS_RELU) v = v < 0.f ? 0.f : v;
     if (EPI == EPI_BIAS_RES) v += res;
     return v;
@@ -157,7 +171,7 @@ __device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][TN], uint16_
                 float v;
                 if (GLU) {
                     const float x = acc[mi][0][r] + bias;
-                    v = 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)) * (acc[mi][1][r] + bias_g);
+                    v = ac::gelu_erf(x) * (acc[mi][1][r] + bias_g);
                 } else {
                     v = fast_epilogue<EPI>(acc[mi][ni][r], bias, 0.f);
                 }

@@ -24,6 +24,7 @@
 #include "common.h"
 #include "gemm_common.h"
 #include "grid_sync.h"
+#include "attention_core.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -43,6 +44,7 @@ struct PipeParams {
     int M, N, K;
     Epilogue epi;
     LnFuse ln;                          // EPI_BIAS_RES_LN only
+    AttnFuse at;                        // EPI_QKV_ATTN only
     unsigned long long* stamps;         // diagnostic (ac_gemm_debug_stamps): 4 shader-clock stamps per workgroup, or null
     int krot;                           // experiment: XCD x starts its k-loop at stage x nk / 8 and wraps (ac_gemm_set_krot)
 };
@@ -216,6 +218,88 @@ __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float
         store_tile_planes<EPI_IDENT, TM, TN, AR>(acc, ln.planes, prm.M, prm.N, m0, n0, wm, wn, lane, e, lds_f + wave * kTrFloats);
 }
 
+// ---- EPI_QKV_ATTN: self-attention of the packed sequences in the epilogue of the QKV projection ----
+// The tile is 256 token rows x (q | k | v of ONE head).  Staged as fp32 rows in LDS (the DMA ring is idle by now), a sequence's
+// attention is exactly what attention_mfma_kernel does from HBM -- acattn::attention_tile, same instructions, same order, one wave
+// per (sequence, 32-query tile) -- so the context rows are bit-identical to the two-launch route, and the 47 MB fp32 qkv round
+// trip (written by this epilogue, read back by the attention launch) and the attention launch itself (22 us per layer at 5141
+// rows, matrix pipe idle) are gone.  The whole tile is 196 KB of fp32, the LDS 160 KB: it is staged in 2 (longest sequence <= 32)
+// or 3 (<= 64) overlapping passes of 160 rows, pass p serving the sequences that START in its first 128 / 96 rows (they end
+// inside its 160).  A sequence that straddles a 256-row tile boundary cannot be finished by either tile: both write their part
+// of its q | k | v rows to the fp32 qkv buffer and attention_mfma_kernel's boundary mode (one wave per boundary, head and query
+// tile, <= 20 sequences at 5141 rows) serves it afterwards.
+constexpr int kAtLd = 196;              // floats per staged row: 192 + 4 (row stride 784 B = 16 B mod 256: the 16 lanes of a b128 read hit distinct banks)
+constexpr int kAtRows = 160;            // staged rows per pass
+constexpr int kAtBytes = kAtRows * kAtLd * 4;
+
+template <int TM, int TN, int WMW, int WNW, int AR>
+__device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], const PipeParams& prm, int bm, int head, int wm, int wn,
+                                                       int lane, int wave, float* T) {
+    static_assert(TM == 2 && TN == 3 && WMW == 4 && WNW == 2, "built for the 256 x 192 tile (8 waves of 64 x 96)");
+    constexpr int BM = 256, NW = WMW * WNW;
+    const AttnFuse& at = prm.at;
+    const int m0 = bm * BM, H = at.H, c = lane & 31;
+    float bias[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int col = wn * 96 + ni * 32 + c;                          // column of the head's q | k | v block
+        bias[ni] = prm.epi.bias[(col >> 6) * H + head * 64 + (col & 63)];
+    }
+    const int stride = at.smax <= 32 ? 128 : 96;                        // + round_up(smax, 32) = 160 staged rows
+    const int tile_end = m0 + BM < prm.M ? m0 + BM : prm.M;
+    // rows [row_a, row_b) of the tile -> their place in the fp32 qkv buffer (q | k | v blocks H apart); one wave, 256-byte runs
+    auto spill_rows = [&](int row_a, int row_b, int lo_r) {
+        for (int row = row_a; row < row_b; ++row) {
+            const float* src = T + (row - m0 - lo_r) * kAtLd;
+            float* dst = at.qkv + (int64_t)row * (3 * H) + head * 64;
+#pragma unroll
+            for (int part = 0; part < 3; ++part) dst[part * H + lane] = src[part * 64 + lane];
+        }
+    };
+    for (int lo_r = 0; lo_r < BM; lo_r += stride) {
+        if (m0 + lo_r >= prm.M) break;                                  // (workgroup-uniform: the ragged last tile)
+        // this pass's rows of the accumulators (+ bias: the operation order of the unfused epilogue) -> LDS, row-major
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int rb = wm * (32 * TM) + mi * 32;                    // first tile row of the 32-row block (wave-uniform)
+            if (rb >= lo_r && rb < lo_r + kAtRows) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        T[(rb - lo_r + acc_row32(r, lane)) * kAtLd + wn * 96 + ni * 32 + c] = acc[mi][ni][r] + bias[ni];
+            }
+        }
+        __syncthreads();
+        const int seq_lo = m0 + lo_r;
+        const int seq_hi = seq_lo + stride < tile_end ? seq_lo + stride : tile_end;
+        int s0 = 0;                                                     // first sequence that starts at or after seq_lo
+        {
+            int hi = at.b;
+            while (s0 < hi) { const int mid = (s0 + hi) >> 1; if (at.cu[mid] < seq_lo) s0 = mid + 1; else hi = mid; }
+        }
+        if (lo_r == 0 && wave == NW - 1) {                              // the part of a sequence that began in the previous tile
+            const int top_end = at.cu[s0] < tile_end ? at.cu[s0] : tile_end;
+            spill_rows(m0, top_end, lo_r);
+        }
+        for (int s = s0 + wave; s < at.b; s += NW) {
+            const int r0 = at.cu[s];
+            if (r0 >= seq_hi) break;
+            const int r1 = at.cu[s + 1];
+            if (r1 <= m0 + BM) {                                        // the whole sequence is in this tile (and in this pass's rows)
+                const float* qb = T + (r0 - seq_lo) * kAtLd;
+                const int S = r1 - r0;
+                for (int qt = 0; qt * 32 < S; ++qt)
+                    acattn::attention_tile<false, 64, false>(qb, qb + 64, qb + 128, kAtLd, S, qt, lane, at.scale, nullptr, nullptr, nullptr, -1,
+                                                      nullptr, H, at.ctx_planes, prm.M, r0, head * 64, AR == 2);
+            } else {
+                spill_rows(r0, tile_end, lo_r);                         // it continues in the next tile
+            }
+        }
+        __syncthreads();                                                // (the next pass overwrites the staging rows)
+    }
+}
+
 template <int EPI, int TM, int TN, int WMW, int WNW, int NS, bool C_PLANES, int PIPE, int AR = 3>
 __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>::WAVES_PER_SIMD)) void gemm_pipe_nt(PipeParams prm) {
     using G = PipeGeom<TM, TN, WMW, WNW, NS, AR>;
@@ -250,7 +334,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
                 int row = m0 + 32 * g + i32; if (row > prm.M - 1) row = prm.M - 1;
                 pp[t] = prm.Ap + p * a_plane + ((int64_t)kg * prm.a_rows + row) * 8;
             } else {
-                int row = n0 + 32 * (g - RA) + i32; if (row > prm.N - 1) row = prm.N - 1;
+                int row;
+                if constexpr (EPI == EPI_QKV_ATTN) {                    // column tile `bn` = head bn: its q rows, then its k rows, then its v rows
+                    const int gg = g - RA;
+                    row = (gg >> 1) * prm.at.H + bn * 64 + (gg & 1) * 32 + i32;
+                } else {
+                    row = n0 + 32 * (g - RA) + i32; if (row > prm.N - 1) row = prm.N - 1;
+                }
                 pp[t] = prm.Wp + p * w_plane + ((int64_t)kg * prm.w_rows + row) * 8;
             }
         }
@@ -393,6 +483,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
         __builtin_amdgcn_s_barrier();                                   // nobody's DMA may land in the epilogue's LDS scratch
         __builtin_amdgcn_sched_barrier(0);
         store_tile_ln<TM, TN, WMW, WNW, AR>(acc, lnres, prm, bm, bn, ntn, wm, wn, lane, tid, wave, reinterpret_cast<float*>(lds));
+    } else if constexpr (EPI == EPI_QKV_ATTN) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                                   // the ring becomes the attention's staging area
+        __builtin_amdgcn_sched_barrier(0);
+        qkv_attention_epilogue<TM, TN, WMW, WNW, AR>(acc, prm, bm, bn, wm, wn, lane, wave, reinterpret_cast<float*>(lds));
     } else if (C_PLANES) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                                   // nobody's DMA may land in the transpose scratch
@@ -424,6 +519,7 @@ int launch_one(PipeParams p, hipStream_t stream) {
     const int64_t tiles = (int64_t)((p.M + G::BM - 1) / G::BM) * ((p.N + G::BN - 1) / G::BN);
     constexpr int LN_BYTES = G::TR_BYTES + (WNW + 1) * G::BM * 8 + 16;                       // EPI_BIAS_RES_LN scratch
     const size_t lds = EPI == EPI_BIAS_RES_LN ? (size_t)(G::LDS_BYTES > LN_BYTES ? G::LDS_BYTES : LN_BYTES)
+                     : EPI == EPI_QKV_ATTN    ? (size_t)(G::LDS_BYTES > kAtBytes ? G::LDS_BYTES : kAtBytes)
                                               : (size_t)(G::LDS_BYTES > G::TR_BYTES || !CP ? G::LDS_BYTES : G::TR_BYTES);
     static std::atomic<unsigned long long> attr_set{0};                // (per instantiation and, inside, per device)
     if (ac::first_call_on_device(attr_set))
@@ -582,6 +678,33 @@ int launch_gemm_pipe(int cfg, const uint16_t* Ap, int64_t a_rows, const uint16_t
 }
 
 
+// ---- the QKV projection with the self-attention of the packed sequences in its epilogue (EPI_QKV_ATTN) ----
+static std::atomic<long long> g_qkv_attn_launches{0};
+bool qkv_attn_applies(int M, int H, int heads, int smax) {
+    if (const char* e = getenv("AC_QKV_ATTN_FUSION"); e && atoi(e) == 0) return false;      // (A/B runs and the two-launch route's tests)
+    return arith_split() && gemm_variant() == 0 && M >= 192 && heads >= 1 && H == heads * 64 && (H % 32) == 0 && H >= 64 &&
+           smax >= 1 && smax <= 64 && pipe_choose(M, 3 * H, H, EPI_BIAS, false) != 0;      // (a table that switches the ring kernels off)
+}
+int launch_gemm_pipe_qkv_attn(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias, int M, int H,
+                              int heads, const int32_t* cu, int b, int smax, float scale, uint16_t* ctx_planes, float* qkv,
+                              hipStream_t stream, int f16) {
+    AC_REQUIRE(qkv_attn_applies(M, H, heads, smax), AC_EUNSUPPORTED, "gemm_pipe: fused attention epilogue not applicable (M %d H %d heads %d longest %d)",
+               M, H, heads, smax);
+    AC_REQUIRE(Ap && Wp && bias && cu && ctx_planes && qkv && b >= 1, AC_EINVAL, "gemm_pipe_qkv_attn: null pointer");
+    PipeParams p;
+    p.Ap = Ap; p.a_rows = a_rows; p.Wp = Wp; p.w_rows = w_rows; p.C = qkv; p.ldc = 3 * (int64_t)H; p.M = M; p.N = 3 * H; p.K = H;
+    Epilogue e;
+    e.bias = bias; e.residual = nullptr; e.ldr = 0; e.act = ACT_NONE; e.alpha = 1.f; e.beta = 0.f; e.mask = nullptr;
+    e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;
+    p.epi = e;
+    p.ln = LnFuse{};
+    p.at.cu = cu; p.at.b = b; p.at.H = H; p.at.smax = smax; p.at.scale = scale; p.at.ctx_planes = ctx_planes; p.at.qkv = qkv;
+    p.stamps = nullptr;
+    g_qkv_attn_launches.fetch_add(1, std::memory_order_relaxed);
+    return f16 ? launch_one<EPI_QKV_ATTN, 2, 3, 4, 2, 4, false, 2, 2>(p, stream)
+               : launch_one<EPI_QKV_ATTN, 2, 3, 4, 2, 3, false, 2, 3>(p, stream);
+}
+
 // ---- bias + residual + LayerNorm fused into the N-wide GEMMs of an encoder layer (EPI_BIAS_RES_LN) ----
 constexpr int kLnCfg = 124262, kLnBM = 128, kLnBN = 128;     // the one tile the fused epilogue is built for
 static std::atomic<int> g_ln_fusion{-1};
@@ -638,6 +761,8 @@ extern "C" int ac_gemm_set_ln_fusion(int on) {
 }
 
 extern "C" int64_t ac_gemm_ln_fusion_launches(void) { return (int64_t)ac::g_ln_launches.load(std::memory_order_relaxed); }
+/* diagnostic (tests assert that the fused route really ran): launches of the QKV GEMM with the attention epilogue so far */
+extern "C" int64_t ac_gemm_qkv_attn_launches(void) { return (int64_t)ac::g_qkv_attn_launches.load(std::memory_order_relaxed); }
 
 static int parse_pipe_table(const char* spec, ac::PipeRule* rules, int* nrules) {
     if (!spec) { *nrules = -1; return AC_OK; }

@@ -265,6 +265,13 @@ int ac_gemm_set_pipe_table_f16(const char* spec);
  * 2 = on, with a starved exchange: every tile waits for an arrival that never comes (tests of the give-up path only). */
 int ac_gemm_set_ln_fusion(int on);
 int64_t ac_gemm_ln_fusion_launches(void);      /* fused launches of this process so far (tests: "did the fused path run") */
+/* The BERT encoder also folds the self-attention (modeling_bert.py:111-203) into the epilogue of the fused QKV projection when
+ * the batch's sequences lie row after row (packed, or unpacked without a mask), the head dimension is 64 and no sequence is
+ * longer than 64 tokens: an output tile is 256 token rows x one head's q | k | v, the sequences inside it are finished from LDS
+ * with the instructions of the stand-alone attention kernel (bit-identical context rows), and the fp32 [T, 3H] round trip plus
+ * the attention launch disappear (gemm_pipe.hip EPI_QKV_ATTN).  Env AC_QKV_ATTN_FUSION=0 keeps the two launches (A/B, tests).
+ * Diagnostic: launches of the fused form by this process so far. */
+int64_t ac_gemm_qkv_attn_launches(void);
 
 /* The persistent one-launch kernels of the latency-bound ends of the path are chosen automatically when the shape fits;
  * this switch (A/B tests, diagnosis) turns them off or on process-wide.  mask bit 0: ac_head_train_step / _epoch through

@@ -490,3 +490,59 @@ def test_per_call_options_do_not_leak_between_objects(cuda_dev):
     bad.gemm_arith_opt = 9
     need = ctypes.c_size_t(0)
     assert lib.ac_bert_workspace(ctypes.byref(bad), 4, 16, ctypes.byref(need)) != 0 and b"options" in lib.ac_last_error()
+
+
+@pytest.mark.parametrize("hidden,layers,heads,inter,b,S,ragged", [
+    (768, 3, 12, 3072, 200, 32, True),     # the bench's launch shape: ~4000 packed rows, 16 row tiles, straddling sequences
+    (768, 2, 12, 3072, 64, 32, False),     # every text at 32 tokens: unpacked, the mask is all ones (synthesised offsets), no straddler
+    (128, 3, 2, 512, 40, 16, True),        # two heads, ragged last row tile (T < 2 tiles)
+    (1024, 2, 16, 4096, 30, 24, True),     # bert-large width: 16 heads
+    (768, 2, 12, 3072, 24, 64, True),      # sequences of up to 64 tokens: three staging passes, two query tiles
+    (768, 2, 12, 3072, 30, 50, False),     # 50-token rows, unpacked: sequences straddle every tile boundary
+    (128, 2, 2, 512, 700, 8, True),        # many short sequences (2 .. 8 tokens): ~20 sequences per staging pass and wave rounds
+])
+@pytest.mark.parametrize("regime", REGIMES)
+def test_attention_fused_into_the_qkv_gemm_epilogue(hidden, layers, heads, inter, b, S, ragged, regime, cuda_dev, monkeypatch):
+    """Self-attention inside the QKV projection's epilogue (gemm_pipe.hip EPI_QKV_ATTN: a tile = 256 token rows x one head's
+    q | k | v, sequences finished from LDS, boundary-straddling sequences by attention_mfma_kernel's boundary mode): the fused
+    launches really run (counter), the CLS vectors are BIT-IDENTICAL to the two-launch route (same instructions on the same
+    values) and meet the 1e-4 bar against transformers in both attention regimes."""
+    from adaptive_classifier import _native as nv
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    vocab = 2000
+    model = bert_oracle.make_bert(hidden, layers, heads, inter, vocab=vocab, seed=5, **regime_kw(regime, hidden))
+    ids, types, mask = bert_oracle.synthetic_batch(b, S, vocab=vocab, seed=77, ragged=ragged)
+    want = bert_oracle.encode_cls(model, ids, types, mask)
+    enc = HipBertEncoder(model, device=cuda_dev)
+    lib = nv.lib()
+    monkeypatch.setenv("AC_QKV_ATTN_FUSION", "0")
+    n0 = lib.ac_gemm_qkv_attn_launches()
+    separate = enc.encode_cls(ids, types, mask).cpu()
+    assert lib.ac_gemm_qkv_attn_launches() == n0
+    monkeypatch.delenv("AC_QKV_ATTN_FUSION")
+    fused = enc.encode_cls(ids, types, mask).cpu()
+    assert lib.ac_gemm_qkv_attn_launches() == n0 + (layers - 1)                # every layer but the CLS-only last one
+    assert torch.equal(fused, separate), (fused - separate).abs().max().item()
+    assert (fused - want).abs().max().item() < 1e-4
+
+
+def test_attention_fusion_leaves_long_or_masked_batches_alone(cuda_dev):
+    """Sequences longer than 64 tokens, and an unpacked batch whose mask has holes (not a prefix: the padded route with its key
+    mask), keep the stand-alone attention launch."""
+    from adaptive_classifier import _native as nv
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_bert(128, 2, 2, 512, vocab=2000, seed=5)
+    enc = HipBertEncoder(model, device=cuda_dev)
+    lib = nv.lib()
+    ids, types, mask = bert_oracle.synthetic_batch(6, 80, vocab=2000, seed=3, ragged=True)
+    n0 = lib.ac_gemm_qkv_attn_launches()
+    got = enc.encode_cls(ids, types, mask).cpu()
+    assert lib.ac_gemm_qkv_attn_launches() == n0
+    assert (got - bert_oracle.encode_cls(model, ids, types, mask)).abs().max().item() < 1e-4
+    ids, types, mask = bert_oracle.synthetic_batch(40, 16, vocab=2000, seed=4, ragged=False)
+    mask[3, 5] = 0                                                             # a hole: not a right-padded mask
+    got = enc.encode_cls(ids, types, mask).cpu()
+    assert lib.ac_gemm_qkv_attn_launches() == n0
+    assert (got - bert_oracle.encode_cls(model, ids, types, mask)).abs().max().item() < 1e-4
