@@ -110,7 +110,18 @@ class AdaptiveClassifier:
         # "as_wired": reproduce the reference, whose EWC term in _train_new_classes is identically 0
         # (SURVEY fact 3).  "intended": penalise the live head against the pre-expansion head.
         self.ewc_mode = (config or {}).get("ewc_mode", "as_wired")
+        # Where the head's dropout masks come from while training.  "device" (default): counter-based, generated inside the
+        # training kernels from (classifier seed, add_examples call, step) -- no mask tensors, a whole epoch in one launch.
+        # "torch_cpu": REPLAY of the reference's CPU run -- the two masks of every step are drawn on the host exactly as
+        # nn.Dropout does there (`torch.empty(B, H).bernoulli_(1 - p)` on torch's global CPU generator, layer order), every other
+        # draw the reference makes from that generator is made too (the Fisher pass of its as-wired EWC: ewc.py:60-64, :81), and
+        # the steps run one by one through the explicit-mask kernels.  Same seeds => the reference's own training trajectory
+        # (tests/test_e2e_reference_gpu.py differences it: epochs, per-epoch loss, predictions); ~10x slower per step.
+        self.dropout_source = (config or {}).get("dropout_source", "device")
+        if self.dropout_source not in ("device", "torch_cpu"):
+            raise ValueError("config['dropout_source'] must be 'device' or 'torch_cpu', got %r" % (self.dropout_source,))
         self.last_train_info = {}
+        self.train_log = []             # one entry per head training run: {"kind", "epoch_losses", "steps"} (diagnostic)
 
     # ------------------------------------------------------------------------------ embeddings
     def _tokenize(self, texts: List[str]):
@@ -281,8 +292,25 @@ class AdaptiveClassifier:
         # reproducible per classifier seed, independent of later torch.manual_seed calls (AdaptiveHead.__init__ itself
         # reseeds torch's global generator to 42); the reference draws them from that global generator (not replayable)
         base_seed = (self._seed * 0x9E3779B97F4A7C15 + self.train_steps * 1000003) & 0x7FFFFFFFFFFFFFFF
+        replay = getattr(self, "dropout_source", "device") == "torch_cpu"
+        epoch_losses = []
         for epoch in range(epochs):
             trainer.loss_accum.zero_()
+            if replay:
+                done = self._replay_epoch(trainer, X, y, targets, epoch_order.next_epoch(), batch_size, ewc, lambda_B, loss_kind)
+                avg_loss = float(trainer.loss_accum.item()) / steps_per_epoch
+                steps += done
+                epoch_losses.append(avg_loss)
+                if sched is not None:
+                    sched.step(avg_loss)
+                    trainer.lr = dummy.param_groups[0]["lr"]
+                if avg_loss < best_loss:
+                    best_loss, patience_counter = avg_loss, 0
+                else:
+                    patience_counter += 1
+                    if patience_counter >= patience:
+                        break
+                continue
             # one H2D of the epoch's batch order (same order as the reference's seeded DataLoader); every batch
             # but the last has batch_size rows (drop_last=False): one native call runs the whole epoch
             order = epoch_order.next_epoch().to(X.device)
@@ -309,6 +337,7 @@ class AdaptiveClassifier:
                 done = run_epoch(stepwise=True)
                 avg_loss = float(trainer.loss_accum.item()) / steps_per_epoch
             steps += done
+            epoch_losses.append(avg_loss)
             if sched is not None:
                 sched.step(avg_loss)
                 trainer.lr = dummy.param_groups[0]["lr"]
@@ -320,12 +349,57 @@ class AdaptiveClassifier:
                     logger.debug(f"Early stopping at epoch {epoch + 1}")
                     break
         self.last_train_info = {"steps": steps, "epochs": epoch + 1, "final_loss": avg_loss}
+        self.train_log.append({"epoch_losses": epoch_losses, "steps": steps, "rows": int(n_rows)})
         if not math.isfinite(avg_loss):
             # (the reference would hand out NaN scores silently after a diverged training run; say so once, where it happened)
             logger.warning("head training ended with a non-finite loss after %d steps: the head's probabilities will be NaN "
                            "until the next add_examples() retrains it (non-finite embeddings are refused earlier, so this is a "
                            "diverged run or a defect)", steps)
         self.train_steps += 1
+
+    def _replay_epoch(self, trainer, X, y, targets, order, batch_size, ewc, lambda_B, loss_kind):
+        """One epoch of config['dropout_source'] == 'torch_cpu': the reference's step loop (classifier.py:1483-1507, :327-353)
+        with ITS dropout masks.  nn.Dropout on a CPU tensor is `noise = empty_like(x).bernoulli_(1 - p)` on the global generator
+        (aten/src/ATen/native/Dropout.cpp, the non-fused path), first for the [B, H1] activation, then for [B, H2]; the same two
+        calls here, in the same order, leave the generator where the reference's step leaves it.  The step itself is the
+        explicit-mask kernel pair (ac_head_fwd_bwd_ce / _loss + ac_ewc_adamw_step) whose single steps tests/golden/head_step.json
+        pins against the reference."""
+        from .training import LOSS_CE
+        n = X.shape[0]
+        p = AdaptiveHead.DROPOUT_P
+        H1, H2 = trainer.dims.H1, trainer.dims.H2
+        done = 0
+        for i0 in range(0, n, batch_size):
+            idx = order[i0:i0 + batch_size].to(X.device)
+            B = int(idx.numel())
+            m1 = torch.empty(B, H1).bernoulli_(1 - p).to(torch.uint8).to(X.device)
+            m2 = torch.empty(B, H2).bernoulli_(1 - p).to(torch.uint8).to(X.device)
+            Xb = X.index_select(0, idx)
+            yb = None if y is None else y.index_select(0, idx)
+            tb = None if targets is None else targets.index_select(0, idx)
+            if loss_kind == LOSS_CE and tb is None:
+                trainer.forward_backward(Xb, yb, m1, m2, p)
+            else:
+                trainer.forward_backward_loss(Xb, y=yb, targets=tb, loss_kind=loss_kind, mask1=m1, mask2=m2, dropout_p=p)
+            out = trainer.optimizer_step(None if ewc is None else ewc.fisher_flat, None if ewc is None else ewc.old_flat,
+                                         0.0 if ewc is None else lambda_B / B)
+            trainer.loss_accum += trainer.loss                       # (device side; one host sync per epoch as elsewhere)
+            if ewc is not None:
+                trainer.loss_accum += out[0:1]                       # the penalty is part of the reference's logged loss (:338-341)
+            done += 1
+        return done
+
+    @staticmethod
+    def _replay_fisher_rng(n_old, c_old):
+        """config['dropout_source'] == 'torch_cpu' in as-wired mode: the reference builds EWC(old_head, old_dataset) here
+        (classifier.py:273-300) although its penalty is identically zero, and that constructor's Fisher pass DRAWS from
+        torch's global generator: a DataLoader(batch_size=32, shuffle=True) without a generator of its own (base seed + the
+        sampler's seed, ewc.py:60-64) and one torch.multinomial(probs [B, C_old], 1) per batch (:81 -- an exponential_ over B x C
+        elements whatever the probabilities are).  The same objects and calls on a dummy dataset of the same length: the
+        generator ends where the reference's does, nothing else is computed."""
+        ds = torch.utils.data.TensorDataset(torch.zeros(n_old, 1), torch.zeros(n_old, dtype=torch.long))
+        for xb, _ in torch.utils.data.DataLoader(ds, batch_size=32, shuffle=True):
+            torch.multinomial(torch.full((xb.shape[0], c_old), 1.0 / c_old), 1)
 
     def _train_adaptive_head(self, epochs: int = 10):
         """classifier.py:1428-1522: retrain on everything stored, sorted by (label, text)."""
@@ -394,6 +468,11 @@ class AdaptiveClassifier:
                 ewc = self._expand_ewc(EWC(old_head, ds, device=self.device, ewc_lambda=5.0))
         # "as_wired": the reference's penalty is built on a frozen copy and is exactly 0 with no
         # gradient into the trained head, i.e. plain CE + AdamW -- which is what runs.
+        if ewc is None and old_head is not None and getattr(self, "dropout_source", "device") == "torch_cpu":
+            n_old = sum(min(5, len(ex)) for label, ex in self.memory.examples.items() if label not in new_classes)
+            c_old = sum(1 for label in self.id_to_label.values() if label not in new_classes)
+            if n_old:
+                self._replay_fisher_rng(n_old, c_old)     # the generator draws of the reference's (ineffective) Fisher pass
         self._run_epochs(X, y, batch_size=32, epochs=15, use_scheduler=False, ewc=ewc, lambda_B=5.0)
 
     def _expand_ewc(self, ewc):

@@ -26,6 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int crow32(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 __device__ __forceinline__ void rope_rotate(f32x4 (&x)[8], const float* cs, const float* sn, int pos, int h) {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         const f32x4 c = *reinterpret_cast<const f32x4*>(cs + (int64_t)pos * 32 + 8 * kb + 4 * h);
@@ -52,6 +53,9 @@ __device__ __forceinline__ void attention_tile(const float* qb, const float* kb_
                                                float scale, const int64_t* mask_row, const float* rope_cos, const float* rope_sin,
                                                int window, float* ctx_rows, int H, uint16_t* ctx_planes, int64_t rows, int64_t row0,
                                                int headcol, int f16) {
+    // No implicit mul + add fusion in here: whether hipcc contracts `l * corr + psum` or packs two of them into v_pk_fma_f32
+    // depends on the surrounding kernel, and the two routes must round alike (the one intended fma is written out).
+#pragma clang fp contract(off)
     static_assert(DHT == 64 || (DHT == 32 && !ROPE), "head dim 64, or 32 without RoPE");
     constexpr int NKB = DHT / 8;                                     // 8-dim k-blocks of the QK^T product
     const int j = lane & 31, h = lane >> 5;
@@ -124,7 +128,7 @@ __device__ __forceinline__ void attention_tile(const float* qb, const float* kb_
 #pragma unroll
         for (int r = 0; r < 16; ++r) { p[r] = none ? 0.f : expf(st[r] - m_new); psum += p[r]; }
         psum += __shfl_xor(psum, 32);
-        l = l * corr + psum;
+        l = __builtin_fmaf(l, corr, psum);
         m = m_new;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }

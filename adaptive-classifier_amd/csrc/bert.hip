@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 struct BertWs {
-    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, cu, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
+    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, cu, tile_seq, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
     size_t lnctl_bytes;
 };
 // cu of an UNPACKED batch without a mask (every sequence has S real tokens): what ac_bert_pack would have produced
@@ -399,8 +399,10 @@ BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     off += w.lnctl_bytes;
     w.lnpart = off;
     off += ac::align_up(ac::pipe_ln_part_bytes((int)T, c.hidden), 256);
-    w.cu = off;                       // sequence offsets of an unpacked, unmasked batch (fused attention epilogue)
+    w.cu = off;                       // sequence offsets of an unpacked, unmasked batch + the row tiles' first sequences (fused attention epilogue)
     off += ac::align_up((size_t)(b + 1) * sizeof(int32_t), 256);
+    w.tile_seq = off;
+    off += ac::align_up(ac::qkv_attn_tile_seq_bytes((int)T), 256);
     w.total = off;
     return w;
 }
@@ -493,6 +495,11 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         AC_LAUNCH_CHECK();
         cu_at = cuw;
     }
+    int32_t* tile_seq = (int32_t*)(base + ws.tile_seq);
+    if (fuse_attn) {
+        rc = ac::qkv_attn_tile_seq(cu_at, b, T, tile_seq, stream);
+        if (rc) return rc;
+    }
     for (int l = 0; l < c.layers; ++l) {
         const uint16_t* qkv_w3 = wplanes ? w->qkv_w3[l] : nullptr;
         const uint16_t* ao_w3 = wplanes ? w->ao_w3[l] : nullptr;
@@ -515,8 +522,8 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
             ldres = H;
         }
         if (fuse_attn && !last) {
-            rc = ac::launch_gemm_pipe_qkv_attn(xp, T, f16 ? w->qkv_wh[l] : qkv_w3, 3 * H, w->qkv_b[l], T, H, c.heads, cu_at, b, Smax, scale,
-                                               ctxp, qkv, stream, (int)f16);
+            rc = ac::launch_gemm_pipe_qkv_attn(xp, T, f16 ? w->qkv_wh[l] : qkv_w3, 3 * H, w->qkv_b[l], T, H, c.heads, cu_at, tile_seq, b, Smax,
+                                               scale, ctxp, qkv, stream, (int)f16);
             if (rc) return rc;
             // the sequences that straddle a 256-row tile boundary (their q | k | v rows are in qkv): one wave per boundary
             const int nbound = (T - 1) / ac::kQkvAttnRows;

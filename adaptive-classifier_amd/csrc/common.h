@@ -83,9 +83,11 @@ int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, 
 // which the caller then serves with attention_mfma_kernel's boundary mode (boundary_stride = kQkvAttnRows)
 constexpr int kQkvAttnRows = 256;
 bool qkv_attn_applies(int M, int H, int heads, int smax);
+size_t qkv_attn_tile_seq_bytes(int M);
+int qkv_attn_tile_seq(const int32_t* cu, int b, int M, int32_t* tile_seq, hipStream_t stream);     // once per forward (cu is the same for every layer)
 int launch_gemm_pipe_qkv_attn(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias, int M, int H,
-                              int heads, const int32_t* cu, int b, int smax, float scale, uint16_t* ctx_planes, float* qkv,
-                              hipStream_t stream, int f16 = 0);
+                              int heads, const int32_t* cu, const int32_t* tile_seq, int b, int smax, float scale, uint16_t* ctx_planes,
+                              float* qkv, hipStream_t stream, int f16 = 0);
 // true when linear_f32(M, N, K) with W planes takes the pre-split kernel (only then may A / C planes be passed)
 bool linear_takes_planes(int M, int N, int K);
 

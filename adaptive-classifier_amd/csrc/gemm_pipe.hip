@@ -230,7 +230,8 @@ __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float
 // tile, <= 20 sequences at 5141 rows) serves it afterwards.
 constexpr int kAtLd = 196;              // floats per staged row: 192 + 4 (row stride 784 B = 16 B mod 256: the 16 lanes of a b128 read hit distinct banks)
 constexpr int kAtRows = 160;            // staged rows per pass
-constexpr int kAtBytes = kAtRows * kAtLd * 4;
+constexpr int kAtCu = 264;              // the tile's sequence offsets (<= 257: sequences of >= 1 row starting inside 256 rows, + the end)
+constexpr int kAtBytes = kAtRows * kAtLd * 4 + kAtCu * 4;
 
 template <int TM, int TN, int WMW, int WNW, int AR>
 __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], const PipeParams& prm, int bm, int head, int wm, int wn,
@@ -247,6 +248,11 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
     }
     const int stride = at.smax <= 32 ? 128 : 96;                        // + round_up(smax, 32) = 160 staged rows
     const int tile_end = m0 + BM < prm.M ? m0 + BM : prm.M;
+    // the offsets of the sequences that start inside this tile (+ the one after them) -> LDS, ONE dependent global load for the
+    // whole epilogue (a binary search over cu in HBM / L2 per pass and two loads per sequence cost ~5 k cycles per tile)
+    int* cuL = reinterpret_cast<int*>(T + kAtRows * kAtLd);
+    const int sb = at.tile_seq[bm], se = at.tile_seq[bm + 1], nseq = se - sb;    // (wave-uniform)
+    for (int i = wave * 64 + lane; i <= nseq; i += NW * 64) cuL[i] = at.cu[sb + i];
     // rows [row_a, row_b) of the tile -> their place in the fp32 qkv buffer (q | k | v blocks H apart); one wave, 256-byte runs
     auto spill_rows = [&](int row_a, int row_b, int lo_r) {
         for (int row = row_a; row < row_b; ++row) {
@@ -273,19 +279,19 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
         __syncthreads();
         const int seq_lo = m0 + lo_r;
         const int seq_hi = seq_lo + stride < tile_end ? seq_lo + stride : tile_end;
-        int s0 = 0;                                                     // first sequence that starts at or after seq_lo
+        int s0 = 0;                                                     // first of the tile's sequences that starts at or after seq_lo
         {
-            int hi = at.b;
-            while (s0 < hi) { const int mid = (s0 + hi) >> 1; if (at.cu[mid] < seq_lo) s0 = mid + 1; else hi = mid; }
+            int hi = nseq;
+            while (s0 < hi) { const int mid = (s0 + hi) >> 1; if (cuL[mid] < seq_lo) s0 = mid + 1; else hi = mid; }
         }
         if (lo_r == 0 && wave == NW - 1) {                              // the part of a sequence that began in the previous tile
-            const int top_end = at.cu[s0] < tile_end ? at.cu[s0] : tile_end;
+            const int top_end = cuL[0] < tile_end ? cuL[0] : tile_end;  // (cuL[0] = cu[sb] >= m0; = T when no sequence starts at or after m0)
             spill_rows(m0, top_end, lo_r);
         }
-        for (int s = s0 + wave; s < at.b; s += NW) {
-            const int r0 = at.cu[s];
+        for (int s = s0 + wave; s < nseq; s += NW) {
+            const int r0 = cuL[s];
             if (r0 >= seq_hi) break;
-            const int r1 = at.cu[s + 1];
+            const int r1 = cuL[s + 1];
             if (r1 <= m0 + BM) {                                        // the whole sequence is in this tile (and in this pass's rows)
                 const float* qb = T + (r0 - seq_lo) * kAtLd;
                 const int S = r1 - r0;
@@ -685,12 +691,28 @@ bool qkv_attn_applies(int M, int H, int heads, int smax) {
     return arith_split() && gemm_variant() == 0 && M >= 192 && heads >= 1 && H == heads * 64 && (H % 32) == 0 && H >= 64 &&
            smax >= 1 && smax <= 64 && pipe_choose(M, 3 * H, H, EPI_BIAS, false) != 0;      // (a table that switches the ring kernels off)
 }
+// tile_seq[t] = the first sequence that starts at or after row 256 t, t = 0 .. ceil(T / 256) (the last entry = b): once per forward
+__global__ __launch_bounds__(64) void qkv_attn_tile_seq_kernel(const int32_t* __restrict__ cu, int b, int ntiles, int32_t* __restrict__ out) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t > ntiles) return;
+    const int row = t * kQkvAttnRows;
+    int lo = 0, hi = b;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cu[mid] < row) lo = mid + 1; else hi = mid; }
+    out[t] = t == ntiles ? b : lo;
+}
+size_t qkv_attn_tile_seq_bytes(int M) { return ((size_t)(M + kQkvAttnRows - 1) / kQkvAttnRows + 1) * sizeof(int32_t); }
+int qkv_attn_tile_seq(const int32_t* cu, int b, int M, int32_t* tile_seq, hipStream_t stream) {
+    const int ntiles = (M + kQkvAttnRows - 1) / kQkvAttnRows;
+    hipLaunchKernelGGL(qkv_attn_tile_seq_kernel, dim3((ntiles + 64) / 64), dim3(64), 0, stream, cu, b, ntiles, tile_seq);
+    AC_LAUNCH_CHECK();
+    return AC_OK;
+}
 int launch_gemm_pipe_qkv_attn(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias, int M, int H,
-                              int heads, const int32_t* cu, int b, int smax, float scale, uint16_t* ctx_planes, float* qkv,
-                              hipStream_t stream, int f16) {
+                              int heads, const int32_t* cu, const int32_t* tile_seq, int b, int smax, float scale, uint16_t* ctx_planes,
+                              float* qkv, hipStream_t stream, int f16) {
     AC_REQUIRE(qkv_attn_applies(M, H, heads, smax), AC_EUNSUPPORTED, "gemm_pipe: fused attention epilogue not applicable (M %d H %d heads %d longest %d)",
                M, H, heads, smax);
-    AC_REQUIRE(Ap && Wp && bias && cu && ctx_planes && qkv && b >= 1, AC_EINVAL, "gemm_pipe_qkv_attn: null pointer");
+    AC_REQUIRE(Ap && Wp && bias && cu && tile_seq && ctx_planes && qkv && b >= 1, AC_EINVAL, "gemm_pipe_qkv_attn: null pointer");
     PipeParams p;
     p.Ap = Ap; p.a_rows = a_rows; p.Wp = Wp; p.w_rows = w_rows; p.C = qkv; p.ldc = 3 * (int64_t)H; p.M = M; p.N = 3 * H; p.K = H;
     Epilogue e;
@@ -698,7 +720,8 @@ int launch_gemm_pipe_qkv_attn(const uint16_t* Ap, int64_t a_rows, const uint16_t
     e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;
     p.epi = e;
     p.ln = LnFuse{};
-    p.at.cu = cu; p.at.b = b; p.at.H = H; p.at.smax = smax; p.at.scale = scale; p.at.ctx_planes = ctx_planes; p.at.qkv = qkv;
+    p.at.cu = cu; p.at.tile_seq = tile_seq; p.at.b = b; p.at.H = H; p.at.smax = smax; p.at.scale = scale; p.at.ctx_planes = ctx_planes;
+    p.at.qkv = qkv;
     p.stamps = nullptr;
     g_qkv_attn_launches.fetch_add(1, std::memory_order_relaxed);
     return f16 ? launch_one<EPI_QKV_ATTN, 2, 3, 4, 2, 4, false, 2, 2>(p, stream)

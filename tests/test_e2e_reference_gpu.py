@@ -185,3 +185,64 @@ def test_multilabel_classifier_from_text_equals_the_reference(standin, cuda_dev)
     batch = clf.predict_multilabel_batch(ex["texts"])
     for i, t in enumerate(ex["texts"]):
         _same(batch[i], [tuple(p) for p in ex["multilabel_default"][i]], ("batched default", t))
+
+
+def _rng_hashes():
+    import hashlib
+    st = np.random.get_state()
+    return {"torch_cpu": hashlib.sha256(torch.get_rng_state().numpy().tobytes()).hexdigest(),
+            "numpy": hashlib.sha256(st[1].tobytes() + str(st[2:]).encode()).hexdigest()}
+
+
+@pytest.mark.parametrize("case", ["bert_mini", "bert_base"])
+def test_training_trajectory_replays_the_reference_from_text(standin, cuda_dev, case):
+    """The TRAINING differential: `add_examples` -> the product's OWN trained head -> `predict`, differenced
+    against the unmodified reference's CPU run from the same texts and seeds (tests/golden/gen_e2e_train.py; reference
+    classifier.py:1428-1522 `_train_adaptive_head`, :202-367 `_train_new_classes`, ewc.py:39-94).  With
+    config={"dropout_source": "torch_cpu"} the product draws every dropout mask -- and every other draw the reference makes from
+    torch's global generator and numpy's -- as the reference does, so the two runs see the same masks, batches and samples:
+    same number of steps (= same early-stopping epoch), per-epoch average loss within 1e-4 relative, both generators left in the
+    reference's final state after each call, and from the product's own head identical label order with |dscore| <= 1e-3 on every
+    fixture text.  No head trained by the reference is loaded anywhere in this test.  `bert_base` is the 12 x 768 architecture
+    (device WordPiece -> packed 768-d encoder -> 768-d kNN -> 768 -> 768 -> 384 head -> blend, three batches per epoch)."""
+    from adaptive_classifier import AdaptiveClassifier
+    ex = json.load(open(os.path.join(GOLD, "e2e_train_%s.json" % case)))
+    torch.manual_seed(0)
+    np.random.seed(0)
+    clf = AdaptiveClassifier(ex["model_name"], device="cuda:0", config={"dropout_source": "torch_cpu"})
+    texts = ex["texts"]
+    assert len(texts) >= (24 if case == "bert_mini" else 20)
+    worst_score = worst_loss = 0.0
+    for ci, (part, call) in enumerate(zip(("train_1", "train_2"), ex["calls"])):
+        n_logs = len(clf.train_log)
+        clf.add_examples([t for t, _ in ex[part]], [l for _, l in ex[part]])
+        assert clf.label_to_id == call["label_to_id"]
+        assert {l: len(v) for l, v in clf.memory.examples.items()} == call["examples_per_class"]
+        log = clf.train_log[n_logs:]
+        assert len(log) == 1
+        want_steps = call["step_losses"]
+        assert log[0]["steps"] == len(want_steps), (part, log[0]["steps"], len(want_steps))          # same early-stopping epoch
+        n_ep = len(log[0]["epoch_losses"])
+        per = len(want_steps) // n_ep
+        assert per * n_ep == len(want_steps) and per == -(-log[0]["rows"] // 32)
+        for e, got in enumerate(log[0]["epoch_losses"]):
+            want = sum(want_steps[e * per:(e + 1) * per]) / per
+            worst_loss = max(worst_loss, abs(got - want) / abs(want))
+            assert abs(got - want) <= 1e-4 * abs(want), (part, e, got, want)
+        assert _rng_hashes() == call["rng_after"], (part, "a generator is not where the reference left it")
+        k_all = len(clf.label_to_id)
+        got_b = clf.predict_batch(texts, k=3)
+        for i, t in enumerate(texts):
+            for got, want, what in ((clf.predict(t, k=k_all), call["predict_all"][i], "predict"), (got_b[i], call["predict_batch_k3"][i], "predict_batch")):
+                assert [l for l, _ in got] == [l for l, _ in want], (part, what, t, got, want)
+                d = max(abs(a - b) for (_, a), (_, b) in zip(got, want))
+                worst_score = max(worst_score, d)
+                assert d <= 1e-3, (part, what, t, d, got, want)
+    print("training differential %s: %d + %d steps, worst relative epoch-loss difference %.2e, worst |dscore| %.2e over %d texts x 2 calls x 2 "
+          "entry points" % (case, len(ex["calls"][0]["step_losses"]), len(ex["calls"][1]["step_losses"]), worst_loss, worst_score, len(texts)))
+
+
+def test_unknown_dropout_source_is_refused(standin, cuda_dev):
+    from adaptive_classifier import AdaptiveClassifier
+    with pytest.raises(ValueError, match="dropout_source"):
+        AdaptiveClassifier("standin/bert-mini-4l", device="cuda:0", config={"dropout_source": "gpu"})
