@@ -337,21 +337,23 @@ def cpu_baseline(hf, clf, rows_dev, sample=2048, chunk=64):
                         "faiss is not installable here)"}}
 
 
-def cpu_baseline_reference(ids, mask, rows_dev, seconds_hint=20.0):
-    """`cpu_baseline` with kind "reference": the UNMODIFIED reference package (staged byte for byte by oracle/stage_ref.py into
-    oracle/_ref/ref_ac: classifier.py, memory.py, models.py ...; sha256 in MANIFEST.json) running ITS `predict_batch`
-    (classifier.py:1308-1388) on the host cores over the configs[1] workload: bert-base architecture (random init, through the
-    offline Hub stand-in), the same 100k x 768 rows in its faiss index (row -> class map = its own `index_to_label`), its own
-    AdaptiveHead, k = 16, batch_size = 256, texts whose tokenisation is exactly the bench's synthetic token ids.
-    `faiss` cannot be installed offline; the stand-in installed here scans the store in fp32 with the C oracle on ONE thread per
-    query -- what faiss's IndexFlat does for nq = 1 (exhaustive_L2sqr_seq parallelises over queries only), and nq = 1 is what
-    the reference's loop asks for (classifier.py:1329-1334 -> memory.py:114).  Returns None when oracle/_ref is not staged."""
+import contextlib
+
+
+@contextlib.contextmanager
+def staged_reference():
+    """The UNMODIFIED reference package (oracle/_ref/ref_ac, staged byte for byte by oracle/stage_ref.py, sha256-checked here on
+    every use) importable as `ref_ac`, with the two things that cannot exist offline stood in for: the Hub (oracle/hub_standin.py)
+    and faiss -- an IndexFlatL2 with the protocol memory.py uses, on the C oracle's fp32 scan, ONE thread per single-query search
+    (what faiss's IndexFlat does for nq = 1: exhaustive_L2sqr_seq parallelises over queries only, and nq = 1 is what the reference's
+    loops ask for, classifier.py:1329-1334 -> memory.py:114).  Yields (ref_ac, cores) or None when oracle/_ref is not staged."""
     import hashlib
     import types
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     man_path = os.path.join(ref_dir, "MANIFEST.json")
     if not os.path.exists(os.path.join(ref_dir, "ref_ac", "classifier.py")) or not os.path.exists(man_path):
-        return None
+        yield None
+        return
     man = json.load(open(man_path))
     for rel, ent in man.items():                       # byte-identical to the reference tree it was staged from
         if hashlib.sha256(open(os.path.join(ref_dir, rel), "rb").read()).hexdigest() != ent["sha256"]:
@@ -389,6 +391,34 @@ def cpu_baseline_reference(ids, mask, rows_dev, seconds_hint=20.0):
     try:
         import ref_ac
         assert os.path.realpath(ref_ac.__file__).startswith(os.path.realpath(ref_dir))
+        yield ref_ac, cores
+    finally:
+        sys.path.remove(ref_dir)
+        c_oracle.set_threads(cores)
+        if saved_faiss is None:
+            sys.modules.pop("faiss", None)
+        else:
+            sys.modules["faiss"] = saved_faiss
+        hub_standin.uninstall()
+
+
+REF_NOTES = {"hub": "oracle/hub_standin.py: bert-base-uncased ARCHITECTURE, seeded random init, synthetic WordPiece vocabulary "
+                    "(texts tokenise to the bench's token ids)",
+             "faiss": "NOT real faiss (not installable offline): IndexFlatL2 stand-in on oracle/knn_oracle.c's fp32 scan, one "
+                      "thread per single-query search as faiss's IndexFlat does for nq = 1"}
+
+
+def cpu_baseline_reference(ids, mask, rows_dev, seconds_hint=20.0):
+    """`cpu_baseline` with kind "reference": the UNMODIFIED reference package (staged_reference above) running ITS `predict_batch`
+    (classifier.py:1308-1388) on the host cores over the configs[1] workload: bert-base architecture (random init, through the
+    offline Hub stand-in), the same 100k x 768 rows in its faiss index (row -> class map = its own `index_to_label`), its own
+    AdaptiveHead, k = 16, batch_size = 256, texts whose tokenisation is exactly the bench's synthetic token ids.
+    Returns None when oracle/_ref is not staged."""
+    from oracle import hub_standin
+    with staged_reference() as env:
+        if env is None:
+            return None
+        ref_ac, cores = env
         clf = ref_ac.AdaptiveClassifier("bert-base-uncased", device="cpu", use_onnx=False)
         labels = [f"c{i}" for i in range(NCLASS)]
         clf.label_to_id = {l: i for i, l in enumerate(labels)}
@@ -418,23 +448,62 @@ def cpu_baseline_reference(ids, mask, rows_dev, seconds_hint=20.0):
         for e in emb[:32]:
             clf.memory.get_nearest_prototypes(e, k=KNN_K)
         t_knn = (time.perf_counter() - t1) / 32
-        return {"value": BATCH / dt, "unit": "queries/s", "cores": int(cores), "kind": "reference",
+        return {"value": BATCH / dt, "unit": "queries/s", "cores": int(cores), "kind": "reference", "gc_frozen": __import__("gc").get_freeze_count() > 0,
                 "sample": "%d x predict_batch(256 texts, k=%d, batch_size=256) of the unmodified reference (oracle/_ref/ref_ac = "
                           "/root/reference/src/adaptive_classifier, sha256-checked): tokenizer -> BertModel fp32 on torch CPU (%d "
                           "threads) -> per query get_nearest_prototypes over %d x %d rows -> head -> blend" % (n, KNN_K, cores, P.shape[0], DIM),
-                "seconds_per_batch": dt, "encode_s_per_batch": t_enc, "knn_ms_per_query": t_knn * 1e3,
-                "hub": "oracle/hub_standin.py: bert-base-uncased ARCHITECTURE, seeded random init, synthetic WordPiece vocabulary "
-                       "(texts tokenise to the bench's token ids)",
-                "faiss": "NOT real faiss (not installable offline): IndexFlatL2 stand-in on oracle/knn_oracle.c's fp32 scan, one "
-                         "thread per single-query search as faiss's IndexFlat does for nq = 1"}
-    finally:
-        sys.path.remove(ref_dir)
-        c_oracle.set_threads(cores)
-        if saved_faiss is None:
-            sys.modules.pop("faiss", None)
-        else:
-            sys.modules["faiss"] = saved_faiss
-        hub_standin.uninstall()
+                "seconds_per_batch": dt, "encode_s_per_batch": t_enc, "knn_ms_per_query": t_knn * 1e3, **REF_NOTES}
+
+
+def cpu_baseline_add_examples_reference(E, n_classes, cap=1000, seconds_hint=15.0):
+    """configs[3]'s `cpu_baseline` with kind "reference": the UNMODIFIED reference's `add_examples` (classifier.py:132-200) on the
+    host cores, fed the workload's pre-computed embeddings -- its `_get_embeddings` (the encoder call the product's
+    `add_embeddings` loop does not contain either) is replaced ON THE INSTANCE by a lookup into the same embedding table, nothing
+    else: label maps, `memory.add_example` per example (prototype update, prune at the cap), `_train_adaptive_head`
+    (:1428-1522: DataLoader, dropout, CE, backward, clip, AdamW, ReduceLROnPlateau, early stopping) on everything stored, index
+    rebuild.  BOUNDED SAMPLE: a 50 000-example run spends 92 % of its calls with the memory at the cap, where one reference call
+    retrains on 4000 examples (seconds); so the memory is first filled to the cap through the reference's own
+    `memory.add_example` (untimed) + one untimed call, then whole `add_examples` calls of 32 are timed for ~seconds_hint."""
+    with staged_reference() as env:
+        if env is None:
+            return None
+        ref_ac, cores = env
+        torch.manual_seed(0)
+        clf = ref_ac.AdaptiveClassifier("bert-base-uncased", device="cpu", use_onnx=False, config={"max_examples_per_class": cap})
+        clf.model = None                                                    # (the encoder is not part of this loop)
+        table = E.float().cpu()
+        clf._get_embeddings = lambda texts: [table[int(t[1:])] for t in texts]
+        labels = [f"c{i}" for i in range(n_classes)]
+        for i, l in enumerate(labels):
+            clf.label_to_id[l] = i
+            clf.id_to_label[i] = l
+        n_fill = cap * n_classes
+        for i in range(n_fill):                                             # untimed: the reference's own bookkeeping up to the cap
+            clf.memory.add_example(ref_ac.Example(f"t{i}", labels[i % n_classes], table[i]), labels[i % n_classes])
+            clf.training_history[labels[i % n_classes]] = clf.training_history.get(labels[i % n_classes], 0) + 1
+        pos = n_fill
+
+        def one_call():
+            nonlocal pos
+            idx = list(range(pos, pos + 32))
+            pos += 32
+            t = time.perf_counter()
+            clf.add_examples([f"t{i}" for i in idx], [labels[i % n_classes] for i in idx])
+            return time.perf_counter() - t
+        one_call()                                                           # untimed warm-up (builds the head, thread pools)
+        times = []
+        while not times or (sum(times) < seconds_hint and len(times) < 8):
+            times.append(one_call())
+        dt = sum(times) / len(times)
+        stored = sum(len(v) for v in clf.memory.examples.values())
+        return {"value": 32.0 / dt, "unit": "examples/s", "cores": int(cores), "kind": "reference", "gc_frozen": __import__("gc").get_freeze_count() > 0,
+                "seconds_per_call": dt, "calls_timed": len(times), "stored_examples": stored,
+                "sample": "%d x add_examples(32 examples) of the unmodified reference (oracle/_ref/ref_ac, sha256-checked; its "
+                          "_get_embeddings replaced on the instance by a lookup into the workload's embedding table, as the product's "
+                          "add_embeddings loop has no encoder call either) with its memory at the %d-per-class cap (%d stored): "
+                          "memory.add_example x 32 -> _train_adaptive_head on everything stored (torch CPU, %d threads) -> "
+                          "_rebuild_index" % (len(times), cap, stored, cores),
+                "faiss": REF_NOTES["faiss"]}
 
 
 def shader_clock_between(a, b):
@@ -660,7 +729,7 @@ def measure_cfg4(dev, args, steps=None, warmup=None, parity_queries=16):
         "parity": parity, "value_f16x2_opt_in": f16, "value_sustained": sus}
 
 
-def measure_add_examples(dev, args, n=None, modes=("as_wired", "intended"), with_cpu=None):
+def measure_add_examples(dev, args, n=None, modes=("as_wired", "intended"), with_cpu=None, with_cpu_reference=False):
     """BASELINE configs[3]: the add_examples() continuous-learning loop on one GPU.  50 000 pre-computed unit-norm 768-d
     embeddings (class centroid + 0.5 noise, 4 classes) fed in chunks of 32 through add_embeddings (= add_examples after
     the encoder call), max_examples_per_class = 1000; every call updates the memory (device prune), retrains the head on
@@ -741,6 +810,13 @@ def measure_add_examples(dev, args, n=None, modes=("as_wired", "intended"), with
         cpu = {"value": nst / dtc * (n / max(1, headline["train_steps"])), "unit": "examples/s", "cores": int(torch.get_num_threads()), "kind": "port",
                "steps_per_s": nst / dtc, "sample": f"{nst} reference training steps (batch 32, torch CPU) in {dtc:.1f} s; value = steps/s x "
                f"examples per training step of the GPU run ({n}/{headline['train_steps']}), memory bookkeeping not charged"}
+    # ... and the unmodified reference's own add_examples loop (kind "reference"), when oracle/_ref is staged: that is `cpu_baseline`,
+    # the port above stays beside it
+    cpu_port = None
+    if with_cpu or with_cpu_reference:
+        ref = _guarded("add_examples cpu_baseline (reference)", cpu_baseline_add_examples_reference, E, C)
+        if ref is not None and "error" not in ref:
+            cpu, cpu_port = ref, cpu
     return {
         "metric": "add_examples() examples/sec (continuous-learning loop)", "value": headline["examples_per_s"], "unit": "examples/s",
         "n_gpus": 1, "steps": headline["train_steps"], "warmup": 0, "ms_per_step": headline["seconds"] / max(1, headline["train_steps"]) * 1e3,
@@ -754,7 +830,7 @@ def measure_add_examples(dev, args, n=None, modes=("as_wired", "intended"), with
         "roofline": {"bound": "latency", "achieved": headline["steps_per_s"], "unit": "training steps/s", "peak": None, "frac": None,
                      "note": "the step is a chain of dependent phases (3 grid barriers + 3 dependent cross-CU reads per step, ~28 us); "
                              "its algorithmic traffic (36 B/param = 32 MB/step) would take 4 us at the HBM peak and never leaves LDS here"},
-        "cpu_baseline": cpu,
+        "cpu_baseline": cpu, "cpu_baseline_port": cpu_port,
         "modes": out}
 
 
@@ -1328,11 +1404,12 @@ def main():
         c4 = measure_cfg4(dev, args, steps=5, warmup=2, parity_queries=8)
         line["cfg4"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "steps", "stages_ms", "roofline_encoder", "parity", "config",
                                                "value_f16x2_opt_in", "value_sustained")}
-        ae = measure_add_examples(dev, args, n=6000, modes=("as_wired",), with_cpu=False)
+        # BASELINE configs[3] at its stated size (50 000 examples, ~25 s) with the unmodified reference's loop timed beside it
+        ae = measure_add_examples(dev, args, n=50_000, modes=("as_wired",), with_cpu=False, with_cpu_reference=not args.no_cpu_baseline)
         m = ae["modes"]["as_wired"]
         line["add_examples"] = {"value": ae["value"], "unit": ae["unit"], "examples": m["examples"], "train_steps": m["train_steps"],
                                 "steps_per_s": m["steps_per_s"], "host_seconds_by_phase": m["host_seconds_by_phase"],
-                                "accuracy_5way": m["accuracy_5way"], "config": ae["config"]}
+                                "accuracy_5way": m["accuracy_5way"], "cpu_baseline": ae["cpu_baseline"], "config": ae["config"]}
         line["add_examples_with_encoder"] = _guarded("add_examples_with_encoder", measure_add_examples_text, dev, args, n=6000)
     print(json.dumps(line), flush=True)
 

@@ -33,3 +33,18 @@ def test_reference_cpu_baseline_runs_on_a_small_instance(monkeypatch):
     # a failing extra never costs the line
     out = bench._guarded("x", lambda: 1 / 0)
     assert "error" in out and "ZeroDivisionError" in out["error"]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_ac", "classifier.py")), reason="oracle/_ref not staged")
+def test_add_examples_reference_baseline_runs_the_staged_reference_loop():
+    """configs[3]'s cpu_baseline (kind "reference"): the unmodified reference's add_examples on pre-computed embeddings, memory at
+    the cap -- here with a cap of 40 per class so the CPU suite stays short; the stand-ins are removed again afterwards."""
+    import sys
+    import torch
+    import bench
+    g = torch.Generator().manual_seed(0)
+    E = torch.nn.functional.normalize(torch.randn(400, 768, generator=g), dim=1)
+    out = bench.cpu_baseline_add_examples_reference(E, 4, cap=40, seconds_hint=1.0)
+    assert out["kind"] == "reference" and out["unit"] == "examples/s" and out["value"] > 0 and out["cores"] >= 1
+    assert out["stored_examples"] == 160 and out["calls_timed"] >= 1
+    assert "ref_ac" in sys.modules and "oracle/_ref" in (sys.modules["ref_ac"].__file__ or "")

@@ -201,9 +201,9 @@ def test_training_trajectory_replays_the_reference_from_text(standin, cuda_dev, 
     classifier.py:1428-1522 `_train_adaptive_head`, :202-367 `_train_new_classes`, ewc.py:39-94).  With
     config={"dropout_source": "torch_cpu"} the product draws every dropout mask -- and every other draw the reference makes from
     torch's global generator and numpy's -- as the reference does, so the two runs see the same masks, batches and samples:
-    same number of steps (= same early-stopping epoch), per-epoch average loss within 1e-4 relative, both generators left in the
-    reference's final state after each call, and from the product's own head identical label order with |dscore| <= 1e-3 on every
-    fixture text.  No head trained by the reference is loaded anywhere in this test.  `bert_base` is the 12 x 768 architecture
+    same number of steps (= same early-stopping epoch), per-epoch average loss within 1e-5 relative (the verdict's bar: 1e-4; first
+    run on MI355X: 7e-7), both generators left in the reference's final state after each call, and from the product's own head
+    identical label order with |dscore| <= 1e-5 on every fixture text (bar: 1e-3; first run: 4e-7).  No head trained by the reference is loaded anywhere in this test.  `bert_base` is the 12 x 768 architecture
     (device WordPiece -> packed 768-d encoder -> 768-d kNN -> 768 -> 768 -> 384 head -> blend, three batches per epoch)."""
     from adaptive_classifier import AdaptiveClassifier
     ex = json.load(open(os.path.join(GOLD, "e2e_train_%s.json" % case)))
@@ -228,7 +228,7 @@ def test_training_trajectory_replays_the_reference_from_text(standin, cuda_dev, 
         for e, got in enumerate(log[0]["epoch_losses"]):
             want = sum(want_steps[e * per:(e + 1) * per]) / per
             worst_loss = max(worst_loss, abs(got - want) / abs(want))
-            assert abs(got - want) <= 1e-4 * abs(want), (part, e, got, want)
+            assert abs(got - want) <= 1e-5 * abs(want), (part, e, got, want)
         assert _rng_hashes() == call["rng_after"], (part, "a generator is not where the reference left it")
         k_all = len(clf.label_to_id)
         got_b = clf.predict_batch(texts, k=3)
@@ -237,7 +237,7 @@ def test_training_trajectory_replays_the_reference_from_text(standin, cuda_dev, 
                 assert [l for l, _ in got] == [l for l, _ in want], (part, what, t, got, want)
                 d = max(abs(a - b) for (_, a), (_, b) in zip(got, want))
                 worst_score = max(worst_score, d)
-                assert d <= 1e-3, (part, what, t, d, got, want)
+                assert d <= 1e-5, (part, what, t, d, got, want)
     print("training differential %s: %d + %d steps, worst relative epoch-loss difference %.2e, worst |dscore| %.2e over %d texts x 2 calls x 2 "
           "entry points" % (case, len(ex["calls"][0]["step_losses"]), len(ex["calls"][1]["step_losses"]), worst_loss, worst_score, len(texts)))
 
