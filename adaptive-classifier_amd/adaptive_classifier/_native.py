@@ -84,6 +84,8 @@ _SIGNATURES = {
     "ac_last_error": (ctypes.c_char_p, []),
     "ac_version": (c_int, []),
     "ac_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_size_t)]),
+    "ac_device_cus": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "ac_persistent_launches": (c_int, [ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "ac_knn_l2_topk_workspace": (c_int, [c_int64, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "ac_knn_l2_topk": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64,
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -616,13 +616,12 @@ class AdaptiveClassifier:
                                  "(device shared or CU-masked?); the fusion is now off for this encoder -- repeat the call")
 
     def _ln_fusion_off(self):
-        """LayerNorm fusion off for this classifier's encoder (per object; a user-supplied encoder without the option falls back to
-        the process-wide switch)."""
+        """LayerNorm fusion off for this classifier's encoder -- per object, always: the process-wide switches of the ABI are test
+        hooks (include/acamd.h) and are never touched by the product.  (An encoder object without the option is not one of the
+        native encoders and runs no such kernel.)"""
         off = getattr(self.model, "disable_ln_fusion", None)
         if off is not None:
             off()
-        else:
-            nv.check(nv.lib().ac_gemm_set_ln_fusion(0), "ac_gemm_set_ln_fusion")
 
     def predict(self, text: str, k: int = 5) -> List[Tuple[str, float]]:
         if not text:

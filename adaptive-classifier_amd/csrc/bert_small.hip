@@ -24,6 +24,8 @@
 
 #include <math.h>
 
+#include <atomic>
+
 namespace {
 
 using namespace acp;
@@ -457,6 +459,10 @@ size_t small_act_floats(int H, int I) { return (size_t)kTok * ((size_t)8 * H + 3
 
 namespace ac {
 
+static std::atomic<long long> g_small_launches{0};
+long long bert_small_launches() { return g_small_launches.load(std::memory_order_relaxed); }
+
+
 size_t bert_small_ws_bytes(int H, int I) {
     return align_up(small_act_floats(H, I) * sizeof(float), 256) + align_up(sizeof(GridCtl), 256) + (3 * kMaxLayers * 12 + 16) * sizeof(unsigned long long);
 }
@@ -497,6 +503,15 @@ int bert_small_encode(const ac_bert_config& c, const ac_bert_weights& w, const i
     // with another compute process; a plain launch then has the same residency as a cooperative one and saves its ~30 us of
     // launch overhead -- 5 % of a single-query predict().  AC_BERT_SMALL_COOP=1 asks for the checked cooperative launch; a
     // barrier that cannot complete gives up after a bounded spin and poisons the output with NaNs.
+    // residency proof at launch (replaces "discover it by a barrier that gives up"): workgroups per CU (occupancy query) x the
+    // CUs this process's workgroups reach (dev_info().cus, measured: a CU mask counts) must hold the grid; otherwise the
+    // layer-by-layer path runs, chosen up front
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kT, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        if ((int64_t)per_cu * dev_info().cus < G) return 1;
+    }
+    g_small_launches.fetch_add(1, std::memory_order_relaxed);
     static const int coop = [] { const char* e = getenv("AC_BERT_SMALL_COOP"); return e ? atoi(e) : 0; }();
     if (coop) {
         void* args[] = {&p};

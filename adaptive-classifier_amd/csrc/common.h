@@ -13,11 +13,26 @@ namespace ac {
 void set_error(const char* fmt, ...);
 
 struct DevInfo {
-    int cus;
+    int cus;             // CUs this process's workgroups can land on (measured once per device: common.hip; <= hw_cus under a CU mask)
     int lds_per_block;   // max dynamic+static LDS per workgroup (bytes)
     size_t hbm_bytes;
+    int hw_cus;          // the chip's CU count (hipDeviceProp.multiProcessorCount)
 };
 const DevInfo& dev_info();   // lazily queried for the current device
+
+// The process-wide switches of the ABI (ac_gemm_set_arith / _variant / _pipe_table / _krot / _ln_fusion, ac_set_persistent_kernels,
+// ac_gemm_debug_stamps) are TEST HOOKS: they exist for tests, A/B runs and tools, and do nothing in a process that has not asked
+// for them with AC_TEST_HOOKS=1 in its environment at load time (they return AC_EUNSUPPORTED).  A production process therefore has
+// no mutable global state besides the per-thread error string; what a call computes is decided by its arguments
+// (ac_bert_config.*_opt) and by the read-once configuration variables (AC_GEMM_ARITH, AC_LN_FUSION, ...).
+bool test_hooks_enabled();
+#define AC_TEST_HOOK_ONLY(name)                                                                                                   \
+    do {                                                                                                                          \
+        if (!ac::test_hooks_enabled()) {                                                                                          \
+            ac::set_error(name ": process-wide switches are test hooks; this process did not enable them (AC_TEST_HOOKS=1)");    \
+            return AC_EUNSUPPORTED;                                                                                               \
+        }                                                                                                                         \
+    } while (0)
 
 // One-time-per-DEVICE work on a latency-critical launch path (function attributes such as the dynamic-LDS opt-in are per
 // device; a plain `static bool` would skip them on a process's second GPU).  `done` = a static std::atomic<uint64_t> of the call
@@ -275,6 +290,8 @@ int head_epoch_persistent(const ac_head_dims& d, float* P, float* M, float* V, f
                           float lam_direct, float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step0,
                           float* out, float* loss_accum, void* ws, hipStream_t stream);
 
+long long head_epoch_launches();       // persistent launches so far (diagnostic: ac_persistent_launches)
+long long bert_small_launches();
 // bert_small.hip: BERT forward of <= 32 token rows in one persistent launch.  AC_OK, 1 (shape not covered) or an error.
 size_t bert_small_ws_bytes(int H, int I);
 int bert_small_encode(const ac_bert_config& c, const ac_bert_weights& w, const int64_t* ids, const int64_t* type_ids,

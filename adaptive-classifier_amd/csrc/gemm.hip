@@ -992,12 +992,14 @@ extern "C" int ac_gemm_f32(int transA, int transB, int M, int N, int K, float al
 }
 
 extern "C" int ac_gemm_set_arith(int mode) {
+    AC_TEST_HOOK_ONLY("ac_gemm_set_arith");
     AC_REQUIRE(mode == AC_GEMM_F32 || mode == AC_GEMM_BF16X3 || mode == AC_GEMM_F16X2, AC_EINVAL, "gemm arith: unknown mode %d", mode);
     ac::set_gemm_arith(mode);
     return AC_OK;
 }
 extern "C" int ac_gemm_get_arith(void) { return ac::gemm_arith(); }
 extern "C" int ac_gemm_set_variant(int v) {
+    AC_TEST_HOOK_ONLY("ac_gemm_set_variant");
     AC_REQUIRE(v == 0 || v == 1 || v >= 1000, AC_EINVAL, "gemm variant: unknown value %d", v);
     ac::g_gemm_variant.store(v, std::memory_order_relaxed);
     return AC_OK;

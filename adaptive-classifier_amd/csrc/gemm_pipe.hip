@@ -573,8 +573,13 @@ int launch_cfg(int cls, bool cp, const PipeParams& p, hipStream_t stream) {
 /* diagnostic: the ring-staged GEMM kernels write 4 shader-clock stamps per workgroup (start, ring filled, loop done, stores
  * drained) into d_buf[4 * workgroup] while d_buf is set and holds the grid (tools/gemm_bench.hip); null switches it off. */
 /* experiment switch: 1 = the XCDs start their k-loops at different stages; 0 (default) = all at stage 0 */
-extern "C" int ac_gemm_set_krot(int on) { g_krot.store(on ? 1 : 0, std::memory_order_relaxed); return AC_OK; }
+extern "C" int ac_gemm_set_krot(int on) {
+    AC_TEST_HOOK_ONLY("ac_gemm_set_krot");
+    g_krot.store(on ? 1 : 0, std::memory_order_relaxed);
+    return AC_OK;
+}
 extern "C" int ac_gemm_debug_stamps(unsigned long long* d_buf, int64_t capacity_workgroups) {
+    AC_TEST_HOOK_ONLY("ac_gemm_debug_stamps");
     g_stamps = d_buf;
     g_stamp_cap = d_buf ? capacity_workgroups : 0;
     return AC_OK;
@@ -744,11 +749,35 @@ bool ln_fusion_enabled() {
 }
 // The launch must be ONE round of one workgroup per CU (all tiles of a row panel co-resident) and the default dispatch must
 // pick the 128 x 128 eight-wave tile for the shape anyway.
+// Residency proof of the exchange, made at launch: workgroups of the fused kernel that fit one CU (occupancy query, once per
+// device) x the CUs this process's workgroups can land on (dev_info().cus: MEASURED, so a CU mask counts) must hold the whole
+// grid -- then every tile of every row panel is resident together and the panel counters fill.  When it does not hold the fused
+// form is simply not chosen.  (What no launch-time check can see is another process's kernels on the same CUs: the bounded wait
+// in store_tile_ln stays for that and for bugs, as an assertion that turns into NaN rows instead of a hung GPU.)
+static int64_t ln_resident_capacity() {
+    static std::atomic<int> occ_cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    int occ = occ_cache[dev].load(std::memory_order_relaxed);
+    if (occ <= 0) {
+        using G = PipeGeom<1, 2, 4, 2, 6, 3>;
+        constexpr int LN_BYTES = G::TR_BYTES + (2 + 1) * G::BM * 8 + 16;
+        const int lds = G::LDS_BYTES > LN_BYTES ? G::LDS_BYTES : LN_BYTES;
+        const void* fn = (const void*)gemm_pipe_nt<EPI_BIAS_RES_LN, 1, 2, 4, 2, 6, false, 2, 3>;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * G::NW, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        occ = per_cu > 0 ? per_cu : -1;
+        occ_cache[dev].store(occ, std::memory_order_relaxed);
+    }
+    return occ > 0 ? (int64_t)occ * dev_info().cus : 0;
+}
 bool pipe_ln_applies(int M, int N, int K) {
     if (!ln_fusion_enabled() || !arith_split() || gemm_variant() != 0) return false;
     if (M < 192 || (N % kLnBN) != 0 || N / kLnBN > 8 || (K % 32) != 0 || K < 64) return false;
     const int64_t tiles = (int64_t)((M + kLnBM - 1) / kLnBM) * (N / kLnBN);
-    return tiles <= dev_info().cus && pipe_choose(M, N, K, EPI_BIAS_RES, false) == kLnCfg;
+    // one tile per CU is what the kernel is tuned for (tiles <= CUs); the proof is tiles <= resident capacity
+    return tiles <= dev_info().cus && tiles <= ln_resident_capacity() && pipe_choose(M, N, K, EPI_BIAS_RES, false) == kLnCfg;
 }
 size_t pipe_ln_part_bytes(int M, int N) { return (size_t)((M + kLnBM - 1) / kLnBM) * (size_t)(N / kLnBN) * kLnBM * sizeof(float2); }
 int pipe_ln_panels(int M) { return (M + kLnBM - 1) / kLnBM; }
@@ -779,6 +808,7 @@ int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, 
  * the built-in table. */
 /* process-wide switch (A/B runs, tests): 0 = the encoder keeps its LayerNorms as separate launches; default 1, or AC_LN_FUSION=0 */
 extern "C" int ac_gemm_set_ln_fusion(int on) {
+    AC_TEST_HOOK_ONLY("ac_gemm_set_ln_fusion");
     ac::g_ln_fusion.store(on == 2 ? 2 : (on ? 1 : 0), std::memory_order_relaxed);
     return AC_OK;
 }
@@ -801,6 +831,12 @@ static int parse_pipe_table(const char* spec, ac::PipeRule* rules, int* nrules) 
     *nrules = n;
     return AC_OK;
 }
-extern "C" int ac_gemm_set_pipe_table(const char* spec) { return parse_pipe_table(spec, ac::g_rules, &ac::g_nrules); }
+extern "C" int ac_gemm_set_pipe_table(const char* spec) {
+    AC_TEST_HOOK_ONLY("ac_gemm_set_pipe_table");
+    return parse_pipe_table(spec, ac::g_rules, &ac::g_nrules);
+}
 /* the same for the fp16x2 kernels (AC_GEMM_F16X2); shapes the table does not name keep the built-in choice */
-extern "C" int ac_gemm_set_pipe_table_f16(const char* spec) { return parse_pipe_table(spec, ac::g_rules_f16, &ac::g_nrules_f16); }
+extern "C" int ac_gemm_set_pipe_table_f16(const char* spec) {
+    AC_TEST_HOOK_ONLY("ac_gemm_set_pipe_table_f16");
+    return parse_pipe_table(spec, ac::g_rules_f16, &ac::g_nrules_f16);
+}

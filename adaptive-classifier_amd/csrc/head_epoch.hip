@@ -24,6 +24,8 @@
 // tiles), which is inside the tolerance the head tests hold against torch.  ac_head_train_step and
 // ac_head_train_epoch both route here when the shape fits, so "epoch == step loop" stays bit-identical.
 #include "common.h"
+
+#include <atomic>
 #include "grid_sync.h"
 
 #include <math.h>
@@ -751,6 +753,9 @@ size_t epoch_lds_bytes(int D, int H1, int H2, int R1, int R2) {
 
 namespace ac {
 
+static std::atomic<long long> g_epoch_launches{0};
+long long head_epoch_launches() { return g_epoch_launches.load(std::memory_order_relaxed); }
+
 size_t head_epoch_ws_bytes(int H1, int H2) {
     return align_up((size_t)kMaxB * H1 * sizeof(float), 256) + align_up((size_t)kMaxB * H2 * sizeof(float), 256) +
            align_up(2 * kMaxG * sizeof(float), 256) + align_up(sizeof(acp::GridCtl), 256) + 16 * 16 * sizeof(unsigned long long);
@@ -801,8 +806,15 @@ int head_epoch_persistent(const ac_head_dims& d, float* P, float* M, float* V, f
         AC_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set[variant] = lds;
     }
+    // residency proof at launch: workgroups per CU (occupancy query) x CUs this process reaches (dev_info().cus is MEASURED, a CU
+    // mask counts) must hold the grid -- otherwise the step-by-step launches run, chosen up front.  hipLaunchCooperativeKernel
+    // repeats the check against the chip's CU count.
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kT, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    if ((int64_t)per_cu * dev_info().cus < G) return 1;
     void* args[] = {&p};
     AC_HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(G), dim3(kT), args, (unsigned)lds, stream));
+    g_epoch_launches.fetch_add(1, std::memory_order_relaxed);
     if (debug) {        // phase timings of workgroup 0 (shader cycles), steps 1..15 averaged
         unsigned long long h[16 * 16];
         AC_HIP_CHECK(hipStreamSynchronize(stream));

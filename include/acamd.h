@@ -40,6 +40,15 @@ typedef void* ac_stream_t;
 const char* ac_last_error(void);
 int ac_version(void);                 /* 100*major + minor */
 int ac_device_info(int* cu_count, int* lds_bytes_per_block, size_t* hbm_bytes);
+/* chip_cus = the device's CU count; active_cus = the CUs this process's workgroups can actually land on -- measured once per device
+ * by a probe launch (fewer than chip_cus under HSA_CU_MASK / ROC_GLOBAL_CU_MASK; env AC_ACTIVE_CUS overrides, for callers whose
+ * own stream carries a CU mask).  cu_count of ac_device_info is active_cus: every co-residency decision of the library (persistent
+ * kernels' grids, the fused-LayerNorm exchange, one-round tile choice, sweep grids) is made against it, i.e. a fused / persistent
+ * path whose workgroups could not all be resident is NOT SELECTED, instead of selected and abandoned by a bounded wait. */
+int ac_device_cus(int* chip_cus, int* active_cus);
+/* Diagnostic (tests: "was the persistent path SELECTED"): launches so far of the persistent training epoch (head_epoch.hip) and of
+ * the one-launch small-batch encoder (bert_small.hip) by this process. */
+int ac_persistent_launches(int64_t* head_epoch, int64_t* bert_small);
 
 /* ------------------------------------------------------------------------- *
  *  M: PrototypeMemory kNN  (faiss.IndexFlatL2.search, memory.py:114)
@@ -233,6 +242,15 @@ int ac_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
 #define AC_GEMM_F32 0
 #define AC_GEMM_BF16X3 1
 #define AC_GEMM_F16X2 2
+/* ---- TEST HOOKS -------------------------------------------------------------------------------------------------------------
+ * ac_gemm_set_arith, ac_gemm_set_variant, ac_gemm_debug_stamps, ac_gemm_set_pipe_table(_f16), ac_gemm_set_krot,
+ * ac_gemm_set_ln_fusion and ac_set_persistent_kernels(mask >= 0) change PROCESS-WIDE state.  They exist for tests, A/B runs and
+ * the scripts under tools/, and are inert in a process that did not set AC_TEST_HOOKS=1 in its environment before loading the
+ * library: they return AC_EUNSUPPORTED (ac_set_persistent_kernels: the unchanged mask) and change nothing.  The product never
+ * calls them: what a call computes is decided by its arguments (ac_bert_config / ac_modernbert_config *_opt words, AC_LOSS_STEPWISE,
+ * AC_BERT_LAYERED) and by configuration variables read once at load (AC_GEMM_ARITH, AC_LN_FUSION, AC_GEMM_VARIANT,
+ * AC_HEAD_PERSISTENT, AC_BERT_SMALL, AC_QKV_ATTN_FUSION, AC_ACTIVE_CUS) -- SURVEY 8b: no global mutable state besides the
+ * per-thread error string.  Queries (ac_gemm_get_arith, ac_set_persistent_kernels(-1), the *_launches counters) always answer. */
 int ac_gemm_set_arith(int mode);
 int ac_gemm_get_arith(void);
 /* Diagnostic / A-B switch for the large-M pre-split GEMM: 0 = default dispatch (per-shape choice between the two-buffer

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the process-wide switches of the C ABI (ac_gemm_set_*, ac_set_persistent_kernels) are test hooks: inert unless the process asks
+# for them before libacamd.so is loaded (include/acamd.h "TEST HOOKS")
+os.environ.setdefault("AC_TEST_HOOKS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "adaptive-classifier_amd")
 for p in (ROOT, PKG):

@@ -69,3 +69,21 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_process_wide_switches_are_inert_without_the_test_hook_flag():
+    """include/acamd.h "TEST HOOKS": in a process that did not set AC_TEST_HOOKS=1 the process-wide setters refuse
+    (AC_EUNSUPPORTED = -2) and change nothing; with the flag (this suite's conftest sets it) they work.  No GPU needed."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from adaptive_classifier import _native as nv; L = nv.lib(); "
+            "a = L.ac_gemm_get_arith(); r = [L.ac_gemm_set_arith(0), L.ac_gemm_set_variant(1), L.ac_gemm_set_ln_fusion(0), "
+            "L.ac_gemm_set_krot(1), L.ac_gemm_set_pipe_table(b''), L.ac_gemm_set_pipe_table_f16(b'')]; "
+            "m = L.ac_set_persistent_kernels(-1); m2 = L.ac_set_persistent_kernels(0); m3 = L.ac_set_persistent_kernels(-1); "
+            "print(r, a == L.ac_gemm_get_arith(), m == m2 == m3, b'AC_TEST_HOOKS' in L.ac_last_error())" % os.path.join(ROOT, "adaptive-classifier_amd"))
+    env = {k: v for k, v in os.environ.items() if k != "AC_TEST_HOOKS"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip()
+    assert out == "[-2, -2, -2, -2, -2, -2] True True True", out
+    env["AC_TEST_HOOKS"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip()
+    assert out.startswith("[0, 0, 0, 0, 0, 0] False False"), out

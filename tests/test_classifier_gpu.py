@@ -604,3 +604,79 @@ def test_non_finite_embeddings_are_refused_before_anything_is_stored(clf):
         assert dict(clf.label_to_id) == before[0]
     finally:
         clf.model = real
+
+
+CU_MASK_SCRIPT = r'''
+import json, logging, os, sys
+sys.path[:0] = [%(root)r, %(pkg)r]
+import ctypes
+import numpy as np
+import torch
+from adaptive_classifier import AdaptiveClassifier, _native as nv
+from adaptive_classifier.encoder import HipBertEncoder
+from oracle import bert_oracle
+records = []
+class H(logging.Handler):
+    def emit(self, r): records.append(r.getMessage())
+logging.getLogger().addHandler(H()); logging.getLogger().setLevel(logging.WARNING)
+L = nv.lib()
+chip, act = ctypes.c_int(0), ctypes.c_int(0)
+nv.check(L.ac_device_cus(ctypes.byref(chip), ctypes.byref(act)), "ac_device_cus")
+out = {"chip": chip.value, "active": act.value}
+dev = torch.device("cuda:0")
+model = bert_oracle.make_bert(768, 3, 12, 3072, vocab=2000, seed=3)
+enc = HipBertEncoder(model, device=dev)
+ids, types, mask = bert_oracle.synthetic_batch(200, 32, vocab=2000, seed=99, ragged=True)     # ~4000 rows: 32 panels x 6 tiles = 192 tiles
+n0 = L.ac_gemm_ln_fusion_launches()
+got = enc.encode_cls(ids, types, mask).cpu()
+out["ln_fused_launches"] = int(L.ac_gemm_ln_fusion_launches() - n0)
+out["ln_gave_up"] = int(enc.ln_gave_up)
+out["enc_err"] = float((got - bert_oracle.encode_cls(model, ids, types, mask)).abs().max())
+he, bs = ctypes.c_int64(0), ctypes.c_int64(0)
+q1 = enc.encode_cls(ids[:1, :12], types[:1, :12], torch.ones_like(mask[:1, :12])).cpu()
+nv.check(L.ac_persistent_launches(ctypes.byref(he), ctypes.byref(bs)), "ac_persistent_launches")
+out["bert_small_launches"] = int(bs.value); out["one_launch"] = bool(enc.last_one_launch)
+out["q1_err"] = float((q1 - bert_oracle.encode_cls(model, ids[:1, :12], types[:1, :12], torch.ones_like(mask[:1, :12]))).abs().max())
+clf = AdaptiveClassifier("synthetic", device="cuda:0", encoder=enc)
+rng = np.random.default_rng(0)
+emb = rng.standard_normal((256, 768)).astype(np.float32); emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+clf.add_embeddings([f"t{i}" for i in range(256)], torch.from_numpy(emb), [f"c{i %% 4}" for i in range(256)])
+nv.check(L.ac_persistent_launches(ctypes.byref(he), ctypes.byref(bs)), "ac_persistent_launches")
+out["head_epoch_launches"] = int(he.value)
+out["final_loss"] = float(clf.last_train_info["final_loss"])
+out["warnings"] = [m for m in records if "gave up" in m or "NaN" in m or "repeating" in m]
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("cu_mask", [None, "0:0-127"])
+def test_residency_is_proven_at_launch_not_discovered_by_a_wait(cuda_dev, cu_mask):
+    """VERDICT r05 item 5.  The library MEASURES how many CUs its workgroups reach (ac_device_cus: a probe launch) and makes every
+    co-residency decision against that count.  Unmasked: all the chip's CUs are seen, the fused LayerNorm epilogues, the one-launch
+    encoder and the persistent training epoch are selected and nothing gives up.  Under HSA_CU_MASK (half the CUs) the forms whose
+    workgroups could not all be resident are NOT SELECTED -- no bounded wait expires, no NaN row is produced, no call is repeated
+    (the warnings the retry paths log stay absent) -- and the results are the same numbers."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("HSA_CU_MASK", None)
+    if cu_mask:
+        env["HSA_CU_MASK"] = cu_mask
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = CU_MASK_SCRIPT % {"root": root, "pkg": os.path.join(root, "adaptive-classifier_amd")}
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    print(cu_mask, out)
+    assert out["enc_err"] < 1e-4 and out["q1_err"] < 1e-4 and out["final_loss"] == out["final_loss"]
+    assert out["ln_gave_up"] == 0 and out["warnings"] == [], out
+    if cu_mask is None:
+        assert out["active"] == out["chip"] >= 64
+        assert out["ln_fused_launches"] == 4 and out["one_launch"] and out["bert_small_launches"] == 1 and out["head_epoch_launches"] >= 1
+    else:
+        if out["active"] == out["chip"]:
+            pytest.skip("HSA_CU_MASK has no effect on this box's runtime (active CUs == chip CUs)")
+        assert out["active"] < out["chip"]
+        # 192 LayerNorm tiles / 192 one-launch workgroups do not fit the masked CUs: the unfused forms run, chosen up front
+        assert out["ln_fused_launches"] == 0 and not out["one_launch"] and out["bert_small_launches"] == 0

@@ -533,11 +533,13 @@ def test_predict_retry_contract_without_a_gpu():
     assert res == ["result of emb1"] and c.model.calls == [(False, False)]
     c, res, seen = run(Enc(one_launch=True), 1)                     # one-launch forward gave NaN -> layer by layer, verified
     assert res == ["result of emb2"] and c.model.calls == [(False, False), (True, True)]
-    switched = []
+    switched = []                                                   # the product switches the fusion off PER OBJECT (the process-wide
+    enc_ln = Enc(ln_aborted=True)                                   # setters of the ABI are test hooks it never calls)
+    enc_ln.disable_ln_fusion = lambda: switched.append(0)
     real_lib = cmod.nv.lib
-    cmod.nv.lib = lambda: type("L", (), {"ac_gemm_set_ln_fusion": staticmethod(lambda on: switched.append(on) or 0)})
+    cmod.nv.lib = lambda: type("L", (), {"ac_gemm_set_ln_fusion": staticmethod(lambda on: (_ for _ in ()).throw(AssertionError("process-wide switch touched")))})
     try:
-        c, res, seen = run(Enc(ln_aborted=True), 1)                 # fused LayerNorm gave up -> fusion off, batch encoded again
+        c, res, seen = run(enc_ln, 1)                               # fused LayerNorm gave up -> fusion off, batch encoded again
     finally:
         cmod.nv.lib = real_lib
     assert res == ["result of emb2"] and c.model.calls == [(False, False), (True, False)] and switched == [0]

@@ -1,6 +1,7 @@
 """A/B of per-shape GEMM kernel tables INSIDE the encoder (bert-base, the bench's ragged 256 x 32 batch): interleaved rounds,
 median encode time per table.  usage: encode_ab.py [--large] "name=NxK=cfg;NxK=cfg" ...   (name=  alone = two-buffer kernels;
 name=@builtin = the built-in choice; name=@builtin-nofuse = the same with the LayerNorms as separate launches)"""
+import os as _os; _os.environ.setdefault("AC_TEST_HOOKS", "1")  # (the process-wide switches used below are test hooks)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "adaptive-classifier_amd")]

@@ -1,5 +1,6 @@
 """A/B of the rotated k order of the ring-staged GEMMs (ac_gemm_set_krot) inside the encoder: bert-base on the bench's ragged
 256 x 32 batch (or --large: bert-large arch, 1024 texts), both arithmetics, interleaved rounds."""
+import os as _os; _os.environ.setdefault("AC_TEST_HOOKS", "1")  # (the process-wide switches used below are test hooks)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "adaptive-classifier_amd")]

@@ -7,6 +7,7 @@ usage: f16x2_probe.py [--large] [--no-sweep]
   2. encode the bench batch under bf16x3 and fp16x2 (interleaved rounds), with the built-in table and with the sweep's winners;
      prints the max abs difference of the embeddings between the two arithmetics.
 """
+import os as _os; _os.environ.setdefault("AC_TEST_HOOKS", "1")  # (the process-wide switches used below are test hooks)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "adaptive-classifier_amd")]

@@ -31,6 +31,7 @@ __global__ void fill(float* x, size_t n, uint64_t seed, float scale) {
 struct Shape { int M, N, K, act, res, cplanes; };
 
 int main(int argc, char** argv) {
+    setenv("AC_TEST_HOOKS", "1", 0);        // ac_gemm_set_variant / ac_gemm_debug_stamps are test hooks (include/acamd.h)
     std::vector<int> variants = {1};
     int reps = 20, rounds = 3;
     std::vector<Shape> shapes = {{5141, 2304, 768, 0, 0, 0}, {5141, 768, 768, 0, 1, 0}, {5141, 3072, 768, 2, 0, 1},

@@ -1,5 +1,6 @@
 """Scratch probe for rocprofv3 --pmc: a few launches of the planes GEMM (both operands pre-split) on one shape
 (M,N,K[,act,res,cplanes]) through the default dispatch."""
+import os as _os; _os.environ.setdefault("AC_TEST_HOOKS", "1")  # (the process-wide switches used below are test hooks)
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "adaptive-classifier_amd")]

@@ -1,4 +1,5 @@
 """Scratch repro (round 5): reference tests/test_classifier.py::test_prediction gave NaN scores on the product under the Hub stand-in."""
+import os as _os; _os.environ.setdefault("AC_TEST_HOOKS", "1")  # (the process-wide switches used below are test hooks)
 import logging, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "adaptive-classifier_amd")]

@@ -2,6 +2,7 @@
 two HIP streams, so that one half's epilogues / ring fills / LayerNorm exchanges run under the other half's k-loops.
 Tile tables for the halves: the built-in per-shape choice at half the rows, and the full batch's tiles forced on the halves.
 Interleaved rounds, median encode time; results must agree."""
+import os as _os; _os.environ.setdefault("AC_TEST_HOOKS", "1")  # (the process-wide switches used below are test hooks)
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "adaptive-classifier_amd")]
