@@ -126,6 +126,19 @@ def time_stages(clf, ids, types, mask, reps=5):
         tot += [e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])]
     tot /= reps
     out["encode_ms"], out["knn_ms"], out["head_ms"] = [float(x) for x in tot]
+    # same box, same process: the encoder with the self-attention as its own launch (the round-5 form; AC_QKV_ATTN_FUSION is read at
+    # every call) -- what the attention epilogue of the QKV GEMM (gemm_pipe.hip EPI_QKV_ATTN) is worth on THIS box
+    os.environ["AC_QKV_ATTN_FUSION"] = "0"
+    try:
+        clf.model.encode_cls(ids, types, mask, verify=False)
+        e[0].record()
+        for _ in range(reps):
+            clf.model.encode_cls(ids, types, mask, verify=False)
+        e[1].record()
+        torch.cuda.synchronize()
+        out["encode_ms_attention_as_its_own_launch"] = float(e[0].elapsed_time(e[1]) / reps)
+    finally:
+        del os.environ["AC_QKV_ATTN_FUSION"]
     return out
 
 

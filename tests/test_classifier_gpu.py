@@ -1,6 +1,8 @@
 """GPU suite: API-level behaviour of the drop-in AdaptiveClassifier (mirrors the reference's
 tests/test_classifier.py with an offline tokenizer stub and a small random BERT) and the reference's
 memory tests against the real device search."""
+import os
+
 import numpy as np
 import pytest
 import torch
