@@ -49,14 +49,24 @@ def _unpack(both):
 
 class ShardedSearch:
     def __init__(self, local_rows, n_local, dim, row_offset, group=None, local_search=None, merge=None,
-                 force_collectives=False, equal_blocks=False):
+                 force_collectives=False, equal_blocks=False, block_rows=None):
         """force_collectives: run the collectives even on a one-rank group (tests: executes the RCCL calls on one GPU).
         equal_blocks: the caller guarantees that every rank passes the same number of queries to every search_block /
-        gather_queries call (a fixed per-rank batch): the ranks then skip the exchange of their block sizes."""
+        gather_queries call (a fixed per-rank batch): the ranks then skip the exchange of their block sizes.
+        block_rows: the FIXED-BATCH path (what a serving loop and bench.py use): every rank's query block has AT MOST this many
+        rows; blocks travel padded to exactly block_rows, so no sizes are exchanged and no value is read back to the host
+        between the collectives (a short or empty block only costs its padding rows of local search), every message has a
+        fixed shape and lives in buffers allocated once (`search_block`), and the query all-gather of the NEXT batch can run
+        under the local sweep of the current one (`prefetch_queries` / `search_blocks`)."""
         self.rows, self.n_local, self.dim, self.row_offset = local_rows, n_local, dim, row_offset
         self.group = group
         self.force_collectives = bool(force_collectives)
         self.equal_blocks = bool(equal_blocks)
+        self.block_rows = None if block_rows is None else int(block_rows)
+        if self.block_rows is not None and self.block_rows < 1:
+            raise ValueError("block_rows must be >= 1")
+        self._bufs = {}                # fixed-batch path: (name, shape, dtype) -> tensor, allocated once
+        self.stats = {"size_exchanges": 0, "buffer_allocations": 0, "prefetched_gathers": 0}
         self._prepared = None          # bf16 planes + norms of the local shard (batched searches), built on first use
         if local_search is None or merge is None:
             from . import index as ix
@@ -121,6 +131,7 @@ class ShardedSearch:
             return [int(m)]
         if self.equal_blocks:
             return [int(m)] * self.world
+        self.stats["size_exchanges"] += 1
         if dist.get_backend(self.group) == "nccl":
             t = torch.tensor([int(m)], dtype=torch.int64, device=self.rows.device if self.rows.is_cuda else "cuda")
             out = torch.empty(self.world, dtype=torch.int64, device=t.device)
@@ -164,12 +175,95 @@ class ShardedSearch:
         both = self._all_gather(_pack(D_loc, I_loc))            # ONE message per peer: fp64 bits and ids side by side
         return self._merge(*_unpack(both))
 
-    def search_block(self, q_local, k, block_sizes=None):
+    # ---- the fixed-batch path (block_rows given): fixed shapes, buffers allocated once, no host read-back ----------------
+    def _buf(self, name, shape, dtype, device):
+        key = (name, tuple(shape), dtype, str(device))
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.empty(shape, dtype=dtype, device=device)
+            self.stats["buffer_allocations"] += 1
+        return t
+
+    def prefetch_queries(self, q_local):
+        """Start the all-gather of a query block (padded to block_rows) WITHOUT waiting for it: under RCCL the collective runs on
+        the communicator's own stream, so it proceeds while the caller's stream is still busy with the previous batch's sweep.
+        Returns a handle for `search_block(..., gathered=handle)`.  Two buffers alternate, so one batch may be in flight while
+        the previous one is being searched."""
+        if self.block_rows is None:
+            raise ValueError("prefetch_queries needs the fixed-batch path (construct with block_rows=...)")
+        m, br, G = int(q_local.shape[0]), self.block_rows, self.world
+        if m > br:
+            raise ValueError(f"query block of {m} rows exceeds block_rows = {br}")
+        slot = self.stats["prefetched_gathers"] & 1
+        self.stats["prefetched_gathers"] += 1
+        dev = q_local.device
+        pad = self._buf(f"qpad{slot}", (br, self.dim), q_local.dtype, dev)
+        pad[:m].copy_(q_local)
+        if m < br:
+            pad[m:].zero_()
+        if not self._collective:
+            return {"m": m, "all": pad, "work": None}
+        if self._staged(pad):
+            parts = [torch.empty((br, self.dim), dtype=pad.dtype) for _ in range(G)]
+            dist.all_gather(parts, pad.cpu(), group=self.group)
+            out = self._buf(f"qall{slot}", (G, br, self.dim), pad.dtype, dev)
+            out.copy_(torch.stack(parts))
+            return {"m": m, "all": out.view(G * br, self.dim), "work": None}
+        out = self._buf(f"qall{slot}", (G, br, self.dim), pad.dtype, dev)
+        if pad.is_cuda:
+            work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
+        else:
+            work = dist.all_gather(list(out.unbind(0)), pad, group=self.group, async_op=True)
+        return {"m": m, "all": out.view(G * br, self.dim), "work": work}
+
+    def _search_block_fixed(self, q_local, k, gathered=None):
+        h = gathered if gathered is not None else self.prefetch_queries(q_local)
+        m, br, G = h["m"], self.block_rows, self.world
+        if h["work"] is not None:
+            h["work"].wait()                       # (RCCL: the caller's STREAM waits for the collective; the host does not)
+        D_loc, I_loc = self._search(self.rows, self.n_local, self.dim, h["all"], k, self.row_offset)
+        if not self._collective:
+            return D_loc[:m].to(torch.float32), I_loc[:m]
+        dev = D_loc.device
+        send = self._buf("cand_send", (G, br, 2 * k), torch.int64, dev)
+        send.view(G * br, 2 * k)[:, :k].copy_(D_loc.contiguous().view(torch.int64))
+        send.view(G * br, 2 * k)[:, k:].copy_(I_loc)
+        recv = self._buf("cand_recv", (G, br, 2 * k), torch.int64, dev)
+        if self._staged(send):
+            src = send.cpu()
+            out = torch.empty_like(src)
+            dist.all_to_all_single(out, src, group=self.group)
+            recv.copy_(out)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
+        if m == 0:
+            return torch.empty((0, k), dtype=torch.float32, device=dev), torch.empty((0, k), dtype=torch.int64, device=dev)
+        return self._merge(*_unpack(recv[:, :m]))
+
+    def search_blocks(self, blocks, k):
+        """The pipelined serving loop over an iterable of query blocks (fixed-batch path): while batch i is swept locally, the
+        query all-gather of batch i + 1 is already running.  Yields (dist fp32 [m_i, k], ids [m_i, k]) per block."""
+        it = iter(blocks)
+        try:
+            cur = self.prefetch_queries(next(it))
+        except StopIteration:
+            return
+        for nxt in it:
+            ahead = self.prefetch_queries(nxt)          # (issued BEFORE the current block's sweep is enqueued)
+            yield self._search_block_fixed(None, k, gathered=cur)
+            cur = ahead
+        yield self._search_block_fixed(None, k, gathered=cur)
+
+    def search_block(self, q_local, k, block_sizes=None, gathered=None):
         """The data-parallel step: this rank's query block [m, D] -> the global (dist fp32 [m, k], ids [m, k]) of THOSE
         queries.  all_gather(queries) -> local search of all of them -> all_to_all of the candidate lists -> this rank
-        merges only its own block.  block_sizes: every rank's m when the caller knows them (validated against this rank's
+        merges only its own block.  With `block_rows` (constructor) this is the fixed-batch path: blocks padded to block_rows,
+        pre-allocated messages, nothing read back to the host; `gathered` = a handle of prefetch_queries() for this block.
+        Otherwise -- block_sizes: every rank's m when the caller knows them (validated against this rank's
         block; a wrong list raises here instead of hanging in the collective); None = the ranks exchange their sizes first
         (one extra 8-byte all_gather).  Sizes may differ and may be 0."""
+        if self.block_rows is not None and block_sizes is None:
+            return self._search_block_fixed(q_local, k, gathered)     # fixed shapes: no size exchange, no host read-back
         if not self._collective:
             D_loc, I_loc = self._search(self.rows, self.n_local, self.dim, q_local, k, self.row_offset)
             return D_loc.to(torch.float32), I_loc

@@ -44,6 +44,17 @@ def _worker(rank, world, port, N, D, nq, k, ret):
     Dg, Ig = ss.search(Q, k)
     Db, Ib = ss.search_block(q_local, k)                                          # all_to_all, own block merged only
     assert torch.equal(Db, Dg[rank * b:(rank + 1) * b]) and torch.equal(Ib, Ig[rank * b:(rank + 1) * b])
+    # the fixed-batch path: blocks padded to block_rows, pre-allocated messages, no size exchange, and the
+    # query all-gather of the next batch issued before the current one is searched -- three batches, the last one short
+    sf = ShardedSearch(rows, hi - lo, D, lo, block_rows=b)
+    blocks = [q_local, q_local.flip(0).contiguous(), q_local[: max(1, b // 2)].contiguous()]
+    outs = list(sf.search_blocks(blocks, k))
+    assert torch.equal(outs[0][1], Ib) and torch.equal(outs[0][0], Db)
+    assert torch.equal(outs[1][1], Ib.flip(0)) and torch.equal(outs[1][0], Db.flip(0))
+    assert torch.equal(outs[2][1], Ib[: max(1, b // 2)]) and torch.equal(outs[2][0], Db[: max(1, b // 2)])
+    allocs = sf.stats["buffer_allocations"]
+    again = sf.search_block(q_local, k)
+    assert torch.equal(again[1], Ib) and sf.stats["buffer_allocations"] == allocs and sf.stats["size_exchanges"] == 0
     # the same through the memory object the classifier uses (row -> class map replicated)
     mem = PrototypeMemory(D, device=str(dev))
     mem.load_rows(rows, torch.arange(N, dtype=torch.int32) % 4, ["c0", "c1", "c2", "c3"], sharded=ss)
@@ -96,11 +107,15 @@ def _rccl_worker(rank, port, ret):
     Q = ss.gather_queries(q)
     Dg, Ig = ss.search(Q, k)                                                        # all_gather of the packed lists + merge
     Db, Ib = ss.search_block(q, k)                                                  # all_to_all_single + merge
+    sf = ShardedSearch(rows, N, D, 0, force_collectives=True, block_rows=nq)       # fixed-batch path: ASYNC all_gather_into_tensor
+    outs = list(sf.search_blocks([q, q[:7].contiguous()], k))                      # (RCCL work handle, stream-side wait) + all_to_all
+    fixed_ok = bool(torch.equal(outs[0][1], uI) and torch.equal(outs[0][0], uD) and torch.equal(outs[1][1], uI[:7])
+                    and sf.stats["size_exchanges"] == 0)
     mem = PrototypeMemory(D, device=str(dev))
     mem.load_rows(rows, torch.arange(N, dtype=torch.int32) % 4, ["c0", "c1", "c2", "c3"], sharded=ss)
     S, Im, Dm = mem.search_batch(q, k)
     torch.cuda.synchronize()
-    ret["ok"] = bool(g.shape == (1, nq, q.shape[1]) and torch.equal(g[0], q) and torch.equal(Q, q)
+    ret["ok"] = bool(fixed_ok and g.shape == (1, nq, q.shape[1]) and torch.equal(g[0], q) and torch.equal(Q, q)
                      and torch.equal(Ig, uI) and torch.equal(Dg, uD) and torch.equal(Ib, uI) and torch.equal(Db, uD)
                      and torch.equal(Im, uI) and torch.equal(Dm, uD) and torch.equal(S, ix.proto_scores(uD, uI)))
     dist.barrier()
