@@ -10,7 +10,7 @@ value it returns; nothing the reference computes is changed):
   * sha256 of torch's global CPU generator state and of numpy's after each call (the product's replay must leave both there);
   * `predict(text, k)` and `predict_batch(texts, k)` of the LIVE classifier after each call.
 Cases: bert_mini ("standin/bert-mini-4l", the e2e fixture's model and texts) and bert_base ("bert-base-uncased" ARCHITECTURE,
-12 x 768, seeded random init through oracle/hub_standin.py: 88 + 20 training texts, 40 query texts -- three batches per epoch).
+12 x 768, seeded random init through oracle/hub_standin.py: 88 + 20 training texts, 50 query texts -- three batches per epoch).
 tests/test_e2e_reference_gpu.py trains the PRODUCT's own head with config={"dropout_source": "torch_cpu"} from the same texts
 and seeds and must reproduce the epochs, the per-epoch losses (1e-4 relative), both generator states, the label order and
 every score to 1e-3 -- without ever loading a head the reference trained.  No reference source and no trained weights are
@@ -61,7 +61,7 @@ def base_case_texts():
     t1 = [(t, l) for i, l in enumerate(["positive", "negative", "neutral", "technical"]) for t in synth_texts(l, 22, 100 + i)]
     t2 = [(t, "sports") for t in synth_texts("sports", 14, 200)] + [(t, "positive") for t in synth_texts("positive", 3, 201)] + \
          [(t, "technical") for t in synth_texts("technical", 3, 202)]
-    q = [t for i, l in enumerate(WORDS) for t in synth_texts(l, 8, 300 + i)]
+    q = [t for i, l in enumerate(WORDS) for t in synth_texts(l, 10, 300 + i)]
     return t1, t2, q
 
 
@@ -71,7 +71,7 @@ def state_hashes():
             "numpy": hashlib.sha256(np_state[1].tobytes() + str(np_state[2:]).encode()).hexdigest()}
 
 
-def near_tie(pred, gap=2e-3):            # (wider than gen_e2e's 2e-4: the replayed head may sit 1e-3 away)
+def near_tie(pred, gap=2e-4):            # (gen_e2e's gap: the replayed head reproduces the reference's scores to ~4e-7 on MI355X)
     s = [v for _, v in pred]
     return any(abs(a - b) < gap for a, b in zip(s, s[1:]))
 
@@ -109,7 +109,7 @@ def run_case(case):
     # not expose the count, so it is derived the way the product derives it; kept in the fixture only as a cross-check
     keep = [i for i in range(len(queries))
             if not any(near_tie(c[k][i]) for c in calls for k in ("predict_all", "predict_batch_k3"))]
-    assert len(keep) >= (24 if case == "bert_mini" else 20), (case, len(keep))
+    assert len(keep) >= 32, (case, len(keep))
     for c in calls:
         for k in ("predict_all", "predict_batch_k3"):
             c[k] = [c[k][i] for i in keep]

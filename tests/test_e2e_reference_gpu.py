@@ -211,7 +211,7 @@ def test_training_trajectory_replays_the_reference_from_text(standin, cuda_dev, 
     np.random.seed(0)
     clf = AdaptiveClassifier(ex["model_name"], device="cuda:0", config={"dropout_source": "torch_cpu"})
     texts = ex["texts"]
-    assert len(texts) >= (24 if case == "bert_mini" else 20)
+    assert len(texts) >= 32
     worst_score = worst_loss = 0.0
     for ci, (part, call) in enumerate(zip(("train_1", "train_2"), ex["calls"])):
         n_logs = len(clf.train_log)
