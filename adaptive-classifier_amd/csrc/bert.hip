@@ -357,8 +357,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 struct BertWs {
-    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, cu, tile_seq, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
-    size_t lnctl_bytes;
+    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, cu, tile_seq, attn_xchg, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
+    size_t lnctl_bytes, attn_xchg_bytes;
 };
 // cu of an UNPACKED batch without a mask (every sequence has S real tokens): what ac_bert_pack would have produced
 __global__ __launch_bounds__(256) void iota_cu_kernel(int32_t* cu, int b, int S) {
@@ -403,6 +403,9 @@ BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     off += ac::align_up((size_t)(b + 1) * sizeof(int32_t), 256);
     w.tile_seq = off;
     off += ac::align_up(ac::qkv_attn_tile_seq_bytes((int)T), 256);
+    w.attn_xchg = off;                // one word per (256-row tile, head): the in-launch exchange of straddling sequences
+    w.attn_xchg_bytes = ac::align_up(((T + ac::kQkvAttnRows - 1) / ac::kQkvAttnRows) * (size_t)c.heads * sizeof(unsigned), 256);
+    off += w.attn_xchg_bytes;
     w.total = off;
     return w;
 }
@@ -496,9 +499,14 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         cu_at = cuw;
     }
     int32_t* tile_seq = (int32_t*)(base + ws.tile_seq);
+    unsigned* attn_xchg = nullptr;
     if (fuse_attn) {
         rc = ac::qkv_attn_tile_seq(cu_at, b, T, tile_seq, stream);
         if (rc) return rc;
+        if (ac::qkv_attn_exchange_applies(T, c.heads, (int)f16)) {        // every tile resident (proven): no boundary launches
+            attn_xchg = (unsigned*)(base + ws.attn_xchg);
+            AC_HIP_CHECK(hipMemsetAsync(attn_xchg, 0, ws.attn_xchg_bytes, stream));
+        }
     }
     for (int l = 0; l < c.layers; ++l) {
         const uint16_t* qkv_w3 = wplanes ? w->qkv_w3[l] : nullptr;
@@ -523,11 +531,12 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         }
         if (fuse_attn && !last) {
             rc = ac::launch_gemm_pipe_qkv_attn(xp, T, f16 ? w->qkv_wh[l] : qkv_w3, 3 * H, w->qkv_b[l], T, H, c.heads, cu_at, tile_seq, b, Smax,
-                                               scale, ctxp, qkv, stream, (int)f16);
+                                               scale, ctxp, qkv, stream, (int)f16, attn_xchg, (unsigned)(l + 1), ln_abort);
             if (rc) return rc;
-            // the sequences that straddle a 256-row tile boundary (their q | k | v rows are in qkv): one wave per boundary
+            // the sequences that straddle a 256-row tile boundary (their q | k | v rows are in qkv): one wave per boundary --
+            // unless the tiles exchanged the rows among themselves inside the launch
             const int nbound = (T - 1) / ac::kQkvAttnRows;
-            if (nbound > 0) {
+            if (nbound > 0 && !attn_xchg) {
                 hipLaunchKernelGGL((attention_mfma_kernel<false, 64>), dim3((Smax + 31) / 32, c.heads, nbound), dim3(64), 0, stream, qkv,
                                    nullptr, S, H, scale, ctx, ctxp, nullptr, nullptr, -1, cu_at, (int64_t)T, (int)f16, ac::kQkvAttnRows, b);
                 AC_LAUNCH_CHECK();

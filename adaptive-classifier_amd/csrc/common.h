@@ -100,9 +100,14 @@ constexpr int kQkvAttnRows = 256;
 bool qkv_attn_applies(int M, int H, int heads, int smax);
 size_t qkv_attn_tile_seq_bytes(int M);
 int qkv_attn_tile_seq(const int32_t* cu, int b, int M, int32_t* tile_seq, hipStream_t stream);     // once per forward (cu is the same for every layer)
+// exchange (optional; qkv_attn_exchange_applies must hold: one proven residency round): ceil(M / 256) * heads words, zero before the
+// forward's first launch, `epoch` distinct per launch (layer + 1) -- straddling sequences are then finished inside the launch and
+// no boundary launch is needed; abort_flag = the encoder call's give-up word
+bool qkv_attn_exchange_applies(int M, int heads, int f16);
 int launch_gemm_pipe_qkv_attn(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias, int M, int H,
                               int heads, const int32_t* cu, const int32_t* tile_seq, int b, int smax, float scale, uint16_t* ctx_planes,
-                              float* qkv, hipStream_t stream, int f16 = 0);
+                              float* qkv, hipStream_t stream, int f16 = 0, unsigned* exchange = nullptr, unsigned epoch = 0,
+                              unsigned* abort_flag = nullptr);
 // true when linear_f32(M, N, K) with W planes takes the pre-split kernel (only then may A / C planes be passed)
 bool linear_takes_planes(int M, int N, int K);
 

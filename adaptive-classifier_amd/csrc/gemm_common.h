@@ -59,6 +59,13 @@ struct AttnFuse {
     float scale;            // 1 / sqrt(head dim)
     uint16_t* ctx_planes;   // [planes][H / 8][T][8]
     float* qkv;             // [T, 3H]: only rows of straddling sequences are written
+    // exchange != null (one-round launches only: every tile co-resident, proven by the host before the launch): the tile BELOW a
+    // boundary publishes its part of the straddling sequence's rows (sc1 stores into qkv) and sets exchange[tile * heads + head] =
+    // epoch; the tile ABOVE waits for that word, pulls the rows into its staging area and finishes the sequence itself -- no
+    // follow-up launch.  null: both tiles spill their parts and attention_mfma_kernel's boundary mode serves the sequence.
+    unsigned* exchange;
+    unsigned epoch;
+    unsigned* abort_;       // the encoder call's give-up word (shared with the LayerNorm exchange)
 };
 
 __device__ __forceinline__ float apply_epilogue(const Epilogue& e, float acc, int64_t row, int col,

@@ -254,13 +254,44 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
     const int sb = at.tile_seq[bm], se = at.tile_seq[bm + 1], nseq = se - sb;    // (wave-uniform)
     for (int i = wave * 64 + lane; i <= nseq; i += NW * 64) cuL[i] = at.cu[sb + i];
     // rows [row_a, row_b) of the tile -> their place in the fp32 qkv buffer (q | k | v blocks H apart); one wave, 256-byte runs
+    // (sc1 stores when another workgroup of THIS launch will read them: write-through, visible across the XCDs' L2s)
+    const bool xchg = at.exchange != nullptr;
     auto spill_rows = [&](int row_a, int row_b, int lo_r) {
         for (int row = row_a; row < row_b; ++row) {
             const float* src = T + (row - m0 - lo_r) * kAtLd;
             float* dst = at.qkv + (int64_t)row * (3 * H) + head * 64;
 #pragma unroll
-            for (int part = 0; part < 3; ++part) dst[part * H + lane] = src[part * 64 + lane];
+            for (int part = 0; part < 3; ++part) {
+                if (xchg) acp::st_sc1(dst + part * H + lane, src[part * 64 + lane]);
+                else dst[part * H + lane] = src[part * 64 + lane];
+            }
         }
+    };
+    // the rows [row_a, row_b) of the NEXT row tile (published there by its top-part spill) -> this pass's staging rows; one wave
+    auto pull_rows = [&](int row_a, int row_b, int lo_r) -> bool {
+        unsigned* flag = at.exchange + (size_t)(bm + 1) * (prm.N / 192) + head;
+        unsigned ok = 1;
+        for (long spins = 0;; ++spins) {
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == at.epoch) break;
+            __builtin_amdgcn_s_sleep(1);
+            // (the neighbour is resident -- the host proved it before choosing this form -- and publishes right after its k-loop,
+            //  long before this point; the bound is an assertion against a device shared with another process, not a protocol step)
+            if ((spins & 63) == 63 && (spins > (1l << 20) || __hip_atomic_load(at.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (lane == 0) __hip_atomic_store(at.abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int row = row_a; row < row_b; ++row) {
+            float* dst = T + (row - m0 - lo_r) * kAtLd;
+            const float* src = at.qkv + (int64_t)row * (3 * H) + head * 64;
+#pragma unroll
+            for (int part = 0; part < 3; ++part) dst[part * 64 + lane] = ok ? acp::ld_sc1(src + part * H + lane) : __uint_as_float(0x7fc00000u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return ok != 0;
     };
     for (int lo_r = 0; lo_r < BM; lo_r += stride) {
         if (m0 + lo_r >= prm.M) break;                                  // (workgroup-uniform: the ragged last tile)
@@ -287,19 +318,28 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
         if (lo_r == 0 && wave == NW - 1) {                              // the part of a sequence that began in the previous tile
             const int top_end = cuL[0] < tile_end ? cuL[0] : tile_end;  // (cuL[0] = cu[sb] >= m0; = T when no sequence starts at or after m0)
             spill_rows(m0, top_end, lo_r);
+            if (xchg) {                                                 // publish: the rows above, then the word the tile above polls
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(at.exchange + (size_t)bm * (prm.N / 192) + head, at.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         for (int s = s0 + wave; s < nseq; s += NW) {
             const int r0 = cuL[s];
             if (r0 >= seq_hi) break;
             const int r1 = cuL[s + 1];
-            if (r1 <= m0 + BM) {                                        // the whole sequence is in this tile (and in this pass's rows)
+            bool whole = r1 <= m0 + BM;                                 // the whole sequence is in this tile (and in this pass's rows)
+            if (!whole && xchg) {                                       // it continues in the next tile: fetch the rest and finish it here
+                pull_rows(tile_end, r1, lo_r);
+                whole = true;
+            }
+            if (whole) {
                 const float* qb = T + (r0 - seq_lo) * kAtLd;
                 const int S = r1 - r0;
                 for (int qt = 0; qt * 32 < S; ++qt)
                     acattn::attention_tile<false, 64, false>(qb, qb + 64, qb + 128, kAtLd, S, qt, lane, at.scale, nullptr, nullptr, nullptr, -1,
-                                                      nullptr, H, at.ctx_planes, prm.M, r0, head * 64, AR == 2);
+                                                             nullptr, H, at.ctx_planes, prm.M, r0, head * 64, AR == 2);
             } else {
-                spill_rows(r0, tile_end, lo_r);                         // it continues in the next tile
+                spill_rows(r0, tile_end, lo_r);                         // it continues in the next tile: the boundary launch serves it
             }
         }
         __syncthreads();                                                // (the next pass overwrites the staging rows)
@@ -689,6 +729,7 @@ int launch_gemm_pipe(int cfg, const uint16_t* Ap, int64_t a_rows, const uint16_t
 }
 
 
+bool ln_fusion_enabled();
 // ---- the QKV projection with the self-attention of the packed sequences in its epilogue (EPI_QKV_ATTN) ----
 static std::atomic<long long> g_qkv_attn_launches{0};
 bool qkv_attn_applies(int M, int H, int heads, int smax) {
@@ -712,9 +753,44 @@ int qkv_attn_tile_seq(const int32_t* cu, int b, int M, int32_t* tile_seq, hipStr
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
+// Residency proof for the in-launch exchange of straddling sequences (as ln_resident_capacity above): the whole grid resident at once
+static int64_t qkv_attn_resident_capacity(int f16) {
+    static std::atomic<int> occ_cache[2][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    int occ = occ_cache[f16 ? 1 : 0][dev].load(std::memory_order_relaxed);
+    if (occ <= 0) {
+        int per_cu = 0;
+        hipError_t e;
+        if (f16) {
+            using G = PipeGeom<2, 3, 4, 2, 4, 2>;
+            const int lds = G::LDS_BYTES > kAtBytes ? G::LDS_BYTES : kAtBytes;
+            const void* fn = (const void*)gemm_pipe_nt<EPI_QKV_ATTN, 2, 3, 4, 2, 4, false, 2, 2>;
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * G::NW, lds);
+        } else {
+            using G = PipeGeom<2, 3, 4, 2, 3, 3>;
+            const int lds = G::LDS_BYTES > kAtBytes ? G::LDS_BYTES : kAtBytes;
+            const void* fn = (const void*)gemm_pipe_nt<EPI_QKV_ATTN, 2, 3, 4, 2, 3, false, 2, 3>;
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * G::NW, lds);
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        occ = per_cu > 0 ? per_cu : -1;
+        occ_cache[f16 ? 1 : 0][dev].store(occ, std::memory_order_relaxed);
+    }
+    return occ > 0 ? (int64_t)occ * dev_info().cus : 0;
+}
+// true: one residency round (proven) and the LayerNorm-exchange option is on -- the straddling sequences are finished inside the launch
+bool qkv_attn_exchange_applies(int M, int heads, int f16) {
+    if (!ln_fusion_enabled()) return false;              // (the encoder's "no in-launch exchanges" switch covers this one too)
+    if (const char* e = getenv("AC_QKV_ATTN_EXCHANGE"); e && atoi(e) == 0) return false;       // (A/B runs, the boundary launch's tests)
+    const int64_t tiles = (int64_t)((M + kQkvAttnRows - 1) / kQkvAttnRows) * heads;
+    return tiles <= qkv_attn_resident_capacity(f16);
+}
 int launch_gemm_pipe_qkv_attn(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias, int M, int H,
                               int heads, const int32_t* cu, const int32_t* tile_seq, int b, int smax, float scale, uint16_t* ctx_planes,
-                              float* qkv, hipStream_t stream, int f16) {
+                              float* qkv, hipStream_t stream, int f16, unsigned* exchange, unsigned epoch, unsigned* abort_flag) {
     AC_REQUIRE(qkv_attn_applies(M, H, heads, smax), AC_EUNSUPPORTED, "gemm_pipe: fused attention epilogue not applicable (M %d H %d heads %d longest %d)",
                M, H, heads, smax);
     AC_REQUIRE(Ap && Wp && bias && cu && tile_seq && ctx_planes && qkv && b >= 1, AC_EINVAL, "gemm_pipe_qkv_attn: null pointer");
@@ -727,6 +803,9 @@ int launch_gemm_pipe_qkv_attn(const uint16_t* Ap, int64_t a_rows, const uint16_t
     p.ln = LnFuse{};
     p.at.cu = cu; p.at.tile_seq = tile_seq; p.at.b = b; p.at.H = H; p.at.smax = smax; p.at.scale = scale; p.at.ctx_planes = ctx_planes;
     p.at.qkv = qkv;
+    AC_REQUIRE(!exchange || (abort_flag && qkv_attn_exchange_applies(M, heads, f16)), AC_EINVAL,
+               "gemm_pipe_qkv_attn: the in-launch exchange needs every tile resident (%d rows x %d heads) and an abort word", M, heads);
+    p.at.exchange = exchange; p.at.epoch = epoch; p.at.abort_ = abort_flag;
     p.stamps = nullptr;
     g_qkv_attn_launches.fetch_add(1, std::memory_order_relaxed);
     return f16 ? launch_one<EPI_QKV_ATTN, 2, 3, 4, 2, 4, false, 2, 2>(p, stream)

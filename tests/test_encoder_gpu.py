@@ -500,6 +500,7 @@ def test_per_call_options_do_not_leak_between_objects(cuda_dev):
     (768, 2, 12, 3072, 24, 64, True),      # sequences of up to 64 tokens: three staging passes, two query tiles
     (768, 2, 12, 3072, 30, 50, False),     # 50-token rows, unpacked: sequences straddle every tile boundary
     (128, 2, 2, 512, 700, 8, True),        # many short sequences (2 .. 8 tokens): ~20 sequences per staging pass and wave rounds
+    (768, 2, 12, 3072, 640, 32, True),     # ~12 800 rows = 50 row tiles x 12 heads: more tiles than CUs -> several rounds, no in-launch exchange
 ])
 @pytest.mark.parametrize("regime", REGIMES)
 def test_attention_fused_into_the_qkv_gemm_epilogue(hidden, layers, heads, inter, b, S, ragged, regime, cuda_dev, monkeypatch):
@@ -525,6 +526,13 @@ def test_attention_fused_into_the_qkv_gemm_epilogue(hidden, layers, heads, inter
     assert lib.ac_gemm_qkv_attn_launches() == n0 + (layers - 1)                # every layer but the CLS-only last one
     assert torch.equal(fused, separate), (fused - separate).abs().max().item()
     assert (fused - want).abs().max().item() < 1e-4
+    # the two ways a sequence that straddles a 256-row tile boundary is finished: inside the launch (the two tiles exchange its
+    # rows; one-round launches, the default above where it applies) and by attention_mfma_kernel's boundary mode afterwards
+    monkeypatch.setenv("AC_QKV_ATTN_EXCHANGE", "0")
+    boundary = enc.encode_cls(ids, types, mask).cpu()
+    monkeypatch.delenv("AC_QKV_ATTN_EXCHANGE")
+    assert torch.equal(boundary, separate)
+    assert not enc.ln_fusion_aborted()
 
 
 def test_attention_fusion_leaves_long_or_masked_batches_alone(cuda_dev):
