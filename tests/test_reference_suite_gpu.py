@@ -328,9 +328,12 @@ def test_tests_the_reference_itself_fails_do_not_crash_the_product(cuda_dev, tes
         outcome = res.get(t, "not run")
         assert outcome in ("passed", "failed"), (t, outcome, out[-4000:])          # "error" = a fixture / collection crash
         if outcome == "failed":
-            # the short summary line: FAILED <path>::<test> - <ExceptionType>: message   (a bare `assert` shows as "assert ...")
-            m = re.search(r"^FAILED \S*::%s - (.*)$" % re.escape(t), out, re.M)
-            why = m.group(1) if m else ""
-            assert why.startswith("assert") or why.startswith("AssertionError"), \
-                "%s fails on the product with something other than one of its own assertions: %r\n%s" % (t, why, out[-4000:])
+            # the test's section of the report (between its "____ name ____" header and the next header): every exception pytest
+            # names there (lines "E   SomeError: ...") must be an AssertionError; a bare `assert a > b` names none
+            m = re.search(r"^_+ %s _+$(.*?)(?=^_{5,} |^=+ )" % re.escape(t), out, re.M | re.S)
+            section = m.group(1) if m else ""
+            assert section, "no report section for %s\n%s" % (t, out[-3000:])
+            raised = set(re.findall(r"^E\s+([A-Za-z_][\w\.]*(?:Error|Exception))\b", section, re.M))
+            assert raised <= {"AssertionError"}, \
+                "%s fails on the product with something other than one of its own assertions: %r\n%s" % (t, raised, section[-4000:])
     print(test_file, {t: res.get(t) for t in names})
