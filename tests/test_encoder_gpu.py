@@ -554,3 +554,32 @@ def test_attention_fusion_leaves_long_or_masked_batches_alone(cuda_dev):
     got = enc.encode_cls(ids, types, mask).cpu()
     assert lib.ac_gemm_qkv_attn_launches() == n0
     assert (got - bert_oracle.encode_cls(model, ids, types, mask)).abs().max().item() < 1e-4
+
+
+def test_modernbert_gemm_arith_is_a_per_call_option(cuda_dev):
+    """`config["gemm_arith"]` / `encode_cls(arith=...)` reaches the ModernBERT encoder too -- a per-call option
+    word inside ac_modernbert_config (thread-local call scope), not the process default.  "f32" runs the strict fp32-input MFMA
+    kernels (different bits from the bf16x3 default, same 1e-4 bar), the process-wide arithmetic is never written, and a classifier
+    configured with an arithmetic hands it to this encoder."""
+    from adaptive_classifier import AdaptiveClassifier, _native as nv
+    from adaptive_classifier.encoder import HipModernBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_modernbert(128, 3, 2, 256, vocab=2000, max_pos=1024, local_attention=16, seed=3, init_scale=4.0)
+    ids, _, mask = bert_oracle.synthetic_batch(40, 24, vocab=2000, seed=7, ragged=True)      # ~600 rows: the planes GEMMs run
+    ids[:, 0] = 1
+    want = bert_oracle.encode_cls_modernbert(model, ids, mask)
+    enc = HipModernBertEncoder(model, device=cuda_dev)
+    before = nv.lib().ac_gemm_get_arith()
+    dflt = enc.encode_cls(ids, None, mask).cpu()
+    f32 = enc.encode_cls(ids, None, mask, arith="f32").cpu()
+    again = enc.encode_cls(ids, None, mask).cpu()
+    split = enc.encode_cls(ids, None, mask, arith="bf16x3").cpu()
+    assert nv.lib().ac_gemm_get_arith() == before
+    assert torch.equal(dflt, again) and torch.equal(dflt, split)            # (the process default IS bf16x3 in this suite)
+    assert not torch.equal(dflt, f32)                                       # another arithmetic really ran ...
+    for got in (dflt, f32):
+        assert (got - want).abs().max().item() < 1e-4                       # ... to the same bar
+    with pytest.raises(ValueError):
+        enc.encode_cls(ids, None, mask, arith="fp8")
+    clf = AdaptiveClassifier("synthetic-modernbert", device=str(cuda_dev), encoder=enc, config={"gemm_arith": "f32"})
+    assert torch.equal(clf._encode_tokens(ids, None, mask).cpu(), f32)
