@@ -70,8 +70,12 @@ class MultiLabelAdaptiveClassifier(AdaptiveClassifier):
 
     def __init__(self, model_name: str, device: Optional[str] = None, config: Optional[Dict[str, Any]] = None,
                  seed: int = 42, default_threshold: float = 0.5, min_predictions: int = 1,
-                 max_predictions: Optional[int] = None, *, encoder=None, tokenizer=None):
-        super().__init__(model_name, device, config, seed, encoder=encoder, tokenizer=tokenizer)
+                 max_predictions: Optional[int] = None, *, use_onnx="auto", trust_remote_code: bool = False, encoder=None,
+                 tokenizer=None):
+        # (use_onnx / trust_remote_code, keyword-only: the reference's constructor lacks them, which is why ITS inherited `load()`
+        #  -- `cls(..., use_onnx=...)`, classifier.py:708-716 -- dies with a TypeError for this class; here load() works)
+        super().__init__(model_name, device, config, seed, use_onnx=use_onnx, trust_remote_code=trust_remote_code,
+                         encoder=encoder, tokenizer=tokenizer)
         self.default_threshold = default_threshold
         self.min_predictions = min_predictions
         self.max_predictions = max_predictions

@@ -253,19 +253,21 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
     int* cuL = reinterpret_cast<int*>(T + kAtRows * kAtLd);
     const int sb = at.tile_seq[bm], se = at.tile_seq[bm + 1], nseq = se - sb;    // (wave-uniform)
     for (int i = wave * 64 + lane; i <= nseq; i += NW * 64) cuL[i] = at.cu[sb + i];
-    // rows [row_a, row_b) of the tile -> their place in the fp32 qkv buffer (q | k | v blocks H apart); one wave, 256-byte runs
-    // (sc1 stores when another workgroup of THIS launch will read them: write-through, visible across the XCDs' L2s)
+    // rows [row_a, row_b) of the tile -> their place in the fp32 qkv buffer (q | k | v blocks H apart); one wave: lanes 0 .. 47 move one
+    // 16-byte piece of a row each (part = lane / 16).  With the in-launch exchange the stores are sc1 (write-through: visible across
+    // the XCDs' L2s) THROUGH A BUFFER DESCRIPTOR -- ordinary stores to the compiler, issued back to back; as relaxed atomics they were
+    // kept in program order with a wait after each one, ~0.7 us per access on the critical path of the tile's last wave.
     const bool xchg = at.exchange != nullptr;
+    const __amdgpu_buffer_rsrc_t rq = acp::make_rsrc(at.qkv, 0xffffffffu);
+    const int xpart = lane >> 4, xc4 = lane & 15;
+    auto qkv_byte_off = [&](int row) { return (unsigned)((((int64_t)row * 3 + xpart) * H + head * 64 + 4 * xc4) * 4); };
     auto spill_rows = [&](int row_a, int row_b, int lo_r) {
-        for (int row = row_a; row < row_b; ++row) {
-            const float* src = T + (row - m0 - lo_r) * kAtLd;
-            float* dst = at.qkv + (int64_t)row * (3 * H) + head * 64;
-#pragma unroll
-            for (int part = 0; part < 3; ++part) {
-                if (xchg) acp::st_sc1(dst + part * H + lane, src[part * 64 + lane]);
-                else dst[part * H + lane] = src[part * 64 + lane];
+        if (lane < 48)
+            for (int row = row_a; row < row_b; ++row) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(T + (row - m0 - lo_r) * kAtLd + xpart * 64 + 4 * xc4);
+                if (xchg) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(acp::u32x4_t, v), rq, qkv_byte_off(row), 0, 16);
+                else *reinterpret_cast<f32x4*>(at.qkv + (int64_t)row * (3 * H) + xpart * H + head * 64 + 4 * xc4) = v;
             }
-        }
     };
     // the rows [row_a, row_b) of the NEXT row tile (published there by its top-part spill) -> this pass's staging rows; one wave
     auto pull_rows = [&](int row_a, int row_b, int lo_r) -> bool {
@@ -283,11 +285,22 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        for (int row = row_a; row < row_b; ++row) {
-            float* dst = T + (row - m0 - lo_r) * kAtLd;
-            const float* src = at.qkv + (int64_t)row * (3 * H) + head * 64;
+        if (lane < 48) {
+            constexpr int RB = 8;                                       // rows in flight per batch of sc1 (L2-bypassing) loads
+            for (int r0b = row_a; r0b < row_b; r0b += RB) {
+                acp::u32x4_t v[RB];
 #pragma unroll
-            for (int part = 0; part < 3; ++part) dst[part * 64 + lane] = ok ? acp::ld_sc1(src + part * H + lane) : __uint_as_float(0x7fc00000u);
+                for (int u = 0; u < RB; ++u) {
+                    const int row = r0b + u < row_b ? r0b + u : row_b - 1;
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rq, qkv_byte_off(row), 0, 16);
+                }
+#pragma unroll
+                for (int u = 0; u < RB; ++u)
+                    if (r0b + u < row_b) {
+                        const acp::u32x4_t w = ok ? v[u] : acp::u32x4_t{0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u};
+                        *reinterpret_cast<acp::u32x4_t*>(T + (r0b + u - m0 - lo_r) * kAtLd + xpart * 64 + 4 * xc4) = w;
+                    }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
