@@ -50,10 +50,11 @@ struct PipeParams {
 };
 
 // shader-clock stamp `i` of this workgroup (wave 0 only; a wave-uniform branch on a kernel argument)
+template <int STRIDE = 4>
 __device__ __forceinline__ void stamp(const PipeParams& prm, int wave, int i) {
     if (prm.stamps && wave == 0) {
         const unsigned long long t = clock64();
-        if ((threadIdx.x & 63) == 0) prm.stamps[(size_t)blockIdx.x * 4 + i] = t;
+        if ((threadIdx.x & 63) == 0) prm.stamps[(size_t)blockIdx.x * STRIDE + i] = t;
     }
 }
 
@@ -306,7 +307,19 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
         __builtin_amdgcn_wave_barrier();
         return ok != 0;
     };
-    for (int lo_r = 0; lo_r < BM; lo_r += stride) {
+    // diagnostic (ac_gemm_debug_stamps + AC_GEMM_STAMP_EPI=8): wave 0's clock at every pass boundary, slots 4 + 3 pass + {0, 1, 2} of
+    // this workgroup's 16 (slots 0 .. 3 are the kernel's own: start, ring filled, k-loop done, end)
+    // (compiled only into measurement builds, -DAC_QKV_ATTN_STAMPS: the kernel sits at its register limit and the extra live values
+    //  of the stamps make hipcc spill -- tests/test_kernel_resources_cpu.py refuses scratch in the shipping build)
+    auto xstamp = [&](int i) {
+#ifdef AC_QKV_ATTN_STAMPS
+        if (prm.stamps && wave == 0 && lane == 0 && i < 16) prm.stamps[(size_t)blockIdx.x * 16 + i] = clock64();
+#else
+        (void)i;
+#endif
+    };
+    int pass_i = 0;
+    for (int lo_r = 0; lo_r < BM; lo_r += stride, ++pass_i) {
         if (m0 + lo_r >= prm.M) break;                                  // (workgroup-uniform: the ragged last tile)
         // this pass's rows of the accumulators (+ bias: the operation order of the unfused epilogue) -> LDS, row-major
 #pragma unroll
@@ -321,6 +334,7 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
             }
         }
         __syncthreads();
+        xstamp(4 + 3 * pass_i);
         const int seq_lo = m0 + lo_r;
         const int seq_hi = seq_lo + stride < tile_end ? seq_lo + stride : tile_end;
         int s0 = 0;                                                     // first of the tile's sequences that starts at or after seq_lo
@@ -355,7 +369,9 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
                 spill_rows(r0, tile_end, lo_r);                         // it continues in the next tile: the boundary launch serves it
             }
         }
+        xstamp(5 + 3 * pass_i);
         __syncthreads();                                                // (the next pass overwrites the staging rows)
+        xstamp(6 + 3 * pass_i);
     }
 }
 
@@ -376,7 +392,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
     const int bn = tile % ntn, bm = tile / ntn;
     const int m0 = bm * BM, n0 = bn * BN;
     const int nk = prm.K / PSBK;
-    stamp(prm, wave, 0);
+    stamp<(EPI == EPI_QKV_ATTN ? 16 : 4)>(prm, wave, 0);
     float lnres[EPI == EPI_BIAS_RES_LN ? TM * TN * 16 : 1];
     if constexpr (EPI == EPI_BIAS_RES_LN) ln_prefetch_residual<TM, TN, WMW, WNW>(lnres, prm, m0, n0, wm, wn, lane);
 
@@ -481,7 +497,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    stamp(prm, wave, 1);
+    stamp<(EPI == EPI_QKV_ATTN ? 16 : 4)>(prm, wave, 1);
 
     if constexpr (PIPE != 0) {
         Frags F0, F1;
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
         }
     }
     wait_vm<0>();                                                       // the over-issued tail stages: LDS is about to be reused / released
-    stamp(prm, wave, 2);
+    stamp<(EPI == EPI_QKV_ATTN ? 16 : 4)>(prm, wave, 2);
     if constexpr (AR == 2) {                                            // operands were x 2^6 and w 2^10
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -556,7 +572,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
     } else {
         store_tile<EPI, TM, BM, TN>(acc, prm.C, prm.ldc, prm.M, prm.N, m0, n0, wm, wn, lane, prm.epi);
     }
-    if (prm.stamps) { wait_vm<0>(); stamp(prm, wave, 3); }
+    if (prm.stamps) { wait_vm<0>(); stamp<(EPI == EPI_QKV_ATTN ? 16 : 4)>(prm, wave, 3); }
 }
 
 std::atomic<int> g_krot{-1};                  // ac_gemm_set_krot (-1 = environment AC_GEMM_KROT, default off)
@@ -584,7 +600,8 @@ int launch_one(PipeParams p, hipStream_t stream) {
     if (ac::first_call_on_device(attr_set))
         AC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE, AR>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    p.stamps = (g_stamps && tiles <= g_stamp_cap) ? g_stamps : nullptr;
+    static const int stamp_epi = [] { const char* e = getenv("AC_GEMM_STAMP_EPI"); return e ? atoi(e) : -1; }();   // only this epilogue class stamps
+    p.stamps = (g_stamps && tiles <= g_stamp_cap && (stamp_epi < 0 || stamp_epi == EPI)) ? g_stamps : nullptr;
     p.krot = krot_enabled();
     hipLaunchKernelGGL((gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE, AR>), dim3((unsigned)tiles), dim3(64 * WMW * WNW), lds, stream, p);
     AC_LAUNCH_CHECK();
