@@ -54,7 +54,7 @@ struct LnFuse {
 // a sequence that straddles a row-tile boundary go to `qkv` (fp32 [T, 3H]) for attention_mfma_kernel's boundary mode.
 struct AttnFuse {
     const int32_t* cu;      // [b + 1] first row of every sequence, cu[b] = T (ac_bert_pack)
-    const int32_t* tile_seq;// [ceil(T / 256) + 1] first sequence that starts at or after row 256 t (qkv_attn_tile_seq), last = b
+    const int32_t* tile_seq;// [ceil(T / 256)][264]: per row tile, the sequences that start in it and their first rows (qkv_attn_tile_seq)
     int b, H, smax;         // sequences, hidden size (= heads * 64), longest sequence (<= 64)
     float scale;            // 1 / sqrt(head dim)
     uint16_t* ctx_planes;   // [planes][H / 8][T][8]

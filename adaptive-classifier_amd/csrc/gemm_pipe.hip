@@ -236,24 +236,20 @@ constexpr int kAtBytes = kAtRows * kAtLd * 4 + kAtCu * 4;
 
 template <int TM, int TN, int WMW, int WNW, int AR>
 __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], const PipeParams& prm, int bm, int head, int wm, int wn,
-                                                       int lane, int wave, float* T) {
+                                                       int lane, int wave, float* T, int cu_pref, const float (&bias)[TN]) {
     static_assert(TM == 2 && TN == 3 && WMW == 4 && WNW == 2, "built for the 256 x 192 tile (8 waves of 64 x 96)");
     constexpr int BM = 256, NW = WMW * WNW;
     const AttnFuse& at = prm.at;
     const int m0 = bm * BM, H = at.H, c = lane & 31;
-    float bias[TN];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int col = wn * 96 + ni * 32 + c;                          // column of the head's q | k | v block
-        bias[ni] = prm.epi.bias[(col >> 6) * H + head * 64 + (col & 63)];
-    }
     const int stride = at.smax <= 32 ? 128 : 96;                        // + round_up(smax, 32) = 160 staged rows
     const int tile_end = m0 + BM < prm.M ? m0 + BM : prm.M;
     // the offsets of the sequences that start inside this tile (+ the one after them) -> LDS, ONE dependent global load for the
     // whole epilogue (a binary search over cu in HBM / L2 per pass and two loads per sequence cost ~5 k cycles per tile)
-    int* cuL = reinterpret_cast<int*>(T + kAtRows * kAtLd);
-    const int sb = at.tile_seq[bm], se = at.tile_seq[bm + 1], nseq = se - sb;    // (wave-uniform)
-    for (int i = wave * 64 + lane; i <= nseq; i += NW * 64) cuL[i] = at.cu[sb + i];
+    // (the tile's row of the per-forward table -- [0] = sequences that start in the tile, [1 + i] = the first row of the i-th of them,
+    //  one more = the end of the last -- was requested before the k-loop, one word per thread: no global latency in this epilogue)
+    int* cuT = reinterpret_cast<int*>(T + kAtRows * kAtLd);
+    if (wave * 64 + lane < kAtCu) cuT[wave * 64 + lane] = cu_pref;
+    const int* cuL = cuT + 1;
     // rows [row_a, row_b) of the tile -> their place in the fp32 qkv buffer (q | k | v blocks H apart); one wave: lanes 0 .. 47 move one
     // 16-byte piece of a row each (part = lane / 16).  With the in-launch exchange the stores are sc1 (write-through: visible across
     // the XCDs' L2s) THROUGH A BUFFER DESCRIPTOR -- ordinary stores to the compiler, issued back to back; as relaxed atomics they were
@@ -335,6 +331,7 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
         }
         __syncthreads();
         xstamp(4 + 3 * pass_i);
+        const int nseq = cuT[0];
         const int seq_lo = m0 + lo_r;
         const int seq_hi = seq_lo + stride < tile_end ? seq_lo + stride : tile_end;
         int s0 = 0;                                                     // first of the tile's sequences that starts at or after seq_lo
@@ -395,6 +392,18 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
     stamp<(EPI == EPI_QKV_ATTN ? 16 : 4)>(prm, wave, 0);
     float lnres[EPI == EPI_BIAS_RES_LN ? TM * TN * 16 : 1];
     if constexpr (EPI == EPI_BIAS_RES_LN) ln_prefetch_residual<TM, TN, WMW, WNW>(lnres, prm, m0, n0, wm, wn, lane);
+    // EPI_QKV_ATTN: what the epilogue needs from global memory -- this thread's word of the tile's sequence table and its three bias
+    // values -- is requested here, ahead of every DMA (older than them on the vmcnt queue), so the epilogue starts without a miss
+    int at_cu_pref = 0;
+    float at_bias[EPI == EPI_QKV_ATTN ? TN : 1];
+    if constexpr (EPI == EPI_QKV_ATTN) {
+        if (tid < kAtCu) at_cu_pref = prm.at.tile_seq[(size_t)bm * kAtCu + tid];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = wn * (32 * TN) + ni * 32 + (lane & 31);          // column of the head's q | k | v block
+            at_bias[ni] = prm.epi.bias[(col >> 6) * prm.at.H + bn * 64 + (col & 63)];
+        }
+    }
 
     // ---- DMA stream: piece j = wave + NW t -> (plane j / RG, group j % RG); lane (i, kg) copies 16 B of row i, k-slot kg
     const uint16_t* pp[PPW];
@@ -562,7 +571,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                                   // the ring becomes the attention's staging area
         __builtin_amdgcn_sched_barrier(0);
-        qkv_attention_epilogue<TM, TN, WMW, WNW, AR>(acc, prm, bm, bn, wm, wn, lane, wave, reinterpret_cast<float*>(lds));
+        if constexpr (EPI == EPI_QKV_ATTN)
+            qkv_attention_epilogue<TM, TN, WMW, WNW, AR>(acc, prm, bm, bn, wm, wn, lane, wave, reinterpret_cast<float*>(lds), at_cu_pref, at_bias);
     } else if (C_PLANES) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                                   // nobody's DMA may land in the transpose scratch
@@ -767,19 +777,23 @@ bool qkv_attn_applies(int M, int H, int heads, int smax) {
     return arith_split() && gemm_variant() == 0 && M >= 192 && heads >= 1 && H == heads * 64 && (H % 32) == 0 && H >= 64 &&
            smax >= 1 && smax <= 64 && pipe_choose(M, 3 * H, H, EPI_BIAS, false) != 0;      // (a table that switches the ring kernels off)
 }
-// tile_seq[t] = the first sequence that starts at or after row 256 t, t = 0 .. ceil(T / 256) (the last entry = b): once per forward
-__global__ __launch_bounds__(64) void qkv_attn_tile_seq_kernel(const int32_t* __restrict__ cu, int b, int ntiles, int32_t* __restrict__ out) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t > ntiles) return;
-    const int row = t * kQkvAttnRows;
-    int lo = 0, hi = b;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cu[mid] < row) lo = mid + 1; else hi = mid; }
-    out[t] = t == ntiles ? b : lo;
+// The per-forward sequence table of the attention epilogue: row t (kAtCu words) describes row tile t = rows [256 t, 256 t + 256):
+// [0] = n = the sequences that START in it, [1 + i] = the first row of the i-th of them (i < n), [1 + n] = the first row of the next
+// sequence (= T after the last one).  Built once per forward (cu is the same for every layer); a tile reads its row with one load
+// per thread.
+__global__ __launch_bounds__(kAtCu) void qkv_attn_tile_seq_kernel(const int32_t* __restrict__ cu, int b, int ntiles, int32_t* __restrict__ out) {
+    const int t = blockIdx.x, i = threadIdx.x;
+    auto first_at_or_after = [&](int row) { int lo = 0, hi = b; while (lo < hi) { const int mid = (lo + hi) >> 1; if (cu[mid] < row) lo = mid + 1; else hi = mid; } return lo; };
+    const int sb = first_at_or_after(t * kQkvAttnRows), se = first_at_or_after((t + 1) * kQkvAttnRows), n = se - sb;
+    int v = 0;
+    if (i == 0) v = n;
+    else if (i - 1 <= n) v = cu[sb + i - 1];                          // (sb + n <= b: cu has b + 1 entries)
+    out[(size_t)t * kAtCu + i] = v;
 }
-size_t qkv_attn_tile_seq_bytes(int M) { return ((size_t)(M + kQkvAttnRows - 1) / kQkvAttnRows + 1) * sizeof(int32_t); }
+size_t qkv_attn_tile_seq_bytes(int M) { return ((size_t)(M + kQkvAttnRows - 1) / kQkvAttnRows) * kAtCu * sizeof(int32_t); }
 int qkv_attn_tile_seq(const int32_t* cu, int b, int M, int32_t* tile_seq, hipStream_t stream) {
     const int ntiles = (M + kQkvAttnRows - 1) / kQkvAttnRows;
-    hipLaunchKernelGGL(qkv_attn_tile_seq_kernel, dim3((ntiles + 64) / 64), dim3(64), 0, stream, cu, b, ntiles, tile_seq);
+    hipLaunchKernelGGL(qkv_attn_tile_seq_kernel, dim3(ntiles), dim3(kAtCu), 0, stream, cu, b, ntiles, tile_seq);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
