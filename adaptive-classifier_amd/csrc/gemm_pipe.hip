@@ -610,8 +610,11 @@ int launch_one(PipeParams p, hipStream_t stream) {
     if (ac::first_call_on_device(attr_set))
         AC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE, AR>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    static const int stamp_epi = [] { const char* e = getenv("AC_GEMM_STAMP_EPI"); return e ? atoi(e) : -1; }();   // only this epilogue class stamps
-    p.stamps = (g_stamps && tiles <= g_stamp_cap && (stamp_epi < 0 || stamp_epi == EPI)) ? g_stamps : nullptr;
+    // AC_GEMM_STAMP_EPI / AC_GEMM_STAMP_K (read at every launch: a probe switches them between forwards): only launches of this
+    // epilogue class / inner dimension stamp, so one GEMM of a whole forward can be looked at in place
+    const char* se = g_stamps ? getenv("AC_GEMM_STAMP_EPI") : nullptr;
+    const char* sk = g_stamps ? getenv("AC_GEMM_STAMP_K") : nullptr;
+    p.stamps = (g_stamps && tiles <= g_stamp_cap && (!se || atoi(se) == EPI) && (!sk || atoi(sk) == p.K)) ? g_stamps : nullptr;
     p.krot = krot_enabled();
     hipLaunchKernelGGL((gemm_pipe_nt<EPI, TM, TN, WMW, WNW, NS, CP, PIPE, AR>), dim3((unsigned)tiles), dim3(64 * WMW * WNW), lds, stream, p);
     AC_LAUNCH_CHECK();
