@@ -48,10 +48,10 @@ int set_persistent_mask(int m) { const int old = g_persistent; if (m >= 0) g_per
 // sweeps' grids (knn_l2.hip) -- is a statement about co-residency: grid <= workgroups per CU x CUs.  hipDeviceProp's
 // multiProcessorCount is the CHIP's CU count; under HSA_CU_MASK / ROC_GLOBAL_CU_MASK the process's queues reach fewer, and a
 // grid sized for 256 would wait for workgroups that are not resident (the bounded waits then give up into NaN rows and the host
-// repeats the call unfused: correct, but discovered by failure).  So the count is MEASURED once per device: a probe launch of
-// 8 x CUs short workgroups (<= 4 resident per CU by LDS) each reports the (XCC, SE, SH, CU) it ran on; the number of distinct
-// places is what dev_info().cus reports and what every such decision uses.  A mask on a caller's own stream
-// (hipExtStreamCreateWithCUMask) cannot be seen from here: such a caller sets AC_ACTIVE_CUS.
+// repeats the call unfused: correct, but discovered by failure).  So, when the environment carries a CU mask, the count is
+// MEASURED once per device: a probe launch of 8 x CUs short workgroups (<= 4 resident per CU by LDS) each reports the (XCC, SE,
+// SH, CU) it ran on; the number of distinct places is what dev_info().cus reports and what every such decision uses.  A mask on a
+// caller's own stream (hipExtStreamCreateWithCUMask) cannot be seen from here: such a caller sets AC_ACTIVE_CUS.
 namespace {
 __global__ __launch_bounds__(256) void cu_probe_kernel(unsigned* __restrict__ out) {
     __shared__ unsigned pad[10 * 1024];                                  // 40 KB: at most 4 of these per CU, so the grid spreads out
@@ -66,6 +66,12 @@ std::atomic<int> g_active_cus[64];                                       // per 
 
 int measure_active_cus(int hw_cus) {
     if (const char* e = getenv("AC_ACTIVE_CUS")) { const int v = atoi(e); if (v >= 1) return v < hw_cus ? v : hw_cus; }
+    // Only a process whose queues are restricted needs the measurement; without a mask in the environment the chip's count stands.
+    // (A probe that shares the device with work already in flight -- the caller's own kernels on another stream -- can find CUs
+    //  full and undercount: seen once as 255 of 256 next to a 30 GB generator kernel.  So the masked case also waits for the device
+    //  to drain first; it is a one-time cost per process and device.)
+    if (!getenv("HSA_CU_MASK") && !getenv("ROC_GLOBAL_CU_MASK")) return hw_cus;
+    (void)hipDeviceSynchronize();
     const int blocks = 8 * hw_cus;
     unsigned* d = nullptr;
     hipStream_t st = nullptr;

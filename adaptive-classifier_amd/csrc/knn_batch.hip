@@ -558,12 +558,14 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
     const int per_xcd = nblk / 8;
     const int nqt_all = (int)(p.q_rows / BBN);
     // up to 4 query tiles share an XCD (their plane stays in its L2); at most 8 such sets per launch
-    for (int t0 = 0; t0 < nqt_all; t0 += 32) {
-        const int nqt = nqt_all - t0 < 32 ? nqt_all - t0 : 32;
-        static const int b_env = getenv("AC_KNN_BATCH_B") ? atoi(getenv("AC_KNN_BATCH_B")) : 0;      // A/B: query tiles per XCD
-        int b = nqt >= 4 ? 4 : (nqt >= 2 ? 2 : 1);
-        if (b_env == 8 && nqt >= 8) b = 8;
-        while (per_xcd % b) b >>= 1;
+    static const int b_env = getenv("AC_KNN_BATCH_B") ? atoi(getenv("AC_KNN_BATCH_B")) : 0;      // A/B: query tiles per XCD
+    int bdiv = b_env == 8 ? 8 : 4;                                  // query tiles one XCD's share of the grid can be split over:
+    while (per_xcd % bdiv) bdiv >>= 1;                              // a power of two that divides it (an odd share -- a CU mask -- gives 1)
+    const int chunk = 8 * bdiv;                                     // query tiles per launch (8 XCDs x bdiv)
+    for (int t0 = 0; t0 < nqt_all; t0 += chunk) {
+        const int nqt = nqt_all - t0 < chunk ? nqt_all - t0 : chunk;
+        int b = bdiv;
+        while (b > 1 && b > nqt) b >>= 1;
         int sets = 1;
         while (sets * b < nqt) sets <<= 1;
         AC_REQUIRE(sets <= 8, AC_EUNSUPPORTED, "knn batch: %d query tiles do not fit 8 XCDs x %d", nqt, b);

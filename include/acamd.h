@@ -40,9 +40,9 @@ typedef void* ac_stream_t;
 const char* ac_last_error(void);
 int ac_version(void);                 /* 100*major + minor */
 int ac_device_info(int* cu_count, int* lds_bytes_per_block, size_t* hbm_bytes);
-/* chip_cus = the device's CU count; active_cus = the CUs this process's workgroups can actually land on -- measured once per device
- * by a probe launch (fewer than chip_cus under HSA_CU_MASK / ROC_GLOBAL_CU_MASK; env AC_ACTIVE_CUS overrides, for callers whose
- * own stream carries a CU mask).  cu_count of ac_device_info is active_cus: every co-residency decision of the library (persistent
+/* chip_cus = the device's CU count; active_cus = the CUs this process's workgroups can actually land on: chip_cus, unless the
+ * environment carries HSA_CU_MASK / ROC_GLOBAL_CU_MASK -- then it is MEASURED once per device by a probe launch (after a device
+ * synchronise); env AC_ACTIVE_CUS overrides, for callers whose own stream carries a CU mask.  cu_count of ac_device_info is active_cus: every co-residency decision of the library (persistent
  * kernels' grids, the fused-LayerNorm exchange, one-round tile choice, sweep grids) is made against it, i.e. a fused / persistent
  * path whose workgroups could not all be resident is NOT SELECTED, instead of selected and abandoned by a bounded wait. */
 int ac_device_cus(int* chip_cus, int* active_cus);
