@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
         }
         uint4 H;
         H.x = pack_f16(v[0], v[1]); H.y = pack_f16(v[2], v[3]); H.z = pack_f16(v[4], v[5]); H.w = pack_f16(v[6], v[7]);
-        // tile_major (store and, since round 6, queries): plane[row / 256][k-slot][row % 256][8] -- a 256-row tile is ONE
+        // queries: plane[k-slot][row][8].  store (tile_major): plane[row / 256][k-slot][row % 256][8] -- a 256-row tile is ONE
         // contiguous run of 256 * Kp * 2 bytes (k-slot-major inside), so a sweep streams the store front to back
         const int64_t at = tile_major ? (((row >> 8) * nslot + q) << 8) + (row & 255) : (int64_t)q * rows_pad + row;
         *reinterpret_cast<uint4*>(plane + at * 8) = H;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
 struct BatchParams {
     const uint16_t* Pp; int64_t p_rows;      // store plane [p_rows / 256][Kp/8][256][8] fp16 (tile-major)
     const float* pnorm;                      // [p_rows]: |p|^2, +inf past N
-    const uint16_t* Qp; int64_t q_rows;      // query plane [q_rows / 256][Kp/8][256][8] (tile-major), q_rows = round_up(nq, 256)
+    const uint16_t* Qp; int64_t q_rows;      // query plane, q_rows = round_up(nq, 256)
     const float* thr;                        // [q_rows]
     const float* qfac;                       // [q_rows]
     int64_t N;                               // LOGICAL rows swept: logical row i is store row (i >> 3) * 8 * row_stride + (i & 7)
@@ -193,11 +193,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
     // ---- DMA stream.  Wave w stages store groups w + NWV t and query groups w + NWV t, both chunks.
     //      A piece = 32 rows x 2 k-slots: lane (i32, kg) copies the 16 B of row i32, k-slot 4 s + 2 c + kg.
     //      Store plane (tile-major): k-slot s of row r sits at ((r / 256 * nslot + s) * 256 + r % 256) * 16 bytes.
-    //      Query plane: tile-major too since round 6 ([q / 256][k-slot][q % 256][8]).  As [k-slot][q_rows][8] the 96 k-slot runs
-    //      of one query tile sat q_rows * 16 bytes apart -- 64 KB at 4096 queries, a power of two: one L2 channel held the whole
-    //      393 KB tile that every row tile re-reads, and it did not stay (profiles/r06/knn_batch_qplane_pmc.json).
-    const int64_t a_step = 4 * 256 * 8, w_step = 4 * 256 * 8;
-    const int64_t a_c1 = 2 * 256 * 8, w_c1 = 2 * 256 * 8;                   // chunk 1 = two k-slots further
+    const int64_t a_step = 4 * 256 * 8, w_step = 4 * prm.q_rows * 8;
+    const int64_t a_c1 = 2 * 256 * 8, w_c1 = 2 * prm.q_rows * 8;          // chunk 1 = two k-slots further
     const int nslot_p = prm.Kp >> 3;
     const uint16_t* pa[GPW];
     const uint16_t* pw[GPW];
@@ -214,7 +211,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
     auto w_base = [&]() {
 #pragma unroll
         for (int t = 0; t < GPW; ++t)
-            pw[t] = prm.Qp + ((((int64_t)qt * nslot_p + kg) << 8) + 32 * (wave + NWV * t) + i32) * 8;
+            pw[t] = prm.Qp + ((int64_t)kg * prm.q_rows + ((int64_t)qt * BBN + 32 * (wave + NWV * t) + i32)) * 8;
     };
     a_base(0); w_base();
     int st_it = 0, st_k = 0, st_slot = 0;                   // unit / ring slot the next issue() loads
@@ -529,7 +526,7 @@ int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t l
     const int Kp = knn_kp(D);
     const int64_t qp = ((int64_t)nq + 255) / 256 * 256;
     hipLaunchKernelGGL(knn_plane_kernel, dim3((unsigned)((qp + 3) / 4)), dim3(256), 0, stream, Q, ldQ, (int64_t)nq, qp, D, Kp,
-                       maxnorm_bits, 1, qplane, sampleD, kp, gamma, thr, qfac, (float*)nullptr, 1, zero_ints, zero_count, (int64_t)0);
+                       maxnorm_bits, 1, qplane, sampleD, kp, gamma, thr, qfac, (float*)nullptr, 0, zero_ints, zero_count, (int64_t)0);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
@@ -574,7 +571,7 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
         AC_REQUIRE(sets <= 8, AC_EUNSUPPORTED, "knn batch: %d query tiles do not fit 8 XCDs x %d", nqt, b);
         p.nqt = nqt; p.b = b; p.sets = sets;
         const size_t qoff = (size_t)t0 * BBN;
-        p.Qp = Qp + (size_t)t0 * (p.Kp >> 3) * 256 * 8;             // tile-major plane: query tile t0 is one contiguous run
+        p.Qp = Qp + qoff * 8;                                       // plane[k/8][q_rows][8]: tile t0 starts at row t0 * 256 of every k-slot
         p.thr = thr + qoff; p.qfac = qfac + qoff;
         p.cand_d = cand_d + qoff * cap; p.cand_i = cand_i + qoff * cap; p.cand_cnt = cand_cnt + qoff * segs;
         p.clear_ctr = t0 == 0 ? clear_ctr : nullptr; p.clear_stats = t0 == 0 ? clear_stats : nullptr;

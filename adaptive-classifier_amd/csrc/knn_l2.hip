@@ -674,7 +674,7 @@ __global__ __launch_bounds__(kThreads, 2) void knn_sweep_ring(SweepParams prm) {
 struct PlaneSweepParams {
     const uint16_t* Pp;       // store plane, tile-major (knn_batch.hip knn_plane_kernel)
     const float* pnorm;       // [round_up(N, 256)] |p|^2, +inf past N
-    const uint16_t* Qp;       // query plane [Kp/8][q_rows][8] (q_rows = 256 here: the tile-major plane of knn_prepare_queries with ONE tile)
+    const uint16_t* Qp;       // query plane [Kp/8][q_rows][8]
     int64_t q_rows;
     const float* qfac;        // [q_rows] -2 2^(e_p + e_q)
     int64_t N;
