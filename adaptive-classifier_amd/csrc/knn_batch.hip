@@ -160,9 +160,10 @@ template <int N> __device__ __forceinline__ void bwait_vm() { asm volatile("s_wa
 //            builds, exact, 1.5x slower under hipcc's schedule -- kept as a template argument, not instantiated.
 // BURST: the form for short launches -- sample stages (row_stride > 1, best_only) and sweeps of small stores (segmented
 // lists); BURST = false is the plain whole-store sweep with one list per query that long launches run.
-// NT: the store plane's DMA carries the non-temporal bit -- its lines pass through the XCD's L2 as streaming data, so the b query
-// tiles' planes (b x 393 KB at D = 768, re-read for every row tile) are what stays resident (round 6, with b = 8: see knn_batch_launch)
-template <int BNS, int NWV, bool BURST, bool NT = false>        // ring depth, waves
+// (Measured and dropped in round 6, profiles/r06/knn_batch_nt_pmc_rejected.json, knn_batch_qplane_pmc_rejected.json: the store
+//  plane's DMA with the non-temporal bit -- the workgroups that share a row tile then each fetch it themselves, 159 / 130 GB of
+//  fabric reads at 4096 x 10M against 75 / 80 -- and a tile-major QUERY plane, 106 / 90 GB.)
+template <int BNS, int NWV, bool BURST>        // ring depth, waves
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams prm) {
     constexpr int WMW = NWV / 2, TM = BBM / (32 * WMW), TN = 4;    // wave grid WMW x 2, wave tile (32 TM) x 128
     constexpr int GPW = BGA / NWV;                                  // store / query groups each wave stages
@@ -220,9 +221,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
 #pragma unroll
         for (int t = 0; t < GPW; ++t) {
             const int ga = wave + NWV * t;
-            __builtin_amdgcn_global_load_lds((glb_void_t*)pa[t], (lds_void_t*)(dst + (0 * BRG + ga) * 64), 16, 0, NT ? 2 : 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)pa[t], (lds_void_t*)(dst + (0 * BRG + ga) * 64), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_void_t*)pw[t], (lds_void_t*)(dst + (0 * BRG + BGA + ga) * 64), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(pa[t] + a_c1), (lds_void_t*)(dst + (1 * BRG + ga) * 64), 16, 0, NT ? 2 : 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(pa[t] + a_c1), (lds_void_t*)(dst + (1 * BRG + ga) * 64), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_void_t*)(pw[t] + w_c1), (lds_void_t*)(dst + (1 * BRG + BGA + ga) * 64), 16, 0, 0);
         }
         st_slot = st_slot + 1 == BNS ? 0 : st_slot + 1;
@@ -576,12 +577,8 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
         p.cand_d = cand_d + qoff * cap; p.cand_i = cand_i + qoff * cap; p.cand_cnt = cand_cnt + qoff * segs;
         p.clear_ctr = t0 == 0 ? clear_ctr : nullptr; p.clear_stats = t0 == 0 ? clear_stats : nullptr;
         const dim3 grid((unsigned)nblk), block(64 * nwv);
-        static const int nt_env = getenv("AC_KNN_BATCH_NT") ? atoi(getenv("AC_KNN_BATCH_NT")) : 0;   // A/B: non-temporal store-plane DMA
         if (segs > 1 || p.row_stride > 1 || best_only) hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, true>), grid, block, lds, stream, p);
-        else if (nt_env) {
-            AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, false, true>), grid, block, lds, stream, p);
-        } else hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, false>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, false>), grid, block, lds, stream, p);
         AC_LAUNCH_CHECK();
     }
     return AC_OK;
