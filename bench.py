@@ -83,7 +83,7 @@ def make_classifier(dev, rank, world):
     lo, hi = shard_bounds(NPROTO, world, rank)
     rows = ix.synth_unit_rows(hi - lo, DIM, 1, row_offset=lo, device=dev)          # this rank's row shard
     row_labels = torch.arange(NPROTO, dtype=torch.int32) % NCLASS                  # replicated row->class map
-    sharded = ShardedSearch(rows, hi - lo, DIM, lo, equal_blocks=True) if world > 1 else None      # 256 texts on every rank
+    sharded = ShardedSearch(rows, hi - lo, DIM, lo, block_rows=BATCH) if world > 1 else None      # 256 texts on every rank: the fixed-batch path
     clf.memory.load_rows(rows, row_labels, labels, sharded=sharded)
     return clf, hf
 
@@ -1108,7 +1108,7 @@ def cfg4_multi(dev, rank, world, steps, warmup):
     lo, hi = shard_bounds(NP_, world, rank)
     rows = ix.synth_unit_rows(hi - lo, D, 1, row_offset=lo, device=dev)
     clf.memory.load_rows(rows, torch.arange(NP_, dtype=torch.int32) % C, labels,
-                         sharded=ShardedSearch(rows, hi - lo, D, lo, equal_blocks=True))
+                         sharded=ShardedSearch(rows, hi - lo, D, lo, block_rows=B // world))
     b = B // world
     g = torch.Generator().manual_seed(1234 + rank)
     ids = torch.randint(1000, VOCAB, (b, S), generator=g); ids[:, 0] = 101
