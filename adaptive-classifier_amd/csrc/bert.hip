@@ -356,32 +356,6 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     for (int c = lane; c < (H >> 2); c += 64) dst[c] = src[c];
 }
 
-// out[i, :] = row rows[i] (or i * S when rows == null) of a [T, H] matrix held as bf16x3 operand planes: h + m + l is the fp32 value
-// bit for bit (the CLS rows of the last layer's input when the fused layers keep the activations as planes only)
-__global__ __launch_bounds__(256) void gather_rows_planes_kernel(const uint16_t* __restrict__ planes, const int32_t* __restrict__ rows, int S,
-                                                                 int n, int64_t T, int H, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
-    const int64_t row = rows ? rows[i] : (int64_t)i * S;
-    const int64_t plane = T * (int64_t)H;
-    for (int q = lane; q < (H >> 3); q += 64) {                       // one k-slot (8 columns) per lane and step
-        const uint16_t* p = planes + ((int64_t)q * T + row) * 8;
-        const uint4 hh = *reinterpret_cast<const uint4*>(p), mm = *reinterpret_cast<const uint4*>(p + plane),
-                    ll = *reinterpret_cast<const uint4*>(p + 2 * plane);
-        const unsigned h4[4] = {hh.x, hh.y, hh.z, hh.w}, m4[4] = {mm.x, mm.y, mm.z, mm.w}, l4[4] = {ll.x, ll.y, ll.z, ll.w};
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[2 * e] = (__uint_as_float(h4[e] << 16) + __uint_as_float(m4[e] << 16)) + __uint_as_float(l4[e] << 16);
-            v[2 * e + 1] = (__uint_as_float(h4[e] & 0xffff0000u) + __uint_as_float(m4[e] & 0xffff0000u)) + __uint_as_float(l4[e] & 0xffff0000u);
-        }
-        float* dst = out + (int64_t)i * H + 8 * q;
-        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    }
-}
-
 struct BertWs {
     size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, cu, tile_seq, attn_xchg, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
     size_t lnctl_bytes, attn_xchg_bytes;
@@ -497,10 +471,6 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
                      ac::linear_f16x2_takes(T, 3 * H, H) && ac::linear_f16x2_takes(T, H, H) && ac::linear_f16x2_takes(T, I, H) &&
                      ac::linear_f16x2_takes(T, H, I);
     const bool fuse_ln = pl && c.layers > 1 && ac::pipe_ln_applies(T, H, H) && ac::pipe_ln_applies(T, H, I);
-    // Between two fused-LayerNorm launches the activations travel as bf16x3 planes ONLY (round 6): h + m + l is the fp32 value bit for
-    // bit, so the residual is rebuilt from the planes and the 15.8 MB fp32 copy per LayerNorm (5141 x 768) is neither written nor read;
-    // the CLS rows the last layer needs in fp32 are gathered from the planes.  (fp16x2 planes are rounded: that mode keeps the rows.)
-    const bool x_planes_only = fuse_ln && !f16;
     unsigned* ln_abort = (unsigned*)base;
     hipLaunchKernelGGL(ln_verdict_roll_kernel, dim3(1), dim3(1), 0, stream, ln_abort);
     AC_LAUNCH_CHECK();
@@ -553,12 +523,7 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         // ... and BEFORE it only K and V of every token and the Q of the CLS rows (round 5): the last QKV projection becomes a
         // [T, 2H] GEMM over the K | V rows of the fused weight (a third fewer flops of that GEMM) + a [b, H] one for Q
         const bool q_cls_only = last && T >= 4 * b;    // (short sequences: the split saves nothing worth two launches)
-        if (last && x_planes_only) {                   // the CLS rows (cu[s], or s * S unpacked) rebuilt from the planes
-            hipLaunchKernelGGL(gather_rows_planes_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, xp, cu, S, b, (int64_t)T, H, ffn);
-            AC_LAUNCH_CHECK();
-            resid = ffn;                               // compact CLS rows, staged in ffn (free until FFN1 writes it)
-            ldres = H;
-        } else if (last && cu) {                       // packed layout: the CLS rows sit at cu[s]; gather them
+        if (last && cu) {                              // packed layout: the CLS rows sit at cu[s]; gather them
             hipLaunchKernelGGL(gather_rows_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, x, cu, b, H, ffn);
             AC_LAUNCH_CHECK();
             resid = ffn;                               // compact CLS rows, staged in ffn (free until FFN1 writes it)
@@ -614,9 +579,8 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
         const int lblocks = (Ml + 3) / 4;
         const bool fl = fuse_ln && lp;                 // x <- LayerNorm(x + ctx Wo^T + b) in ONE launch, in place
         if (fl) {
-            rc = ac::launch_gemm_pipe_ln(ctxp, Ml, f16 ? w->ao_wh[l] : ao_w3, H, w->ao_b[l], x_planes_only ? nullptr : x, H,
-                                         x_planes_only ? nullptr : x, H, Ml, H, H, w->ln1_g[l], w->ln1_b[l], c.ln_eps, base + ws.lnpart,
-                                         ln_count + (size_t)(2 * l) * ln_panels, ln_abort, xp, stream, (int)f16, x_planes_only ? xp : nullptr);
+            rc = ac::launch_gemm_pipe_ln(ctxp, Ml, f16 ? w->ao_wh[l] : ao_w3, H, w->ao_b[l], x, H, x, H, Ml, H, H, w->ln1_g[l], w->ln1_b[l], c.ln_eps,
+                                         base + ws.lnpart, ln_count + (size_t)(2 * l) * ln_panels, ln_abort, xp, stream, (int)f16);
             if (rc) return rc;
         } else {
             // (last layer: b CLS rows = a handful of output tiles -> split-K over the qkv buffer, which is dead by now)
@@ -638,9 +602,8 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
                                           0.f, 0, ff1_w3, lp ? xp : nullptr, lp ? ffnp : nullptr));
         if (rc) return rc;
         if (fl) {                                      // x <- LayerNorm(x + ffn W2^T + b), planes for the next layer's QKV GEMM
-            rc = ac::launch_gemm_pipe_ln(ffnp, Ml, f16 ? w->ff2_wh[l] : ff2_w3, H, w->ff2_b[l], x_planes_only ? nullptr : x, H,
-                                         x_planes_only ? nullptr : x, H, Ml, H, I, w->ln2_g[l], w->ln2_b[l], c.ln_eps, base + ws.lnpart,
-                                         ln_count + (size_t)(2 * l + 1) * ln_panels, ln_abort, xp, stream, (int)f16, x_planes_only ? xp : nullptr);
+            rc = ac::launch_gemm_pipe_ln(ffnp, Ml, f16 ? w->ff2_wh[l] : ff2_w3, H, w->ff2_b[l], x, H, x, H, Ml, H, I, w->ln2_g[l], w->ln2_b[l], c.ln_eps,
+                                         base + ws.lnpart, ln_count + (size_t)(2 * l + 1) * ln_panels, ln_abort, xp, stream, (int)f16);
             if (rc) return rc;
             continue;
         }

@@ -92,8 +92,7 @@ int pipe_ln_panels(int M);
 int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias,
                         const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, const float* gamma,
                         const float* beta, float eps, void* part, unsigned* count, unsigned* abort_flag, uint16_t* planes,
-                        hipStream_t stream, int f16 = 0,       // f16: operands AND emitted planes are fp16x2
-                        const uint16_t* res_planes = nullptr); // bf16x3 planes of the residual (then `residual` may be null; C null = no fp32 rows)
+                        hipStream_t stream, int f16 = 0);      // f16: operands AND emitted planes are fp16x2
 // the [T, 3H] QKV projection of a PACKED batch with the self-attention in its epilogue (gemm_pipe.hip EPI_QKV_ATTN): context rows
 // go straight to `ctx_planes`; `qkv` (fp32 [T, 3H]) only receives the rows of sequences that straddle a 256-row tile boundary,
 // which the caller then serves with attention_mfma_kernel's boundary mode (boundary_stride = kQkvAttnRows)

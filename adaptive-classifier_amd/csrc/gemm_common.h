@@ -45,10 +45,6 @@ struct LnFuse {
     unsigned* abort_;       // set when a row panel's tiles did not all arrive (the results are NaN then)
     uint16_t* planes;       // [3][N/8][M][8] or null
     int starve;             // test hook (ac_gemm_set_ln_fusion(2)): wait for one arrival more than will ever come
-    // round 6: the residual read from its bf16x3 operand planes ([3][N/8][M][8]; may be `planes` itself -- every element is read at
-    // kernel start and written in the epilogue by the same workgroup) instead of from fp32 rows: h + m + l IS the fp32 value, bit for
-    // bit, so the fp32 copy of the activations (C == null: not written) is redundant between two fused launches
-    const uint16_t* res_planes;
 };
 
 // EPI_QKV_ATTN (gemm_pipe.hip): the [T, 3H] QKV projection with the self-attention of the packed sequences computed in the

@@ -97,40 +97,6 @@ __device__ __forceinline__ void ln_prefetch_residual(float (&res)[TM * TN * 16],
         }
 }
 
-// The same residual block from its bf16x3 operand planes (LnFuse.res_planes): the three terms of every element are loaded as fp32
-// values -- a bf16 is the upper half of the fp32 with the same value, so a 16-bit load into the high half of a zeroed register
-// (global_load_short_d16_hi) IS the conversion -- and kept apart until the epilogue adds them, (h + m) + l = the split's input bit
-// for bit.  No ALU touches them here: a sum at kernel start would make every launch wait out the loads' latency before its ring
-// prologue is even issued (measured in the listing: vmcnt(47) ... vmcnt(0) ahead of the first DMA).
-typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float bf16_bits_as_f32(const uint16_t* p) {
-    u16x2_t v = {0, 0};
-    v[1] = *p;
-    return __builtin_bit_cast(float, v);
-}
-template <int TM, int TN, int WMW, int WNW>
-__device__ __forceinline__ void ln_prefetch_residual_planes(float (&rh)[TM * TN * 16], float (&rm)[TM * TN * 16], float (&rl)[TM * TN * 16],
-                                                            const PipeParams& prm, int m0, int n0, int wm, int wn, int lane) {
-    const uint16_t* rp = prm.ln.res_planes;
-    const int64_t plane = (int64_t)prm.M * prm.N;
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int col = n0 + wn * (32 * TN) + ni * 32 + (lane & 31);
-            const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int64_t row = rbase + acc_row32(r, lane);
-                if (row > prm.M - 1) row = prm.M - 1;
-                const int64_t o = ac::plane_off(prm.M, row, col);
-                rh[(mi * TN + ni) * 16 + r] = bf16_bits_as_f32(rp + o);
-                rm[(mi * TN + ni) * 16 + r] = bf16_bits_as_f32(rp + o + plane);
-                rl[(mi * TN + ni) * 16 + r] = bf16_bits_as_f32(rp + o + 2 * plane);
-            }
-        }
-}
-
 // ---- EPI_BIAS_RES_LN: y = acc + bias + residual, LayerNorm over the whole row, result as fp32 rows AND operand planes ----
 // A row of the output spans the N / BN tiles of its row panel; each tile reduces its BN columns to a per-row (mean, M2),
 // publishes them (sc1 stores), counts itself into the panel's counter and waits for the others -- all tiles of a panel are
@@ -247,9 +213,8 @@ __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float
                 acc[mi][ni][r] = (acc[mi][ni][r] - st.x) * st.y * g + b;
             }
         }
-    // 7. fp32 rows (later residuals; not written when the next consumer takes the residual from the planes) and the operand planes
-    //    of the next GEMM
-    if (prm.C) store_tile<EPI_IDENT, TM, BM, TN>(acc, prm.C, prm.ldc, prm.M, prm.N, m0, n0, wm, wn, lane, e);
+    // 7. fp32 rows (later residuals) and the operand planes of the next GEMM
+    store_tile<EPI_IDENT, TM, BM, TN>(acc, prm.C, prm.ldc, prm.M, prm.N, m0, n0, wm, wn, lane, e);
     if (ln.planes)
         store_tile_planes<EPI_IDENT, TM, TN, AR>(acc, ln.planes, prm.M, prm.N, m0, n0, wm, wn, lane, e, lds_f + wave * kTrFloats);
 }
@@ -425,12 +390,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
     const int m0 = bm * BM, n0 = bn * BN;
     const int nk = prm.K / PSBK;
     stamp<(EPI == EPI_QKV_ATTN ? 16 : 4)>(prm, wave, 0);
-    // EPI_BIAS_RES_LN with C_PLANES = the form that takes the residual from its bf16x3 planes and writes no fp32 rows (LnFuse.res_planes)
-    constexpr bool LN = EPI == EPI_BIAS_RES_LN, LNP = LN && C_PLANES;
-    float lnres[LN ? TM * TN * 16 : 1];
-    float lnm[LNP ? TM * TN * 16 : 1], lnl[LNP ? TM * TN * 16 : 1];
-    if constexpr (LNP) ln_prefetch_residual_planes<TM, TN, WMW, WNW>(lnres, lnm, lnl, prm, m0, n0, wm, wn, lane);
-    else if constexpr (LN) ln_prefetch_residual<TM, TN, WMW, WNW>(lnres, prm, m0, n0, wm, wn, lane);
+    float lnres[EPI == EPI_BIAS_RES_LN ? TM * TN * 16 : 1];
+    if constexpr (EPI == EPI_BIAS_RES_LN) ln_prefetch_residual<TM, TN, WMW, WNW>(lnres, prm, m0, n0, wm, wn, lane);
     // EPI_QKV_ATTN: what the epilogue needs from global memory -- this thread's word of the tile's sequence table and its three bias
     // values -- is requested here, ahead of every DMA (older than them on the vmcnt queue), so the epilogue starts without a miss
     int at_cu_pref = 0;
@@ -605,10 +566,6 @@ __global__ __launch_bounds__(64 * WMW * WNW, (PipeGeom<TM, TN, WMW, WNW, NS, AR>
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                                   // nobody's DMA may land in the epilogue's LDS scratch
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (LNP) {                                            // x = (h + m) + l: both additions exact
-#pragma unroll
-            for (int i = 0; i < TM * TN * 16; ++i) lnres[i] = (lnres[i] + lnm[i]) + lnl[i];
-        }
         store_tile_ln<TM, TN, WMW, WNW, AR>(acc, lnres, prm, bm, bn, ntn, wm, wn, lane, tid, wave, reinterpret_cast<float*>(lds));
     } else if constexpr (EPI == EPI_QKV_ATTN) {
         __builtin_amdgcn_sched_barrier(0);
@@ -681,8 +638,6 @@ int launch_cfg_f16(int cls, bool cp, const PipeParams& p, hipStream_t stream) {
 template <int TM, int TN, int WMW, int WNW, int NS, int PIPE>
 int launch_cfg(int cls, bool cp, const PipeParams& p, hipStream_t stream) {
     if (cp) {
-        if constexpr (TM == 1 && TN == 2 && WMW == 4 && WNW == 2 && NS == 6 && PIPE == 2)      // (LayerNorm with the residual from planes)
-            if (cls == EPI_BIAS_RES_LN) return launch_one<EPI_BIAS_RES_LN, TM, TN, WMW, WNW, NS, true, PIPE>(p, stream);
         if (cls == EPI_BIAS_GELU) return launch_one<EPI_BIAS_GELU, TM, TN, WMW, WNW, NS, true, PIPE>(p, stream);
         if (cls == EPI_BIAS) return launch_one<EPI_BIAS, TM, TN, WMW, WNW, NS, true, PIPE>(p, stream);
         if constexpr (TN == 2) if (cls == EPI_GEGLU32) return launch_one<EPI_GEGLU32, TM, TN, WMW, WNW, NS, true, PIPE>(p, stream);
@@ -956,11 +911,9 @@ int pipe_ln_panels(int M) { return (M + kLnBM - 1) / kLnBM; }
 int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, int64_t w_rows, const float* bias,
                         const float* residual, int64_t ldr, float* C, int64_t ldc, int M, int N, int K, const float* gamma,
                         const float* beta, float eps, void* part, unsigned* count, unsigned* abort_flag, uint16_t* planes,
-                        hipStream_t stream, int f16, const uint16_t* res_planes) {
+                        hipStream_t stream, int f16) {
     AC_REQUIRE(pipe_ln_applies(M, N, K), AC_EUNSUPPORTED, "gemm_pipe: fused LayerNorm epilogue not applicable to %d x %d x %d", M, N, K);
-    AC_REQUIRE(Ap && Wp && bias && (residual || res_planes) && (C || planes) && gamma && beta && part && count && abort_flag, AC_EINVAL,
-               "gemm_pipe_ln: null pointer");
-    AC_REQUIRE(!res_planes || !f16, AC_EINVAL, "gemm_pipe_ln: the residual can be rebuilt from bf16x3 planes only (fp16x2 planes are rounded)");
+    AC_REQUIRE(Ap && Wp && bias && residual && C && gamma && beta && part && count && abort_flag, AC_EINVAL, "gemm_pipe_ln: null pointer");
     PipeParams p;
     p.Ap = Ap; p.a_rows = a_rows; p.Wp = Wp; p.w_rows = w_rows; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
     Epilogue e;
@@ -968,12 +921,11 @@ int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, 
     e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;
     p.epi = e;
     p.ln.gamma = gamma; p.ln.beta = beta; p.ln.eps = eps; p.ln.part = (float2*)part; p.ln.count = count; p.ln.abort_ = abort_flag;
-    p.ln.res_planes = res_planes;
     p.ln.planes = planes; p.ln.starve = (call_opts().ln_fusion >= 0 ? call_opts().ln_fusion : g_ln_fusion.load(std::memory_order_relaxed)) == 2 ? 1 : 0;
     p.stamps = nullptr;
     g_ln_launches.fetch_add(1, std::memory_order_relaxed);
     return f16 ? launch_cfg_f16<1, 2, 4, 2, 6, 2>(EPI_BIAS_RES_LN, false, p, stream)
-               : launch_cfg<1, 2, 4, 2, 6, 2>(EPI_BIAS_RES_LN, res_planes != nullptr, p, stream);
+               : launch_cfg<1, 2, 4, 2, 6, 2>(EPI_BIAS_RES_LN, false, p, stream);
 }
 }  // namespace ac
 
