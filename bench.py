@@ -1071,6 +1071,9 @@ def encoder_roofline(clf, stages, enc_flops, enc_peak, arith):
             "peak": enc_peak, "unit": "TFLOP/s",
             "frac": enc_flops / stages["encode_ms"] / 1e9 / enc_peak,
             "flops_per_step": enc_flops,
+            # the same FLOPs over the encoder's time in a back-to-back loop (its kernels' own time: no per-step launch ramp after the
+            # step's result copy); `frac` stays on the stage time of the timed step, as in earlier rounds
+            "frac_back_to_back": (enc_flops / stages["encode_ms_back_to_back"] / 1e9 / enc_peak) if "encode_ms_back_to_back" in stages else None,
             "peak_note": ("fp32-equivalent: bf16 MFMA dense peak 2500 / 6 products" if arith == 1
                           else "fp16 MFMA dense peak 2500 / 3 products (opt-in fp16x2 arithmetic)" if arith == 2
                           else "fp32-input MFMA dense peak"),
