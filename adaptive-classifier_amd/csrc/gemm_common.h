@@ -45,6 +45,11 @@ struct LnFuse {
     unsigned* abort_;       // set when a row panel's tiles did not all arrive (the results are NaN then)
     uint16_t* planes;       // [3][N/8][M][8] or null
     int starve;             // test hook (ac_gemm_set_ln_fusion(2)): wait for one arrival more than will ever come
+    // 0 (default): the fence-free hand-off -- sc1 (write-through) payload stores, s_waitcnt vmcnt(0), a RELAXED agent-scope arrival, a
+    // relaxed poll, sc1 (L2-bypassing) payload loads: nothing of the payload ever sits in a non-coherent cache, so no cache write-back /
+    // invalidate is needed (MI355X_MICROARCH.md "handoff-flag"; the grid barrier of grid_sync.h is built the same way).  1
+    // (AC_EXCHANGE_FENCES=1, A/B): release on the arrival + acquire after the poll (buffer_wbl2 / buffer_inv: ~3.5 us per exchange).
+    int fences;
 };
 
 // EPI_QKV_ATTN (gemm_pipe.hip): the [T, 3H] QKV projection with the self-attention of the packed sequences computed in the
@@ -65,6 +70,7 @@ struct AttnFuse {
     // follow-up launch.  null: both tiles spill their parts and attention_mfma_kernel's boundary mode serves the sequence.
     unsigned* exchange;
     unsigned epoch;
+    int fences;             // as LnFuse::fences
     unsigned* abort_;       // the encoder call's give-up word (shared with the LayerNorm exchange)
 };
 

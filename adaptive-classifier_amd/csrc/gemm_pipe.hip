@@ -159,8 +159,12 @@ __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // release: the workgroup's partial stores (made visible to thread 0 by the barrier) happen-before the arrival count
-    if (tid == 0) __hip_atomic_fetch_add(ln.count + bm, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // the workgroup's partial stores are write-through and acknowledged (vmcnt(0) above, every wave; the barrier orders them before
+    // thread 0's arrival): a relaxed arrival is enough -- see LnFuse::fences
+    if (tid == 0) {
+        if (ln.fences) __hip_atomic_fetch_add(ln.count + bm, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(ln.count + bm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // 4. wait for the panel's other tiles (bounded: a bug or a CU mask must not hang the GPU -- the rows become NaN instead)
     if (tid < 64) {
         // (~1 us per poll: gives up after about a second; once one panel has given up -- the flag is per encoder call -- the
@@ -169,8 +173,9 @@ __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float
         for (long spins = 0;; ++spins) {
             const unsigned v = __hip_atomic_load(ln.count + bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v >= (unsigned)(ntn + ln.starve)) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // acquire: pairs with the arrivals' release; the
-                break;                                                     // partial loads below cannot be served stale
+                if (ln.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the partial loads below are sc1: never served from a cache)
+                else asm volatile("" ::: "memory");                                    // (compiler: keep them after the poll)
+                break;
             }
             __builtin_amdgcn_s_sleep(1);
             if ((spins & 63) == 63 && (spins > (1l << 20) || __hip_atomic_load(ln.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
@@ -281,7 +286,8 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (at.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // (the row loads below are sc1: never served from a cache)
+        else asm volatile("" ::: "memory");                                        // (compiler: keep them after the poll)
         if (lane < 48) {
             constexpr int RB = 8;                                       // rows in flight per batch of sc1 (L2-bypassing) loads
             for (int r0b = row_a; r0b < row_b; r0b += RB) {
@@ -344,7 +350,10 @@ __device__ __forceinline__ void qkv_attention_epilogue(f32x16 (&acc)[TM][TN], co
             spill_rows(m0, top_end, lo_r);
             if (xchg) {                                                 // publish: the rows above, then the word the tile above polls
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(at.exchange + (size_t)bm * (prm.N / 192) + head, at.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {                                        // (the rows are write-through and acknowledged: AttnFuse::fences)
+                    if (at.fences) __hip_atomic_store(at.exchange + (size_t)bm * (prm.N / 192) + head, at.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    else __hip_atomic_store(at.exchange + (size_t)bm * (prm.N / 192) + head, at.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         for (int s = s0 + wave; s < nseq; s += NW) {
@@ -773,6 +782,11 @@ int launch_gemm_pipe(int cfg, const uint16_t* Ap, int64_t a_rows, const uint16_t
 
 
 bool ln_fusion_enabled();
+// A/B switch of the in-launch exchanges' memory ordering (LnFuse::fences): AC_EXCHANGE_FENCES=1 = release / acquire fences
+static int exchange_fences() {
+    static const int v = [] { const char* e = getenv("AC_EXCHANGE_FENCES"); return e && atoi(e) != 0 ? 1 : 0; }();
+    return v;
+}
 // ---- the QKV projection with the self-attention of the packed sequences in its epilogue (EPI_QKV_ATTN) ----
 static std::atomic<long long> g_qkv_attn_launches{0};
 bool qkv_attn_applies(int M, int H, int heads, int smax) {
@@ -852,7 +866,7 @@ int launch_gemm_pipe_qkv_attn(const uint16_t* Ap, int64_t a_rows, const uint16_t
     p.at.qkv = qkv;
     AC_REQUIRE(!exchange || (abort_flag && qkv_attn_exchange_applies(M, heads, f16)), AC_EINVAL,
                "gemm_pipe_qkv_attn: the in-launch exchange needs every tile resident (%d rows x %d heads) and an abort word", M, heads);
-    p.at.exchange = exchange; p.at.epoch = epoch; p.at.abort_ = abort_flag;
+    p.at.exchange = exchange; p.at.epoch = epoch; p.at.abort_ = abort_flag; p.at.fences = exchange_fences();
     p.stamps = nullptr;
     g_qkv_attn_launches.fetch_add(1, std::memory_order_relaxed);
     return f16 ? launch_one<EPI_QKV_ATTN, 2, 3, 4, 2, 4, false, 2, 2>(p, stream)
@@ -921,6 +935,7 @@ int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, 
     e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;
     p.epi = e;
     p.ln.gamma = gamma; p.ln.beta = beta; p.ln.eps = eps; p.ln.part = (float2*)part; p.ln.count = count; p.ln.abort_ = abort_flag;
+    p.ln.fences = exchange_fences();
     p.ln.planes = planes; p.ln.starve = (call_opts().ln_fusion >= 0 ? call_opts().ln_fusion : g_ln_fusion.load(std::memory_order_relaxed)) == 2 ? 1 : 0;
     p.stamps = nullptr;
     g_ln_launches.fetch_add(1, std::memory_order_relaxed);
