@@ -25,6 +25,7 @@ class NativeError(RuntimeError):
 
 AC_GEMM_F32, AC_GEMM_BF16X3, AC_GEMM_F16X2 = 0, 1, 2     # include/acamd.h: ac_gemm_set_arith
 AC_BERT_LAYERED = 1     # include/acamd.h: ac_bert_encode_cls_opts never takes the one-launch path
+AC_BERT_PATH_PACKED, AC_BERT_PATH_PADDED, AC_BERT_PATH_PADDED_MASK = 0, 1, 2     # ac_bert_encode_cls_unpad's *path
 
 
 def build(force=False):
@@ -172,6 +173,9 @@ _SIGNATURES = {
     "ac_bert_encode_cls_packed": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p, c_void_p,
                                           c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
                                           c_void_p]),
+    "ac_bert_encode_cls_unpad": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p, c_void_p,
+                                         c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t, c_int,
+                                         ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p]),
     "ac_bert_encode_cls_opts": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p,
                                         c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t, c_int,
                                         ctypes.POINTER(c_int), c_void_p]),

@@ -14,6 +14,7 @@ projections are fused into one [3H, H] matrix.  `HipModernBertEncoder` covers Mo
 covered by the HIP encoders and raise.
 """
 import ctypes
+import os
 
 import torch
 
@@ -282,10 +283,7 @@ class HipBertEncoder:
         with torch.cuda.device(self.device):
             # the fused-LayerNorm verdict of this call starts clean (sticky over the chunks below; include/acamd.h); a call
             # that runs as the one persistent launch has no such epilogue (and is the latency path: no extra launch)
-            if b * S > SMALL_TOKENS or force_layered:
-                nv.check(nv.lib().ac_bert_ln_fusion_clear(nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
-                         "ac_bert_ln_fusion_clear")
-            layered = self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg)
+            layered = self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg, clear=b * S > SMALL_TOKENS or force_layered)
             if verify and layered and self.ln_fusion_aborted():
                 import logging
                 logging.getLogger(__name__).warning(
@@ -294,9 +292,7 @@ class HipBertEncoder:
                 self.ln_gave_up += 1
                 self.disable_ln_fusion()
                 cfg = self._call_cfg(arith)
-                nv.check(nv.lib().ac_bert_ln_fusion_clear(nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
-                         "ac_bert_ln_fusion_clear")
-                self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg)
+                self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg, clear=True)
             if verify and layered and self.f16x2_active(arith) and not bool(torch.isfinite(out).all()):
                 # an activation beyond fp16's range at scale 2^6 turned its rows into NaN (never into a wrong number)
                 import logging
@@ -314,17 +310,45 @@ class HipBertEncoder:
                 self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg)
         return out
 
-    def _run_chunks(self, ids, tt, mk, b, S, cb, out, verify, force_layered, cfg=None):
+    # one call for packing + forward, no stream synchronisation (include/acamd.h ac_bert_encode_cls_unpad); AC_BERT_UNPAD_ONE_CALL=0
+    # keeps the separate ac_bert_pack -> read-back -> ac_bert_encode_cls_packed form (A/B runs, the equivalence test)
+    _UNPAD_MAX_SEQS = 8192
+
+    def _run_chunks(self, ids, tt, mk, b, S, cb, out, verify, force_layered, cfg=None, clear=False):
         """The native calls of one encode_cls: row chunks of <= cb sequences.  Returns True when at least one chunk ran layer
-        by layer (the path whose GEMM epilogues may carry the fused LayerNorm)."""
+        by layer (the path whose GEMM epilogues may carry the fused LayerNorm).  clear: the fused-LayerNorm verdict words of
+        the workspace start clean with this call (sticky over its chunks)."""
         self.last_tokens = 0
         layered = False
         cfg = self.ccfg if cfg is None else cfg
+        one_call = os.environ.get("AC_BERT_UNPAD_ONE_CALL", "1") != "0"
+        if one_call and os.environ.get("AC_LIBACAMD_PATH"):      # (an older library under A/B, tools/: the entry may not exist)
+            try:
+                nv.lib().ac_bert_encode_cls_unpad
+            except AttributeError:
+                one_call = False
         for r0 in range(0, b, cb):
             r1 = min(b, r0 + cb)
             nb = r1 - r0
             mk_all_ones = False
-            if self.unpad and mk is not None and S > 1 and nb * S > SMALL_TOKENS:
+            unpad = self.unpad and mk is not None and S > 1 and nb * S > SMALL_TOKENS
+            if unpad and one_call and nb <= self._UNPAD_MAX_SEQS:
+                total, path = ctypes.c_int(0), ctypes.c_int(0)
+                nv.check(nv.lib().ac_bert_encode_cls_unpad(
+                    ctypes.byref(cfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]), nv.ptr(None if tt is None else tt[r0:r1]),
+                    nv.ptr(mk[r0:r1]), nb, S, nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(),
+                    1 if clear else 0, ctypes.byref(total), ctypes.byref(path), nv.stream_ptr(self.device)),
+                    "ac_bert_encode_cls_unpad")
+                clear = False
+                self.last_one_launch = False
+                layered = True
+                self.last_tokens += total.value
+                continue
+            if clear:
+                nv.check(nv.lib().ac_bert_ln_fusion_clear(nv.ptr(self._ws), self._ws.numel(), nv.stream_ptr(self.device)),
+                         "ac_bert_ln_fusion_clear")
+                clear = False
+            if unpad:
                 # padding-free path: pack on the device, read back {rows, prefix flag, longest} (one 16-byte D2H)
                 cu = torch.empty(nb + 1, dtype=torch.int32, device=self.device)
                 src = torch.empty(nb * S, dtype=torch.int32, device=self.device)

@@ -14,6 +14,8 @@
 #include "attention_core.h"
 
 #include <math.h>
+#include <atomic>
+#include <string.h>
 
 namespace {
 
@@ -72,7 +74,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const
                                                        int H, const float* word, const float* pos,
                                                        const float* type, const float* g, const float* b,
                                                        float eps, float* out, uint16_t* planes,
-                                                       const int32_t* __restrict__ tok_src = nullptr) {
+                                                       const int32_t* __restrict__ tok_src = nullptr,
+                                                       const int32_t* __restrict__ t_dev = nullptr) {
+    // t_dev: the token-row count is still on its way to the host (ac_bert_encode_cls_unpad): the launch covers b * S rows and
+    // the real count -- the row stride of the operand planes too -- is read here
+    if (t_dev) T = t_dev[0];
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -357,13 +363,96 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 struct BertWs {
-    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, cu, tile_seq, attn_xchg, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
+    size_t x, qkv, ctx, y, ffn, xp, ctxp, ffnp, small, lnctl, lnpart, cu, tile_seq, attn_xchg, pack_src, pack_info, total;     // *p: bf16x3 operand planes (3 * rows * K uint16)
     size_t lnctl_bytes, attn_xchg_bytes;
 };
 // cu of an UNPACKED batch without a mask (every sequence has S real tokens): what ac_bert_pack would have produced
 __global__ __launch_bounds__(256) void iota_cu_kernel(int32_t* cu, int b, int S) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i <= b) cu[i] = i * S;
+}
+// Everything of a padding-free forward that comes before its first GEMM and needs no token count on the HOST, in ONE workgroup
+// (ac_bert_encode_cls_unpad; the separate form is ac_bert_pack + 2 memsets + the verdict roll + the tile table = 9 stream
+// operations and a D2H round trip of ~27 us with the GPU idle):
+//   lens / prefix check / exclusive scan -> cu, info = {rows, not-prefix flag, longest, -}   (pack_lens / pack_scan)
+//   tok_src[cu[s] + p] = s * S + p                                                            (pack_fill)
+//   the fused attention epilogue's row-tile table                                             (ac::qkv_attn_tile_seq_kernel)
+//   the LayerNorm exchange's counters and the attention exchange's words := 0, the verdict words rolled (or cleared)
+//   info -> a host-mapped slot, `epoch` last: the host spins on it while the embedding kernel (launched over b * S rows, reading
+//   the count from `info`) already runs
+__global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __restrict__ mask, int b, int S, int32_t* __restrict__ cu,
+                                                             int32_t* __restrict__ tok_src, int32_t* __restrict__ info,
+                                                             int32_t* __restrict__ tile_seq, unsigned* __restrict__ zero_a, int zero_a_words,
+                                                             unsigned* __restrict__ zero_b, int zero_b_words, unsigned* __restrict__ verdict,
+                                                             int clear_verdict, int32_t* host_slot, int epoch) {
+    extern __shared__ int32_t pk_lds[];                 // lens[b] | cu[b + 1]
+    __shared__ int part[1024];
+    __shared__ int s_bad, s_longest;
+    int32_t* lens = pk_lds;
+    int32_t* cus = pk_lds + b;
+    const int tid = threadIdx.x, n = b * S;
+    for (int i = tid; i < b; i += 1024) lens[i] = 0;
+    if (tid == 0) { s_bad = 0; s_longest = 0; }
+    __syncthreads();
+    for (int i = tid; i < zero_a_words; i += 1024) zero_a[i] = 0u;
+    for (int i = tid; i < zero_b_words; i += 1024) zero_b[i] = 0u;
+    if (tid == 0) {
+        if (clear_verdict) { verdict[0] = 0u; verdict[1] = 0u; }
+        else { verdict[1] |= verdict[0]; verdict[0] = 0u; }
+    }
+    int bad = 0;
+    for (int i = tid; i < n; i += 1024) {               // ones form a prefix of the row <=> no one right after a zero
+        const int p = i % S;
+        if (mask[i] != 0) {
+            atomicAdd(&lens[i / S], 1);
+            if (p > 0 && mask[i - 1] == 0) bad = 1;
+        }
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    const int per = (b + 1023) / 1024;
+    int sum = 0, mx = 0;
+    for (int i = tid * per; i < (tid + 1) * per && i < b; ++i) {
+        const int l = lens[i];
+        sum += l; mx = l > mx ? l : mx;
+        if (l == 0) bad = 1;
+    }
+    if (bad) s_bad = 1;
+    if (mx) atomicMax(&s_longest, mx);
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                // inclusive Hillis-Steele scan of the partial sums
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int i = tid * per; i < (tid + 1) * per && i < b; ++i) { cus[i] = run; cu[i] = run; run += lens[i]; }
+    const int total = part[1023];
+    if (tid == 0) { cus[b] = total; cu[b] = total; info[0] = total; info[1] = s_bad; info[2] = s_longest; info[3] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int q = i / S, p = i - q * S;
+        if (p < lens[q]) tok_src[cus[q] + p] = i;
+    }
+    // the row-tile table (gemm_pipe.hip qkv_attn_tile_seq_kernel): a wave per tile
+    const int ntiles = (total + ac::kQkvAttnRows - 1) / ac::kQkvAttnRows, lane = tid & 63;
+    for (int t = tid >> 6; t < ntiles; t += 16) {
+        auto first_at_or_after = [&](int row) { int lo = 0, hi = b; while (lo < hi) { const int mid = (lo + hi) >> 1; if (cus[mid] < row) lo = mid + 1; else hi = mid; } return lo; };
+        const int sb = first_at_or_after(t * ac::kQkvAttnRows), se = first_at_or_after((t + 1) * ac::kQkvAttnRows), ns = se - sb;
+        for (int i = lane; i < ac::kQkvAttnCu; i += 64) {
+            int v = 0;
+            if (i == 0) v = ns;
+            else if (i - 1 <= ns) v = cus[sb + i - 1];
+            tile_seq[(size_t)t * ac::kQkvAttnCu + i] = v;
+        }
+    }
+    if (tid == 0 && host_slot) {
+        host_slot[0] = total; host_slot[1] = s_bad; host_slot[2] = s_longest;
+        __threadfence_system();
+        __hip_atomic_store(&host_slot[3], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 // The verdict of the fused-LayerNorm GEMM epilogues sits at offset 0 of the workspace WHATEVER (b, S) the workspace is used
 // with: word 0 = "a panel of the CURRENT call gave up" (set by the kernels; later launches of the call stop waiting at their first
@@ -406,6 +495,10 @@ BertWs bert_ws(const ac_bert_config& c, int b, int S) {
     w.attn_xchg = off;                // one word per (256-row tile, head): the in-launch exchange of straddling sequences
     w.attn_xchg_bytes = ac::align_up(((T + ac::kQkvAttnRows - 1) / ac::kQkvAttnRows) * (size_t)c.heads * sizeof(unsigned), 256);
     off += w.attn_xchg_bytes;
+    w.pack_src = off;                 // ac_bert_encode_cls_unpad: token sources of the packed rows, {rows, flag, longest, -}
+    off += ac::align_up(T * sizeof(int32_t), 256);
+    w.pack_info = off;
+    off += 256;
     w.total = off;
     return w;
 }
@@ -439,9 +532,36 @@ namespace {
 
 // shared body of ac_bert_encode_cls (cu == nullptr: the [b, S] rows incl. padding, T = b * S) and
 // ac_bert_encode_cls_packed (cu / tok_src from ac_bert_pack: T = cu[b] real-token rows, no mask)
+// What of a forward is decided by the token-row count alone: operand planes between the GEMMs, fp16x2 planes
+struct EncodePlan { bool wplanes, pl, f16; };
+EncodePlan encode_plan(const ac_bert_config& c, const ac_bert_weights* w, int T) {
+    const int H = c.hidden, I = c.intermediate;
+    EncodePlan p;
+    p.wplanes = w->qkv_w3 && w->ao_w3 && w->ff1_w3 && w->ff2_w3;
+    p.pl = p.wplanes && ac::linear_takes_planes(T, H, H) && ac::linear_takes_planes(T, H, I) && (H % 8) == 0;
+    p.f16 = p.pl && ac::gemm_arith() == AC_GEMM_F16X2 && w->qkv_wh && w->ao_wh && w->ff1_wh && w->ff2_wh && c.layers > 1 &&
+            ac::linear_f16x2_takes(T, 3 * H, H) && ac::linear_f16x2_takes(T, H, H) && ac::linear_f16x2_takes(T, I, H) &&
+            ac::linear_f16x2_takes(T, H, I);
+    return p;
+}
+// the embedding launch over `rows` token rows (t_dev: the real count is read on the device, see embed_ln_kernel)
+void launch_embed(const ac_bert_config& c, const ac_bert_weights* w, const EncodePlan& pn, const int64_t* d_ids, const int64_t* d_type_ids,
+                  int rows, int S, float* x, uint16_t* xp, const int32_t* tok_src, const int32_t* t_dev, hipStream_t stream) {
+    const int H = c.hidden, tok_blocks = (rows + 3) / 4;
+    if (pn.f16)
+        hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, rows, S, H,
+                           w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x, xp, tok_src, t_dev);
+    else
+        hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, rows, S, H,
+                           w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x,
+                           pn.pl ? xp : nullptr, tok_src, t_dev);
+}
+// pre (ac_bert_encode_cls_unpad's pack_prologue_kernel ran on this stream): kPreCtl = the verdict roll, the zeroing of the exchange
+// words and the row-tile table are done; kPreEmbed = the embedding kernel too
+constexpr int kPreCtl = 1, kPreEmbed = 2;
 int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids, const int64_t* d_type_ids,
                      const int64_t* d_mask, int b, int S, const int32_t* cu, const int32_t* tok_src, int T, int Smax,
-                     float* d_out, int64_t ldo, void* d_ws, size_t ws_bytes, hipStream_t stream) {
+                     float* d_out, int64_t ldo, void* d_ws, size_t ws_bytes, hipStream_t stream, int pre = 0) {
     int rc;
     const ac_bert_config& c = *cfg;
     const BertWs ws = bert_ws(c, b, S);
@@ -453,7 +573,6 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
     float* y = (float*)(base + ws.y);
     float* ffn = (float*)(base + ws.ffn);
     const int H = c.hidden, I = c.intermediate;
-    const int tok_blocks = (T + 3) / 4;
 
     uint16_t* xp = (uint16_t*)(base + ws.xp);
     uint16_t* ctxp = (uint16_t*)(base + ws.ctxp);
@@ -462,30 +581,26 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
     // -- the LayerNorms, the attention kernel, the GELU epilogue of FFN1 -- emits the bf16x3 planes the next
     // GEMM stages with direct global->LDS loads, so no GEMM splits its operands again.  The T-row GEMMs of
     // layers 0 .. L-2 qualify; the CLS-only last layer (b rows) keeps fp32 activations.
-    const bool wplanes = w->qkv_w3 && w->ao_w3 && w->ff1_w3 && w->ff2_w3;
-    const bool pl = wplanes && ac::linear_takes_planes(T, H, H) && ac::linear_takes_planes(T, H, I) && (H % 8) == 0;
+    const EncodePlan pn = encode_plan(c, w, T);
+    const bool wplanes = pn.wplanes, pl = pn.pl;
     // bias + residual + LayerNorm in the epilogue of the attention-output and FFN2 GEMMs (one-round launches only)
     // AC_GEMM_F16X2 (opt-in): the same flow on fp16x2 planes when the fp16 weight planes are there and all four token-row GEMMs
     // take the ring-staged kernel; the CLS-only tail of the last layer (fp32 activations, b rows) stays bf16x3
-    const bool f16 = pl && ac::gemm_arith() == AC_GEMM_F16X2 && w->qkv_wh && w->ao_wh && w->ff1_wh && w->ff2_wh && c.layers > 1 &&
-                     ac::linear_f16x2_takes(T, 3 * H, H) && ac::linear_f16x2_takes(T, H, H) && ac::linear_f16x2_takes(T, I, H) &&
-                     ac::linear_f16x2_takes(T, H, I);
+    const bool f16 = pn.f16;
     const bool fuse_ln = pl && c.layers > 1 && ac::pipe_ln_applies(T, H, H) && ac::pipe_ln_applies(T, H, I);
     unsigned* ln_abort = (unsigned*)base;
-    hipLaunchKernelGGL(ln_verdict_roll_kernel, dim3(1), dim3(1), 0, stream, ln_abort);
-    AC_LAUNCH_CHECK();
+    if (!(pre & kPreCtl)) {
+        hipLaunchKernelGGL(ln_verdict_roll_kernel, dim3(1), dim3(1), 0, stream, ln_abort);
+        AC_LAUNCH_CHECK();
+    }
     unsigned* ln_count = (unsigned*)(base + ws.lnctl);
     const int ln_panels = ac::pipe_ln_panels(T);
-    if (fuse_ln) AC_HIP_CHECK(hipMemsetAsync(base + ws.lnctl, 0, ws.lnctl_bytes, stream));
+    if (fuse_ln && !(pre & kPreCtl)) AC_HIP_CHECK(hipMemsetAsync(base + ws.lnctl, 0, ws.lnctl_bytes, stream));
 
-    if (f16)
-        hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, T, S, H,
-                           w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x, xp, tok_src);
-    else
-        hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(tok_blocks), dim3(256), 0, stream, d_ids, d_type_ids, T, S, H,
-                           w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, c.ln_eps, x,
-                           pl ? xp : nullptr, tok_src);
-    AC_LAUNCH_CHECK();
+    if (!(pre & kPreEmbed)) {
+        launch_embed(c, w, pn, d_ids, d_type_ids, T, S, x, xp, tok_src, nullptr, stream);
+        AC_LAUNCH_CHECK();
+    }
     const int dh = c.hidden / c.heads;                // 64, or 32 (MiniLM family)
     const float scale = 1.0f / sqrtf((float)dh);
     // Self-attention inside the QKV GEMM's epilogue (gemm_pipe.hip EPI_QKV_ATTN): sequences laid out row after row (packed, or
@@ -501,11 +616,13 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
     int32_t* tile_seq = (int32_t*)(base + ws.tile_seq);
     unsigned* attn_xchg = nullptr;
     if (fuse_attn) {
-        rc = ac::qkv_attn_tile_seq(cu_at, b, T, tile_seq, stream);
-        if (rc) return rc;
+        if (!(pre & kPreCtl) || !cu) {
+            rc = ac::qkv_attn_tile_seq(cu_at, b, T, tile_seq, stream);
+            if (rc) return rc;
+        }
         if (ac::qkv_attn_exchange_applies(T, c.heads, (int)f16)) {        // every tile resident (proven): no boundary launches
             attn_xchg = (unsigned*)(base + ws.attn_xchg);
-            AC_HIP_CHECK(hipMemsetAsync(attn_xchg, 0, ws.attn_xchg_bytes, stream));
+            if (!(pre & kPreCtl)) AC_HIP_CHECK(hipMemsetAsync(attn_xchg, 0, ws.attn_xchg_bytes, stream));
         }
     }
     for (int l = 0; l < c.layers; ++l) {
@@ -695,6 +812,90 @@ extern "C" int ac_bert_pack(const int64_t* d_mask, int b, int S, int32_t* d_cu, 
     hipLaunchKernelGGL(pack_fill_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, d_cu, b, S, d_tok_src);
     AC_LAUNCH_CHECK();
     return AC_OK;
+}
+
+namespace {
+// Host-mapped slots the prologue kernel reports {rows, not-prefix flag, longest, epoch} into (fine-grained pinned memory: the host
+// sees the stores while later kernels of the stream run).  64 slots of 64 bytes, handed out round-robin: concurrent callers
+// (threads / streams) never share a slot in flight unless 64 calls overtake one.
+int32_t* info_slot(int* epoch_out) {
+    static int32_t* base = [] {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64 * 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return (int32_t*)nullptr; }
+        memset(p, 0, 64 * 64);
+        return (int32_t*)p;
+    }();
+    static std::atomic<unsigned> next{0};
+    const unsigned n = next.fetch_add(1, std::memory_order_relaxed) + 1;
+    *epoch_out = (int)(n & 0x3fffffff) + 1;               // never 0 (the slots' initial value)
+    return base ? base + 16 * (n & 63) : nullptr;
+}
+}  // namespace
+
+// ac_bert_pack + ac_bert_encode_cls_packed as ONE call without a stream synchronisation (include/acamd.h)
+extern "C" int ac_bert_encode_cls_unpad(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids,
+                                        const int64_t* d_type_ids, const int64_t* d_mask, int b, int S, float* d_out, int64_t ldo,
+                                        void* d_ws, size_t ws_bytes, int clear_verdict, int* total_tokens, int* path, ac_stream_t stream_) {
+    if (total_tokens) *total_tokens = 0;
+    if (path) *path = AC_BERT_PATH_PACKED;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (b == 0) return AC_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const ac::CallScope scope(cfg->gemm_arith_opt, cfg->ln_fusion_opt, cfg->one_launch_opt);
+    AC_REQUIRE(w && d_ids && d_mask && d_out && b > 0 && S >= 2 && S <= cfg->max_pos && ldo >= cfg->hidden && (int64_t)b * S > 32 &&
+                   (int64_t)b * S < ((int64_t)1 << 30),
+               AC_EINVAL, "bert_encode_cls_unpad: bad arguments (b=%d S=%d max_pos=%d; more than 32 token rows)", b, S, cfg->max_pos);
+    const ac_bert_config& c = *cfg;
+    const BertWs ws = bert_ws(c, b, S);
+    AC_REQUIRE(d_ws && ws_bytes >= ws.total, AC_EWORKSPACE, "bert_encode_cls_unpad: workspace %zu < %zu", ws_bytes, ws.total);
+    char* base = (char*)d_ws;
+    int32_t* cu = (int32_t*)(base + ws.cu);
+    int32_t* src = (int32_t*)(base + ws.pack_src);
+    int32_t* info = (int32_t*)(base + ws.pack_info);
+    int epoch = 0;
+    int32_t* slot = info_slot(&epoch);
+    const size_t lds = (size_t)(2 * b + 1) * sizeof(int32_t);
+    AC_REQUIRE(slot && lds <= 96 * 1024, AC_EUNSUPPORTED, "bert_encode_cls_unpad: %d sequences in one call (or no pinned host memory): "
+               "use ac_bert_pack + ac_bert_encode_cls_packed", b);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)pack_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(pack_prologue_kernel, dim3(1), dim3(1024), lds, stream, d_mask, b, S, cu, src, info, (int32_t*)(base + ws.tile_seq),
+                       (unsigned*)(base + ws.lnctl), (int)(ws.lnctl_bytes / 4), (unsigned*)(base + ws.attn_xchg), (int)(ws.attn_xchg_bytes / 4),
+                       (unsigned*)base, clear_verdict, slot, epoch);
+    AC_LAUNCH_CHECK();
+    // the embedding kernel does not wait for the host: same plan at the fewest (one per sequence) and the most (b * S) token rows
+    // a batch can have <=> the launch is the one the count would have chosen
+    const EncodePlan lo = encode_plan(c, w, b), hi = encode_plan(c, w, b * S);
+    const bool early = lo.pl == hi.pl && lo.f16 == hi.f16;
+    if (early) {
+        launch_embed(c, w, hi, d_ids, d_type_ids, b * S, S, (float*)(base + ws.x), (uint16_t*)(base + ws.xp), src, info, stream);
+        AC_LAUNCH_CHECK();
+    }
+    // the host's copy of {rows, flag, longest}: a short spin on the slot (the kernel above is ~10 us of a stream that is normally
+    // empty), then a blocking wait for whatever was queued ahead of this call
+    volatile int32_t* vs = slot;
+    bool seen = false;
+    for (int spin = 0; spin < 200000 && !seen; ++spin) {
+        seen = __atomic_load_n(&vs[3], __ATOMIC_ACQUIRE) == epoch;
+        if (!seen) __builtin_ia32_pause();
+    }
+    if (!seen) {
+        AC_HIP_CHECK(hipStreamSynchronize(stream));
+        seen = __atomic_load_n(&vs[3], __ATOMIC_ACQUIRE) == epoch;
+        AC_REQUIRE(seen, AC_EHIP, "bert_encode_cls_unpad: the packing kernel's report never arrived");
+    }
+    const int total = vs[0], not_prefix = vs[1], longest = vs[2];
+    if (total_tokens) *total_tokens = total;
+    if (!not_prefix && total < b * S) {
+        AC_REQUIRE(total >= b && longest >= 1 && longest <= S, AC_EHIP, "bert_encode_cls_unpad: bad report (%d rows, longest %d)", total, longest);
+        return bert_encode_impl(cfg, w, d_ids, d_type_ids, nullptr, b, S, cu, src, total, longest, d_out, ldo, d_ws, ws_bytes, stream,
+                                kPreCtl | (early ? kPreEmbed : 0));
+    }
+    // nothing to leave out (every row full: no mask needed), or a mask whose ones are not a prefix of its row: the [b, S] forward
+    if (path) *path = not_prefix ? AC_BERT_PATH_PADDED_MASK : AC_BERT_PATH_PADDED;
+    if (total_tokens) *total_tokens = b * S;
+    return bert_encode_impl(cfg, w, d_ids, d_type_ids, not_prefix ? d_mask : nullptr, b, S, nullptr, nullptr, b * S, S, d_out, ldo, d_ws,
+                            ws_bytes, stream);
 }
 
 extern "C" int ac_bert_encode_cls_packed(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids,

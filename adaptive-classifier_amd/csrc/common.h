@@ -97,6 +97,7 @@ int launch_gemm_pipe_ln(const uint16_t* Ap, int64_t a_rows, const uint16_t* Wp, 
 // go straight to `ctx_planes`; `qkv` (fp32 [T, 3H]) only receives the rows of sequences that straddle a 256-row tile boundary,
 // which the caller then serves with attention_mfma_kernel's boundary mode (boundary_stride = kQkvAttnRows)
 constexpr int kQkvAttnRows = 256;
+constexpr int kQkvAttnCu = 264;            // words of one row tile's entry in the sequence table (gemm_pipe.hip kAtCu)
 bool qkv_attn_applies(int M, int H, int heads, int smax);
 size_t qkv_attn_tile_seq_bytes(int M);
 int qkv_attn_tile_seq(const int32_t* cu, int b, int M, int32_t* tile_seq, hipStream_t stream);     // once per forward (cu is the same for every layer)

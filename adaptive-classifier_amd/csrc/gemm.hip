@@ -636,6 +636,78 @@ __global__ __launch_bounds__(256) void gemm_direct_pair(DirectProblem p1, Direct
 }
 
 // ---------------------------------------------------------------------------------------------
+// few-tile NT kernel (65 <= M <= 1024 with fewer 64 x 128 tiles than half the CUs: the head's three layers over a predict
+// batch, the CLS-row GEMMs of the encoder's last layer).  Such a shape is latency-bound, not pipe-bound: the tiled kernels put
+// 256 x 768 x 768 on 24 workgroups (30 us), split-K over operand planes needs a reduce launch (10 + 6 us).  Here one workgroup
+// owns a 32 x 32 output tile (256 x 768 -> 192 workgroups), its 8 waves split K in interleaved 16-column slots (a lane reads
+// whole 64-byte lines of its row: two float4 of A, two of W per slot, straight into v_mfma_f32_32x32x2_f32 operands -- exact
+// fp32 products, fp32 accumulation), the next slot's loads are in flight under the current slot's 8 MFMAs, and the 8 partial
+// tiles meet in LDS in a fixed order.  One launch, ~5 us for the head's layers.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFtWaves = 8;
+__global__ __launch_bounds__(kFtWaves * 64) void gemm_fewtiles_nt(const float* __restrict__ A, int64_t lda,
+                                                                  const float* __restrict__ W, int64_t ldw,
+                                                                  float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                                  Epilogue epi, int tiles_n) {
+    __shared__ float red[kFtWaves][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+    const int i = lane & 31, h = lane >> 5;
+    int arow = m0 + i; if (arow > M - 1) arow = M - 1;
+    int wrow = n0 + i; if (wrow > N - 1) wrow = N - 1;
+    const float* ap = A + (int64_t)arow * lda + 8 * h;
+    const float* wp = W + (int64_t)wrow * ldw + 8 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // slot s of this wave covers k in [16 (8 s + wave), +16): this lane's 8 of them start at 16 (8 s + wave) + 8 h  (K % 8 == 0)
+    auto load = [&](int s, f32x4 (&a)[2], f32x4 (&b)[2]) {
+        const int k = 16 * (kFtWaves * s + wave);
+        if (k + 8 * h < K) {
+            a[0] = *reinterpret_cast<const f32x4*>(ap + k); a[1] = *reinterpret_cast<const f32x4*>(ap + k + 4);
+            b[0] = *reinterpret_cast<const f32x4*>(wp + k); b[1] = *reinterpret_cast<const f32x4*>(wp + k + 4);
+        } else {
+            a[0] = a[1] = b[0] = b[1] = zero;
+        }
+    };
+    const int nslots = (K + 16 * kFtWaves - 1) / (16 * kFtWaves);
+    f32x4 a0[2], b0[2], a1[2], b1[2];
+    load(0, a0, b0);
+    for (int s = 0; s < nslots; s += 2) {
+        load(s + 1, a1, b1);                    // (beyond K: zeros)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e][c], b0[e][c], acc, 0, 0, 0);
+        load(s + 2, a0, b0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e][c], b1[e][c], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {                // 1024 outputs, 2 per thread; fixed summation order over the 8 K-slices
+        const int o = tid + 512 * e;              // o = r * 64 + l
+        const int r = o >> 6, l = o & 63;
+        const float v = (((red[0][r][l] + red[1][r][l]) + (red[2][r][l] + red[3][r][l])) +
+                         ((red[4][r][l] + red[5][r][l]) + (red[6][r][l] + red[7][r][l])));
+        const int64_t row = m0 + acc_row32(r, l);
+        const int col = n0 + (l & 31);
+        if (row < M && col < N) C[row * ldc + col] = apply_epilogue(epi, v, row, col, C, ldc, N);
+    }
+}
+// (the shapes it takes: see the comment above; `aligned` = 16-byte aligned bases and lda, ldw multiples of 4)
+static bool fewtiles_takes(int M, int N, int K, bool aligned) {
+    if (const char* e = getenv("AC_GEMM_FEWTILES")) { if (atoi(e) == 0) return false; }
+    const int64_t t64 = (int64_t)((M + 63) / 64) * ((N + BN - 1) / BN);
+    return aligned && M >= 65 && M <= 1024 && (K % 8) == 0 && K >= 64 && 2 * t64 <= ac::dev_info().cus;
+}
+
+// ---------------------------------------------------------------------------------------------
 // small-M NT kernel (M <= 64): weight streaming.  out[m][n] = sum_k X[m][k] W[n][k] is computed as
 // (W rows) x (X^T) on v_mfma_f32_16x16x4_f32: the A operand is 16 rows of W straight from HBM
 // (float4 per lane, 16 rows x 64 B per wave load, exactly the kNN sweep's access shape), the B operand
@@ -737,6 +809,10 @@ static int launch_gemm(bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, co
         if (M <= 16) hipLaunchKernelGGL((gemm_smallm_nt<1>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
         else if (M <= 32) hipLaunchKernelGGL((gemm_smallm_nt<2>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
         else hipLaunchKernelGGL((gemm_smallm_nt<4>), grid, block, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi);
+    } else if (a_kmaj && b_kmaj && !Ap && !Cp && fewtiles_takes(M, N, K, aligned)) {
+        const int tn = (N + 31) / 32;
+        hipLaunchKernelGGL(gemm_fewtiles_nt, dim3((unsigned)(((M + 31) / 32) * tn)), dim3(kFtWaves * 64), 0, stream, A, lda, B, ldb, C, ldc,
+                           M, N, K, epi, tn);
     } else if (a_kmaj && b_kmaj && aligned && M >= 192 && K >= BK && (K % BK) == 0) {
         // pick the M-tile that wastes fewer CU-rounds: cost = rounds * (tile rows) * (resident blocks)
         const int cus = ac::dev_info().cus;
@@ -921,7 +997,10 @@ int linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, 
     const int cus = dev_info().cus;
     const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + BN - 1) / BN);
     int ksplit = 1;
-    if (Wp && scratch && arith_split() && gemm_variant() == 0 && M >= 65 && M <= 512 && (N % 4) == 0 &&
+    // (the few-tile fp32 kernel runs such a shape in ONE launch; its fp32 matrix pipe is 1/16 of the bf16 one, so only up to the
+    //  size of 256 x 768 x 768 -- 8.6 us against 10 + 6 for split-K and its reduce; at the FFN shapes the two are level)
+    const bool direct = W && (int64_t)M * N * K <= (int64_t)160 << 20 && fewtiles_takes(M, N, K, (lda % 4) == 0 && (ldw % 4) == 0 && ((((uintptr_t)A) | ((uintptr_t)W)) & 15) == 0);
+    if (!direct && Wp && scratch && arith_split() && gemm_variant() == 0 && M >= 65 && M <= 512 && (N % 4) == 0 &&
         (K % 32) == 0 && (lda % 4) == 0 && ((((uintptr_t)A) & 15) == 0) && 2 * tiles <= cus) {
         const int nk = K / SBK;
         // as many slices as fill ~1.5 workgroups per CU, each at least 6 stages long, dividing the stage count

@@ -236,7 +236,7 @@ __device__ __forceinline__ void store_tile_ln(f32x16 (&acc)[TM][TN], const float
 // tile, <= 20 sequences at 5141 rows) serves it afterwards.
 constexpr int kAtLd = 196;              // floats per staged row: 192 + 4 (row stride 784 B = 16 B mod 256: the 16 lanes of a b128 read hit distinct banks)
 constexpr int kAtRows = 160;            // staged rows per pass
-constexpr int kAtCu = 264;              // the tile's sequence offsets (<= 257: sequences of >= 1 row starting inside 256 rows, + the end)
+constexpr int kAtCu = ac::kQkvAttnCu;             // the tile's sequence offsets (<= 257: sequences of >= 1 row starting inside 256 rows, + the end)
 constexpr int kAtBytes = kAtRows * kAtLd * 4 + kAtCu * 4;
 
 template <int TM, int TN, int WMW, int WNW, int AR>

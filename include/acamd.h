@@ -644,6 +644,28 @@ int ac_bert_encode_cls_packed(const ac_bert_config* cfg, const ac_bert_weights* 
                               float* d_out_unit_cls, int64_t ldo,
                               void* d_ws, size_t ws_bytes, ac_stream_t stream);
 
+/*
+ * ac_bert_pack + ac_bert_encode_cls_packed as ONE call with no stream synchronisation in it (the predict paths' form).  One
+ * workgroup derives the packing, the fused attention epilogue's row-tile table and the zeroed exchange words from d_mask and
+ * reports {token rows, not-prefix flag, longest} into a host-mapped slot; the embedding kernel is launched at once over b * S
+ * rows (the real count is read on the device), the host picks the report up while that kernel runs and sizes the GEMM launches
+ * -- the separate form leaves the GPU idle for the D2H round trip (~27 us) and 9 small stream operations in front of the first
+ * GEMM.  More than 32 token rows (fewer: ac_bert_encode_cls, the one persistent launch).
+ *   clear_verdict     1 = the fused-LayerNorm verdict words start clean (what ac_bert_ln_fusion_clear does, without its memset);
+ *                     0 = rolled like every encode call
+ *   *total_tokens     the token rows the forward ran (b * S on the two padded paths)
+ *   *path             AC_BERT_PATH_PACKED; AC_BERT_PATH_PADDED = every row of the mask is all ones: the [b, S] forward without a
+ *                     mask; AC_BERT_PATH_PADDED_MASK = some row's ones are not a non-empty prefix: the [b, S] forward with d_mask
+ * Same results as the separate calls, bit for bit.  Workspace as ac_bert_workspace(b, S).  Replaces classifier.py:1259-1275
+ * (tokenizer output -> model forward -> CLS rows) like ac_bert_encode_cls.
+ */
+#define AC_BERT_PATH_PACKED      0
+#define AC_BERT_PATH_PADDED      1
+#define AC_BERT_PATH_PADDED_MASK 2
+int ac_bert_encode_cls_unpad(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids, const int64_t* d_type_ids,
+                             const int64_t* d_mask, int b, int S, float* d_out_unit_cls, int64_t ldo, void* d_ws, size_t ws_bytes,
+                             int clear_verdict, int* total_tokens, int* path, ac_stream_t stream);
+
 /* ---- ModernBERT encoder ("answerdotai/ModernBERT-base", the reference's other default) ----
  * transformers modeling_modernbert.py: token embeddings -> LayerNorm; `layers` pre-norm blocks
  *   x += Wo attn(rope(Wqkv norm(x)))        (layer 0 has no attn norm; layer l attends globally when

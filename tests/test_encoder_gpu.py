@@ -583,3 +583,71 @@ def test_modernbert_gemm_arith_is_a_per_call_option(cuda_dev):
         enc.encode_cls(ids, None, mask, arith="fp8")
     clf = AdaptiveClassifier("synthetic-modernbert", device=str(cuda_dev), encoder=enc, config={"gemm_arith": "f32"})
     assert torch.equal(clf._encode_tokens(ids, None, mask).cpu(), f32)
+
+
+def test_unpad_one_call_equals_pack_then_encode(cuda_dev, monkeypatch):
+    """ac_bert_encode_cls_unpad (one workgroup derives the packing, the row-tile table and the zeroed exchange words; the embedding
+    kernel starts before the host knows the token count; no stream synchronisation) against the separate form it replaces
+    (ac_bert_pack -> 16-byte read-back -> ac_bert_encode_cls_packed): the same CLS vectors BIT FOR BIT, the same token count,
+    over ragged batches (packed path, with and without the fused attention / LayerNorm epilogues), an all-ones mask (padded path
+    without a mask), a left-padded mask and an empty row (padded path with the mask), a ragged multi-chunk batch with a sticky
+    verdict, and a width whose plan differs between the fewest and the most rows a batch can have (embedding launched late)."""
+    import ctypes
+    from adaptive_classifier import _native as nv, encoder as encmod
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_bert(768, 3, 12, 3072, vocab=3000, seed=2)
+    enc = HipBertEncoder(model, device=cuda_dev, unpad=True)
+
+    def both(ids, types, mask):
+        monkeypatch.setenv("AC_BERT_UNPAD_ONE_CALL", "0")
+        a = enc.encode_cls(ids, types, mask).clone(); ta = enc.last_tokens
+        monkeypatch.setenv("AC_BERT_UNPAD_ONE_CALL", "1")
+        enc._ws[256:].fill_(0x7f)                                # nothing of the earlier call may be what makes this one right
+        c = enc.encode_cls(ids, types, mask).clone(); tc = enc.last_tokens
+        assert ta == tc, (ta, tc)
+        assert torch.equal(torch.isnan(a), torch.isnan(c)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(c)), (a - c).abs().max().item()
+        return c
+
+    for (b, S, seed) in [(256, 32, 1234), (37, 48, 3), (5, 130, 9), (3, 16, 4), (700, 12, 6)]:
+        ids, types, mask = bert_oracle.synthetic_batch(b, S, vocab=3000, seed=seed, ragged=True)
+        types[:, S // 3:] = 1
+        got = both(ids, types, mask)
+        assert enc.last_tokens == int(mask.sum())
+        assert (got.cpu() - bert_oracle.encode_cls(model, ids, types, mask)).abs().max().item() < 1e-4
+    # every row full -> the [b, S] forward without a mask
+    ids, types, mask = bert_oracle.synthetic_batch(40, 16, vocab=3000, seed=7, ragged=False)
+    both(ids, types, mask)
+    assert enc.last_tokens == 40 * 16
+    # left padding, a hole, an empty row -> the [b, S] forward with the mask
+    ids, types, mask = bert_oracle.synthetic_batch(6, 24, vocab=3000, seed=5, ragged=True)
+    for variant in range(3):
+        m = mask.clone()
+        if variant == 0: m = torch.flip(m, dims=[1])
+        elif variant == 1: m[3, 2] = 0
+        else: m[4, :] = 0
+        got = both(ids, types, m)
+        assert enc.last_tokens == 6 * 24
+    # the entry reports its path
+    cfg = enc._call_cfg(None)
+    total, path = ctypes.c_int(0), ctypes.c_int(0)
+    out = torch.empty(6, 768, device=cuda_dev)
+    for m, want_path in ((mask, nv.AC_BERT_PATH_PACKED), (torch.ones_like(mask), nv.AC_BERT_PATH_PADDED), (torch.flip(mask, dims=[1]), nv.AC_BERT_PATH_PADDED_MASK)):
+        idd, md = ids.to(cuda_dev), m.to(cuda_dev).contiguous()
+        nv.check(nv.lib().ac_bert_encode_cls_unpad(ctypes.byref(cfg), ctypes.byref(enc.weights), nv.ptr(idd), None, nv.ptr(md), 6, 24, nv.ptr(out), 768,
+                                                   nv.ptr(enc._ws), enc._ws.numel(), 1, ctypes.byref(total), ctypes.byref(path), nv.stream_ptr(cuda_dev)), "unpad")
+        assert path.value == want_path and total.value == (int(m.sum()) if want_path == nv.AC_BERT_PATH_PACKED else 6 * 24)
+    # several chunks of one call share the workspace; the verdict words are cleared by the FIRST chunk only
+    max_tokens = encmod.MAX_TOKENS
+    monkeypatch.setattr(encmod, "MAX_TOKENS", 60 * 32)
+    ids, types, mask = bert_oracle.synthetic_batch(150, 32, vocab=3000, seed=11, ragged=True)
+    got = both(ids, types, mask)
+    assert torch.isfinite(got).all() and enc.last_tokens == int(mask.sum()) and not enc.ln_fusion_aborted()
+    monkeypatch.setattr(encmod, "MAX_TOKENS", max_tokens)
+    # 100 sequences of <= 2 tokens: 100 rows do not take operand planes, 200 do -> the embedding waits for the count
+    ids, types, mask = bert_oracle.synthetic_batch(100, 2, vocab=3000, seed=13, ragged=True)
+    both(ids, types, mask)
+    # bad arguments are refused before anything is launched
+    rc = nv.lib().ac_bert_encode_cls_unpad(ctypes.byref(cfg), ctypes.byref(enc.weights), nv.ptr(idd), None, None, 6, 24, nv.ptr(out), 768,
+                                           nv.ptr(enc._ws), enc._ws.numel(), 1, ctypes.byref(total), ctypes.byref(path), nv.stream_ptr(cuda_dev))
+    assert rc == -1

@@ -293,3 +293,33 @@ def test_rotated_k_order_sums_every_stage_exactly_once(M, N, K, res, cuda_dev, a
     finally:
         lib.ac_gemm_set_variant(0)
         lib.ac_gemm_set_krot(0)
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (256, 768, 768, 1, False),      # the head's first layer over a predict batch (192 tiles of 32 x 32)
+    (256, 384, 768, 1, False),      # its second layer
+    (256, 4, 384, 0, False),        # its output layer: one column tile, 28 of 32 columns beyond N
+    (256, 3072, 768, 2, False),     # the last encoder layer's FFN over the CLS rows
+    (256, 768, 3072, 0, True),
+    (65, 33, 72, 0, True),          # ragged rows and columns, K = 4.5 slots of 16 (the tail slot is half zeros)
+    (1000, 40, 136, 1, True),       # an odd number of 128-column rounds
+])
+def test_few_tile_kernel_is_an_exact_fp32_product(M, N, K, act, res, cuda_dev, arith):
+    """gemm_fewtiles_nt (gemm.hip): fp32 MFMA products, fp32 accumulation over 8 interleaved K-slices summed in a fixed order.
+    Bars: the a-priori fp32 dot-product bound K * 2^-24 * sum|a||b| (+ one rounding of the epilogue), whatever arithmetic the
+    process is set to (the kernel takes these shapes under both), and the launch must be THIS kernel: same result as with the
+    kernel switched off only to fp32 roundoff, not bit for bit (different summation order) -- the bound is the test."""
+    from adaptive_classifier import _native as nv
+    rng = np.random.default_rng(7 * M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    want = _ref(A, W, b, R, act)
+    bound = K * 2.0 ** -24 * (np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T) + 2.0 ** -23 * np.abs(want) + 1e-6
+    for mode in (F32, BF16X3):
+        arith(mode)
+        got = _linear(nv, cuda_dev, A, W, b, R, act)
+        assert np.isfinite(got).all()
+        es = np.abs(got - want)
+        assert np.all(es <= bound), (mode, es.max(), bound.min())
