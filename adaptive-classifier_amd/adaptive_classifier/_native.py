@@ -173,6 +173,11 @@ _SIGNATURES = {
     "ac_bert_encode_cls_packed": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p, c_void_p,
                                           c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t,
                                           c_void_p]),
+    "ac_bert_unpad_last_wait_ns": (ctypes.c_longlong, []),
+    "ac_predict_post": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "ac_host_alloc": (c_int, [c_size_t, ctypes.POINTER(c_void_p)]),
+    "ac_host_free": (c_int, [c_void_p]),
     "ac_bert_encode_cls_unpad": (c_int, [ctypes.POINTER(ac_bert_config), ctypes.POINTER(ac_bert_weights), c_void_p, c_void_p,
                                          c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_size_t, c_int,
                                          ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p]),

@@ -21,9 +21,11 @@ What changed underneath:
 Each method documents where it intentionally deviates.
 """
 import copy
+import ctypes
 import json
 import logging
 import math
+import os
 from pathlib import Path
 from typing import Any, Dict, List, Optional, Set, Tuple, Union
 
@@ -32,6 +34,10 @@ import torch
 import torch.nn.functional as F
 
 from . import _native as nv
+try:                                    # host-side C helper (csrc/host/hostfast.c, built by the same Makefile); optional: the
+    from . import _hostfast             # Python form of the same list building stays below
+except ImportError:                     # pragma: no cover
+    _hostfast = None
 from .ewc import EWC
 from .memory import PrototypeMemory
 from .models import AdaptiveHead, Example, ModelConfig
@@ -571,6 +577,15 @@ class AdaptiveClassifier:
         """The packed result of _blend_device (already on the host, numpy uint8) -> list of (label, score) per query.
         NaN scores: noted in self._last_nan; check=True additionally asks the encoder whether it gave up and raises if so."""
         b, kk, off_cls, off_val, C = layout
+        kcap = min(kk, k) if k >= 0 else 0
+        if _hostfast is not None:                                # one C pass (csrc/host/hostfast.c): same lists, ~5x faster
+            names = getattr(self, "_label_tuple", None)
+            if names is None or names[0] is not self.id_to_label or len(names[1]) != C or (C <= 64 and names[2] != tuple(self.id_to_label.values())):
+                names = self._label_tuple = (self.id_to_label, tuple(self.id_to_label[c] for c in range(C)), tuple(self.id_to_label.values()))
+            res, self._last_nan = _hostfast.unpack(names[1], host, b, kk, off_cls, off_val, kcap)
+            if self._last_nan and check:
+                self._raise_if_encoder_gave_up()
+            return res
         n = host[:off_cls].view(np.int32)
         cls = host[off_cls:off_cls + 4 * b * kk].view(np.int32)
         val = host[off_val:].view(np.float64)
@@ -582,7 +597,6 @@ class AdaptiveClassifier:
             names = self._label_array = (self.id_to_label, np.array([self.id_to_label[c] for c in range(C)], dtype=object))
         # one pass over the flat arrays (a tuple per hit is what the reference returns); rows are slices of it
         pairs = list(zip(names[1][np.clip(cls, 0, C - 1)].tolist(), val.tolist()))
-        kcap = min(kk, k) if k >= 0 else 0
         if int(n.min()) >= kcap:
             return [pairs[i:i + kcap] for i in range(0, b * kk, kk)]
         n = n.tolist()
@@ -683,8 +697,7 @@ class AdaptiveClassifier:
 
         def finish(emb):
             max_classes = len(self.id_to_label) if self.id_to_label else k
-            S, I, P = self._device_stage(emb, max_classes)
-            res = self._finish(S, I, P, k, regular=True, b=1, check=False)[0]
+            res = self._finish_from_embeddings(emb, k, regular=True, check=False, k_proto=max_classes)[0]
             return res, any(s != s for _, s in res)
         return self._predict_with_retry(encode, finish)
 
@@ -714,15 +727,83 @@ class AdaptiveClassifier:
 
     def _predict_batch_core(self, encode, k):
         def finish(emb):
-            S, I, P = self._device_stage(emb, k)
-            res = self._finish(S, I, P, k, regular=False, b=emb.shape[0], check=False)
+            res = self._finish_from_embeddings(emb, k, regular=False, check=False)
             return res, self._last_nan
         return self._predict_with_retry(encode, finish)
 
+    # ---- the tail of a batch in one launch + no copy (include/acamd.h ac_predict_post) ------------------------------------------
+    _POST_MAX_HITS = 1024
+
+    def _post_buffer(self, nbytes: int):
+        """This classifier's host-mapped result buffer (ac_host_alloc), grown as needed: (address, numpy uint8 view)."""
+        buf = getattr(self, "_post_buf", None)
+        if buf is None or buf[2] < nbytes:
+            if buf is not None:
+                nv.lib().ac_host_free(buf[0])
+            size = max(1 << 16, 2 * nbytes)
+            p = ctypes.c_void_p()
+            nv.check(nv.lib().ac_host_alloc(size, ctypes.byref(p)), "ac_host_alloc")
+            view = np.frombuffer((ctypes.c_ubyte * size).from_address(p.value), dtype=np.uint8)
+            buf = self._post_buf = (p, view, size)
+        return buf[0], buf[1]
+
+    def __del__(self):
+        buf = getattr(self, "_post_buf", None)
+        if buf is not None:
+            try:
+                self._post_buf = None
+                nv.lib().ac_host_free(buf[0])
+            except Exception:       # interpreter shutdown
+                pass
+
+    def _finish_from_embeddings(self, emb: torch.Tensor, k: int, regular: bool, check: bool = True, k_proto: Optional[int] = None):
+        """Embeddings -> the reference's list of (label, score) per query.  One native call after the search and the head's
+        forward (ac_predict_post: prototype scores, hit classes, F.softmax, blend, top-k, the packed result written straight
+        into host-mapped memory and waited for without a stream synchronisation); the separate kernels + a D2H copy
+        (_device_stage / _finish) beyond its limits (2048 classes, 1024 hits per query) or with AC_PREDICT_POST=0."""
+        C = len(self.id_to_label)
+        b = emb.shape[0]
+        k_proto = k if k_proto is None else k_proto
+        mode = os.environ.get("AC_PREDICT_POST", "1")
+        if (mode == "0" or C < 1 or C > self._BLEND_DEVICE_MAX_CLASSES or b == 0
+                or k_proto > self._POST_MAX_HITS or not emb.is_cuda):
+            S, Cid, P = self._device_stage(emb, k_proto)
+            return self._finish(S, Cid, P, k, regular=regular, b=b, check=check)
+        self._last_nan = False
+        with torch.no_grad():
+            D = I = head = None
+            cmap = (None, 0, None, 0)
+            if self.memory.index.ntotal > 0 or self.memory.updates_since_rebuild >= self.config.prototype_update_frequency:
+                D, I = self.memory.search_raw(emb, k_proto)
+                D, I = D.contiguous(), I.contiguous()
+                cmap = self.memory.class_map(self.label_to_id, emb.device)
+            if self.adaptive_head is not None:
+                self.adaptive_head.eval()
+                head = self._head_outputs(emb).contiguous()
+        if D is None and head is None:
+            return [[] for _ in range(b)]
+        kp = 0 if D is None else D.shape[1]
+        kk = max(1, min(k, C))
+        w = self._blend_weights(regular)
+        ncls = C if regular else min(k, C)
+        off_cls = 4 * b
+        off_val = (off_cls + 4 * b * kk + 7) // 8 * 8
+        need = (off_val + 8 * b * kk + 15) // 16 * 16
+        addr, view = self._post_buffer(need)
+        stage = getattr(self, "_post_stage", None)
+        if stage is None or stage.numel() < need or stage.device != emb.device:
+            stage = self._post_stage = torch.empty(max(1 << 16, 2 * need), dtype=torch.uint8, device=emb.device)
+        with torch.cuda.device(emb.device):
+            nv.check(nv.lib().ac_predict_post(nv.ptr(D), nv.ptr(I), kp, nv.ptr(cmap[0]), cmap[1], nv.ptr(cmap[2]), cmap[3],
+                                              nv.ptr(head), C, 1, w[0].data_ptr(), w[1].data_ptr(), ncls, kk, b, nv.ptr(stage), need,
+                                              None if mode == "2" else addr, nv.stream_ptr(emb.device)), "ac_predict_post")
+        if mode == "2":                 # (A/B: the fused kernel with an ordinary D2H copy of its result)
+            return self._unpack(stage[:need].cpu().numpy(), (b, kk, off_cls, off_val, C), k, check)
+        return self._unpack(view[:need], (b, kk, off_cls, off_val, C), k, check)
+
     def predict_embeddings(self, emb: torch.Tensor, k: int = 5) -> List[List[Tuple[str, float]]]:
         """predict_batch() after the encoder: device kNN + head, then the blend of :1359-1384."""
-        S, I, P = self._device_stage(emb, k)
-        return self._finish(S, I, P, k, regular=False, b=emb.shape[0])
+        return self._finish_from_embeddings(emb, k, regular=False)
 
     def _blend(self, S, Cid, P, k, regular):
         """The two score-combination formulas of the reference, evaluated in fp64 like its Python floats,

@@ -476,18 +476,28 @@ class PrototypeMemory:
             if self._row_labels is None and self.updates_since_rebuild >= self.config.prototype_update_frequency:
                 self._rebuild_index()
             self._flush_dirty()
-            sharded = getattr(self, "_sharded", None)
-            if sharded is not None and (sharded.world > 1 or sharded.force_collectives):
-                D, I = sharded.search_block(queries, k)       # this rank's queries against every rank's row shard
-                return proto_scores(D, I), I, D
-            k = min(k, max(self.index.ntotal, 1))
-            D, I = self.index.search_device(queries, k)
+            D, I = self._search_locked(queries, k)
             return proto_scores(D, I), I, D
 
-    def hit_class_ids(self, I: torch.Tensor, label_to_id: Dict[str, int]) -> torch.Tensor:
-        """Classifier class id of every hit row id in I [b, k] (-1 = padding / unknown label), on device,
-        one native launch (`ac_rows_to_class`)."""
-        dev = I.device
+    def search_raw(self, queries: torch.Tensor, k: int):
+        """search_batch without the score kernel: (dist [b,k] f32, row ids [b,k] i64) on the device -- the inputs of
+        ac_predict_post, which derives the scores itself."""
+        with self._lock:
+            if self._row_labels is None and self.updates_since_rebuild >= self.config.prototype_update_frequency:
+                self._rebuild_index()
+            self._flush_dirty()
+            return self._search_locked(queries, k)
+
+    def _search_locked(self, queries, k):
+        sharded = getattr(self, "_sharded", None)
+        if sharded is not None and (sharded.world > 1 or sharded.force_collectives):
+            return sharded.search_block(queries, k)           # this rank's queries against every rank's row shard
+        k = min(k, max(self.index.ntotal, 1))
+        return self.index.search_device(queries, k)
+
+    def class_map(self, label_to_id: Dict[str, int], dev):
+        """(row_class int32 tensor or None, nrows, lut int64 tensor, nlut): hit row id -> classifier class id, the arguments
+        of ac_rows_to_class / ac_predict_post (None row_class: row id == index of the label in index_to_label)."""
         if self._row_labels is not None:
             names, row_class, nrows = self._row_label_names, self._row_labels, int(self._row_labels.numel())
         else:
@@ -498,12 +508,18 @@ class PrototypeMemory:
         if cached is None or cached[0] != key or cached[1].device != dev:
             cached = (key, torch.tensor(key if key else (-1,), dtype=torch.int64, device=dev))
             self._class_lut_cache = cached
-        lut = cached[1]
+        return row_class, nrows, cached[1], len(key)
+
+    def hit_class_ids(self, I: torch.Tensor, label_to_id: Dict[str, int]) -> torch.Tensor:
+        """Classifier class id of every hit row id in I [b, k] (-1 = padding / unknown label), on device,
+        one native launch (`ac_rows_to_class`)."""
+        dev = I.device
+        row_class, nrows, lut, nlut = self.class_map(label_to_id, dev)
         I = I.contiguous()
         out = torch.empty_like(I)
         with torch.cuda.device(dev):
             nv.check(nv.lib().ac_rows_to_class(nv.ptr(I), I.numel(), nv.ptr(row_class), nrows, nv.ptr(lut),
-                                               len(key), nv.ptr(out), nv.stream_ptr(dev)), "ac_rows_to_class")
+                                               nlut, nv.ptr(out), nv.stream_ptr(dev)), "ac_rows_to_class")
         return out
 
     # ------------------------------------------------------------------ misc API

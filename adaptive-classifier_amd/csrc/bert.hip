@@ -15,6 +15,7 @@
 
 #include <math.h>
 #include <atomic>
+#include <chrono>
 #include <string.h>
 
 namespace {
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __re
                                                              unsigned* __restrict__ zero_b, int zero_b_words, unsigned* __restrict__ verdict,
                                                              int clear_verdict, int32_t* host_slot, int epoch) {
     extern __shared__ int32_t pk_lds[];                 // lens[b] | cu[b + 1]
-    __shared__ int part[1024];
+    __shared__ int part[16];
     __shared__ int s_bad, s_longest;
     int32_t* lens = pk_lds;
     int32_t* cus = pk_lds + b;
@@ -401,12 +402,20 @@ __global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __re
         else { verdict[1] |= verdict[0]; verdict[0] = 0u; }
     }
     int bad = 0;
-    for (int i = tid; i < n; i += 1024) {               // ones form a prefix of the row <=> no one right after a zero
-        const int p = i % S;
-        if (mask[i] != 0) {
-            atomicAdd(&lens[i / S], 1);
-            if (p > 0 && mask[i - 1] == 0) bad = 1;
+    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {        // ones form a prefix of the row <=> no one right after a zero
+        int64_t m[4], mp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                   // (eight independent loads in flight before the first use)
+            const int i = i0 + 1024 * u;
+            m[u] = i < n ? mask[i] : 0;
+            mp[u] = (i < n && (i % S) > 0) ? mask[i - 1] : 1;
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (m[u] != 0) {
+                atomicAdd(&lens[(i0 + 1024 * u) / S], 1);
+                if (mp[u] == 0) bad = 1;
+            }
     }
     if (bad) s_bad = 1;
     __syncthreads();
@@ -419,18 +428,35 @@ __global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __re
     }
     if (bad) s_bad = 1;
     if (mx) atomicMax(&s_longest, mx);
-    part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {                // inclusive Hillis-Steele scan of the partial sums
-        const int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    // inclusive scan of the 1024 partial sums: inside each wave on shuffles, then the 16 wave totals (two barriers instead of the
+    // twenty of a Hillis-Steele pass over LDS)
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
     }
-    int run = tid ? part[tid - 1] : 0;
+    if ((tid & 63) == 63) part[tid >> 6] = incl;
+    __syncthreads();
+    int wave_base = 0, grand = 0;
+#pragma unroll
+    for (int wv = 0; wv < 16; ++wv) {
+        const int t = part[wv];
+        if (wv < (tid >> 6)) wave_base += t;
+        grand += t;
+    }
+    incl += wave_base;
+    int run = incl - sum;
     for (int i = tid * per; i < (tid + 1) * per && i < b; ++i) { cus[i] = run; cu[i] = run; run += lens[i]; }
-    const int total = part[1023];
-    if (tid == 0) { cus[b] = total; cu[b] = total; info[0] = total; info[1] = s_bad; info[2] = s_longest; info[3] = 0; }
+    const int total = grand;
+    if (tid == 0) {
+        cus[b] = total; cu[b] = total; info[0] = total; info[1] = s_bad; info[2] = s_longest; info[3] = 0;
+        if (host_slot) {                                // the host's copy leaves now: it sizes the GEMM launches while the rest runs
+            host_slot[0] = total; host_slot[1] = s_bad; host_slot[2] = s_longest;
+            __threadfence_system();
+            __hip_atomic_store(&host_slot[3], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const int q = i / S, p = i - q * S;
@@ -447,11 +473,6 @@ __global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __re
             else if (i - 1 <= ns) v = cus[sb + i - 1];
             tile_seq[(size_t)t * ac::kQkvAttnCu + i] = v;
         }
-    }
-    if (tid == 0 && host_slot) {
-        host_slot[0] = total; host_slot[1] = s_bad; host_slot[2] = s_longest;
-        __threadfence_system();
-        __hip_atomic_store(&host_slot[3], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 // The verdict of the fused-LayerNorm GEMM epilogues sits at offset 0 of the workspace WHATEVER (b, S) the workspace is used
@@ -832,6 +853,10 @@ int32_t* info_slot(int* epoch_out) {
 }
 }  // namespace
 
+// (measurement: how long the last ac_bert_encode_cls_unpad call waited for the packing kernel's report, launch latency included)
+static std::atomic<long long> g_unpad_wait_ns{0};
+extern "C" long long ac_bert_unpad_last_wait_ns(void) { return g_unpad_wait_ns.load(std::memory_order_relaxed); }
+
 // ac_bert_pack + ac_bert_encode_cls_packed as ONE call without a stream synchronisation (include/acamd.h)
 extern "C" int ac_bert_encode_cls_unpad(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids,
                                         const int64_t* d_type_ids, const int64_t* d_mask, int b, int S, float* d_out, int64_t ldo,
@@ -875,6 +900,7 @@ extern "C" int ac_bert_encode_cls_unpad(const ac_bert_config* cfg, const ac_bert
     // empty), then a blocking wait for whatever was queued ahead of this call
     volatile int32_t* vs = slot;
     bool seen = false;
+    const auto wait_t0 = std::chrono::steady_clock::now();
     for (int spin = 0; spin < 200000 && !seen; ++spin) {
         seen = __atomic_load_n(&vs[3], __ATOMIC_ACQUIRE) == epoch;
         if (!seen) __builtin_ia32_pause();
@@ -884,6 +910,8 @@ extern "C" int ac_bert_encode_cls_unpad(const ac_bert_config* cfg, const ac_bert
         seen = __atomic_load_n(&vs[3], __ATOMIC_ACQUIRE) == epoch;
         AC_REQUIRE(seen, AC_EHIP, "bert_encode_cls_unpad: the packing kernel's report never arrived");
     }
+    g_unpad_wait_ns.store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - wait_t0).count(),
+                          std::memory_order_relaxed);
     const int total = vs[0], not_prefix = vs[1], longest = vs[2];
     if (total_tokens) *total_tokens = total;
     if (!not_prefix && total < b * S) {

@@ -577,6 +577,28 @@ int ac_blend_topk(const float* d_scores, const int64_t* d_hit_class, int kp,
                   int32_t* d_out_n, int32_t* d_out_class, double* d_out_score,
                   ac_stream_t stream);
 
+/*
+ * The whole tail of a predict batch in ONE launch: ac_proto_scores + ac_rows_to_class + ac_softmax_rows + ac_blend_topk (the
+ * same arithmetic in the same order; results bit for bit those of the four calls), and -- wait_host = 1 -- without a copy or
+ * a stream synchronisation: the workgroup that finishes last copies the packed result from `out` (device memory) into h_out
+ * (host-mapped memory from ac_host_alloc, at least as large) and publishes a completion flag the call spins on (falling
+ * back to a blocking wait); the call returns when h_out can be read by the host.  h_out = NULL: asynchronous, result in `out`.
+ *   d_dist / d_ids [b, kp]   the search's fp32 distances and int64 row ids (both NULL: no prototype hits); kp <= 1024
+ *   d_row_class / nrows / d_class_lut / nlut   as ac_rows_to_class
+ *   d_head [b, C]            the head's outputs (NULL: none); head_softmax = 1 applies F.softmax over them first
+ *   d_w_proto / d_w_head / ncls_head / k       as ac_blend_topk;  C <= 2048
+ *   out                      n[b] int32 | class[b, k] int32 | score[b, k] float64 at byte offsets 0, 4 b, round_up(4 b + 4 b k, 8)
+ *                            (device memory, 16-byte aligned, out_bytes >= that size rounded up to 16; h_out receives the same bytes)
+ * Replaces classifier.py:1347-1384 (prototype scores, label lookup, F.softmax, the blend and its sort) for a whole batch.
+ * ac_host_alloc: page-locked, device-mapped, fine-grained host memory (hipHostMalloc coherent | mapped).
+ */
+int ac_predict_post(const float* d_dist, const int64_t* d_ids, int kp, const int32_t* d_row_class, int64_t nrows,
+                    const int64_t* d_class_lut, int nlut, const float* d_head, int C, int head_softmax,
+                    const double* d_w_proto, const double* d_w_head, int ncls_head, int k, int b, void* out,
+                    size_t out_bytes, void* h_out, ac_stream_t stream);
+int ac_host_alloc(size_t bytes, void** p);
+int ac_host_free(void* p);
+
 int ac_bert_workspace(const ac_bert_config* cfg, int b, int S, size_t* bytes);
 
 /*
@@ -665,6 +687,9 @@ int ac_bert_encode_cls_packed(const ac_bert_config* cfg, const ac_bert_weights* 
 int ac_bert_encode_cls_unpad(const ac_bert_config* cfg, const ac_bert_weights* w, const int64_t* d_ids, const int64_t* d_type_ids,
                              const int64_t* d_mask, int b, int S, float* d_out_unit_cls, int64_t ldo, void* d_ws, size_t ws_bytes,
                              int clear_verdict, int* total_tokens, int* path, ac_stream_t stream);
+/* measurement: nanoseconds the last ac_bert_encode_cls_unpad call spent waiting for the packing kernel's report (its launch
+ * latency + run time + the host-mapped store); tools/r06_gap_probe.py */
+long long ac_bert_unpad_last_wait_ns(void);
 
 /* ---- ModernBERT encoder ("answerdotai/ModernBERT-base", the reference's other default) ----
  * transformers modeling_modernbert.py: token embeddings -> LayerNorm; `layers` pre-norm blocks

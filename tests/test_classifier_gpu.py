@@ -695,3 +695,82 @@ def test_residency_is_proven_at_launch_not_discovered_by_a_wait(cuda_dev, cu_mas
         assert out["active"] < out["chip"]
         # 192 LayerNorm tiles / 192 one-launch workgroups do not fit the masked CUs: the unfused forms run, chosen up front
         assert out["ln_fused_launches"] == 0 and not out["one_launch"] and out["bert_small_launches"] == 0
+
+
+@pytest.mark.parametrize("C,kp,k,regular", [(4, 16, 16, False), (4, 4, 3, True), (37, 16, 5, False), (300, 24, 7, False),
+                                            (2048, 8, 4, True), (5, 1024, 5, False), (70, 1, 70, True)])
+def test_predict_post_equals_the_four_kernels_it_replaces(C, kp, k, regular, cuda_dev):
+    """ac_predict_post (prototype scores + hit classes + F.softmax + blend + top-k in one launch, the packed result written
+    into host-mapped memory and waited for on a completion flag) against ac_proto_scores -> ac_rows_to_class ->
+    ac_softmax_rows -> ac_blend_topk -> D2H: the same packed bytes, over random distances with padding ids (-1), ids beyond
+    the store, labels unknown to the classifier, a row -> class map with several rows per class, tied logits; with and
+    without hits / head; without a host buffer (asynchronous form) the device buffer holds the same bytes."""
+    import ctypes
+    from adaptive_classifier import _native as nv
+    from adaptive_classifier.ops import softmax_rows
+    from adaptive_classifier.index import proto_scores
+    rng = np.random.default_rng(C * 7 + kp)
+    b, nrows, nlut = 41, 5000, C + 3
+    D = np.sort(rng.random((b, kp)).astype(np.float32) * 2, axis=1)
+    I = rng.integers(-1, nrows + 40, (b, kp)).astype(np.int64)
+    I[2, :] = -1
+    row_class = rng.integers(0, nlut, nrows).astype(np.int32)
+    lut = np.concatenate([rng.permutation(C), [-1, -1, -1]]).astype(np.int64)[rng.permutation(nlut)]
+    Z = (rng.standard_normal((b, C)) * 3).astype(np.float32)
+    Z[3, :] = 0.5
+    wts = torch.tensor(rng.choice([0.3, 0.7], size=(2, C)), dtype=torch.float64, device=cuda_dev)
+    dev = lambda a: torch.from_numpy(a).to(cuda_dev)
+    Dd, Id, rc, lt, Zd = dev(D), dev(I), dev(row_class), dev(lut), dev(Z)
+    kk = max(1, min(k, C)); ncls = C if regular else min(k, C)
+    off_cls = 4 * b; off_val = (off_cls + 4 * b * kk + 7) // 8 * 8; need = (off_val + 8 * b * kk + 15) // 16 * 16
+    lib = nv.lib()
+    sp = nv.stream_ptr(cuda_dev)
+    hp = ctypes.c_void_p()
+    nv.check(lib.ac_host_alloc(need + 64, ctypes.byref(hp)), "ac_host_alloc")
+    host = np.frombuffer((ctypes.c_ubyte * (need + 64)).from_address(hp.value), dtype=np.uint8)
+    try:
+        for use_hits, use_head in ((True, True), (True, False), (False, True)):
+            # the separate kernels
+            S = Cid = P = None
+            if use_hits:
+                S = proto_scores(Dd, Id)
+                Cid = torch.empty_like(Id)
+                nv.check(lib.ac_rows_to_class(nv.ptr(Id), Id.numel(), nv.ptr(rc), nrows, nv.ptr(lt), nlut, nv.ptr(Cid), sp), "rows_to_class")
+            if use_head:
+                P = softmax_rows(Zd)
+            want = torch.zeros(need, dtype=torch.uint8, device=cuda_dev)
+            base = want.data_ptr()
+            nv.check(lib.ac_blend_topk(nv.ptr(S), nv.ptr(Cid), kp if use_hits else 0, nv.ptr(P), C, wts[0].data_ptr(), wts[1].data_ptr(), ncls, kk, b,
+                                       base, base + off_cls, base + off_val, sp), "blend")
+            want = want.cpu().numpy()
+            n = want[:off_cls].view(np.int32)
+            for wait_host in (1, 0):
+                host[:] = 0xAB
+                got_d = torch.zeros(need, dtype=torch.uint8, device=cuda_dev)
+                nv.check(lib.ac_predict_post(nv.ptr(Dd) if use_hits else None, nv.ptr(Id) if use_hits else None, kp, nv.ptr(rc), nrows, nv.ptr(lt), nlut,
+                                             nv.ptr(Zd) if use_head else None, C, 1, wts[0].data_ptr(), wts[1].data_ptr(), ncls, kk, b, nv.ptr(got_d), need,
+                                             hp if wait_host else None, sp), "ac_predict_post")
+                got = host[:need].copy() if wait_host else got_d.cpu().numpy()      # (h_out given: no synchronisation by the caller)
+                assert np.array_equal(got[:off_cls], want[:off_cls]), (use_hits, use_head, wait_host, got[:off_cls].view(np.int32), n)
+                gc, wc = got[off_cls:off_cls + 4 * b * kk].view(np.int32).reshape(b, kk), want[off_cls:off_cls + 4 * b * kk].view(np.int32).reshape(b, kk)
+                gv, wv = (a[off_val:off_val + 8 * b * kk].view(np.float64).reshape(b, kk) for a in (got, want))
+                for q in range(b):               # (entries beyond n[q] are not written by either form)
+                    assert np.array_equal(gc[q, :n[q]], wc[q, :n[q]]) and np.array_equal(gv[q, :n[q]], wv[q, :n[q]]), (q, use_hits, use_head, wait_host)
+        assert lib.ac_predict_post(nv.ptr(Dd), nv.ptr(Id), 1025, None, 0, None, 0, None, C, 1, wts[0].data_ptr(), wts[1].data_ptr(), ncls, kk, b, nv.ptr(Dd), need, hp, sp) == -2
+        assert lib.ac_predict_post(nv.ptr(Dd), nv.ptr(Id), kp, None, 0, None, 0, None, C, 1, wts[0].data_ptr(), wts[1].data_ptr(), ncls, kk, b, nv.ptr(Dd), need - 16, hp, sp) == -3
+    finally:
+        nv.check(lib.ac_host_free(hp), "ac_host_free")
+
+
+def test_predictions_do_not_depend_on_the_post_kernel(clf, monkeypatch):
+    """predict / predict_batch / predict_embeddings through ac_predict_post (default) and through the separate kernels
+    (AC_PREDICT_POST=0): identical lists."""
+    texts = TEXTS + ["something else entirely", "good"]
+    monkeypatch.setenv("AC_PREDICT_POST", "0")
+    a_batch = clf.predict_batch(texts, k=3)
+    a_one = [clf.predict(t, k=2) for t in texts[:4]]
+    monkeypatch.setenv("AC_PREDICT_POST", "1")
+    assert clf.predict_batch(texts, k=3) == a_batch
+    assert [clf.predict(t, k=2) for t in texts[:4]] == a_one
+    emb = clf._embed_device(texts)
+    assert clf.predict_embeddings(emb, k=3) == a_batch

@@ -582,3 +582,48 @@ def test_predict_retry_contract_without_a_gpu():
     c = AdaptiveClassifier.__new__(AdaptiveClassifier)
     c.model = Plain()
     assert c._encoder_options() == set() and c._encode_tokens(None, verify=False, force_layered=True) == "e" and c.model.calls == 1
+
+
+def test_hostfast_unpack_builds_the_lists_of_the_python_form():
+    """csrc/host/hostfast.c (CPython extension, built by the same Makefile as the library): the packed device result ->
+    the reference's list of (label, score) lists.  Same objects as classifier.py::_unpack's Python form for ragged counts,
+    k smaller than the packed width, out-of-range class ids (clamped like np.clip) and NaN scores; a layout that does not
+    fit the buffer is refused."""
+    import numpy as np
+    from adaptive_classifier import classifier as cm
+    assert cm._hostfast is not None, "the _hostfast extension was not built (make -C adaptive-classifier_amd/csrc)"
+    rng = np.random.default_rng(3)
+
+    class Obj:
+        _last_nan = False
+        def _raise_if_encoder_gave_up(self):
+            raise AssertionError("check=False must not ask the encoder")
+
+    for (b, kk, C, k) in [(256, 4, 4, 16), (7, 16, 100, 5), (1, 1, 1, 1), (33, 5, 3, 0), (64, 8, 70, 8)]:
+        off_cls = 4 * b
+        off_val = (off_cls + 4 * b * kk + 7) // 8 * 8
+        host = np.zeros(off_val + 8 * b * kk, np.uint8)
+        host[:off_cls].view(np.int32)[:] = rng.integers(0, kk + 1, b)
+        host[off_cls:off_cls + 4 * b * kk].view(np.int32)[:] = rng.integers(-1, C + 1, b * kk)
+        host[off_val:].view(np.float64)[:] = rng.random(b * kk)
+        o = Obj(); o.id_to_label = {i: "label-%d" % i for i in range(C)}
+        layout = (b, kk, off_cls, off_val, C)
+        for nan in (False, True):
+            if nan:
+                host[off_val:].view(np.float64)[b * kk // 2] = np.nan
+            fast = cm.AdaptiveClassifier._unpack(o, host, layout, k, False)
+            assert o._last_nan == nan
+            saved, cm._hostfast = cm._hostfast, None
+            try:
+                slow = cm.AdaptiveClassifier._unpack(o, host, layout, k, False)
+            finally:
+                cm._hostfast = saved
+            assert o._last_nan == nan
+            assert len(fast) == b and all(type(r) is list for r in fast)
+            assert repr(fast) == repr(slow)              # (repr: nan == nan)
+            assert all(type(t) is tuple and type(t[1]) is float for r in fast for t in r)
+        if C <= 64:                     # (small label sets are re-read at every call; big ones are cached by dict identity + size)
+            o.id_to_label[0] = "renamed"
+            assert all(t[0] != "label-0" for r in cm.AdaptiveClassifier._unpack(o, host, layout, k, False) for t in r)
+    with pytest.raises(ValueError):
+        cm._hostfast.unpack(("a",), np.zeros(16, np.uint8), 4, 4, 16, 80, 4)
