@@ -777,6 +777,8 @@ class AdaptiveClassifier:
                 D, I = self.memory.search_raw(emb, k_proto)
                 D, I = D.contiguous(), I.contiguous()
                 cmap = self.memory.class_map(self.label_to_id, emb.device)
+            # (the head's three launches on a side stream under the search's seven: overlapped in the trace, 0.04 ms SLOWER per step --
+            #  two cross-stream waits cost more than 25 us of small kernels; profiles/r06/head_side_stream.txt)
             if self.adaptive_head is not None:
                 self.adaptive_head.eval()
                 head = self._head_outputs(emb).contiguous()

@@ -128,6 +128,96 @@ inline void launch_ln(bool f16, int blocks, hipStream_t stream, const float* in,
     else hipLaunchKernelGGL(ln_kernel_t<false>, dim3(blocks), dim3(256), 0, stream, in, T, H, g, b, eps, out, planes, in_stride);
 }
 
+// The end of the CLS-only last layer in ONE launch (instead of gemm_splitk_reduce -> ln_kernel_t -> cls_normalize_kernel): the K
+// slices of the FFN-down product summed in order + bias + residual, LayerNorm over the row, F.normalize of the result.  One wave
+// per CLS row; same expressions as the three kernels (the norm's sum runs over this kernel's lane layout: equal to fp32 rounding).
+__global__ __launch_bounds__(256) void splitk_ln_normalize_kernel(const float* __restrict__ part, int ksplit, int M, int H,
+                                                                  const float* __restrict__ bias, const float* __restrict__ residual,
+                                                                  int64_t ldr, const float* __restrict__ g, const float* __restrict__ be,
+                                                                  float eps, float* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= M) return;
+    const int nv = H >> 2;
+    const size_t slice = (size_t)M * H;
+    f32x4 x[kMaxVec];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < kMaxVec; ++e) x[e] = zero4;
+    // the slices in order, four at a time: the loads of a group (x kMaxVec vectors) are in flight together -- one slice per
+    // round trip made this kernel 21 us for 256 rows
+    for (int z0 = 0; z0 < ksplit; z0 += 4) {
+        f32x4 t[4][kMaxVec];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < kMaxVec; ++e) {
+                const int c4 = lane + 64 * e;
+                t[u][e] = (z0 + u < ksplit && c4 < nv) ? *reinterpret_cast<const f32x4*>(part + (size_t)(z0 + u) * slice + (size_t)i * H + 4 * c4) : zero4;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (z0 + u < ksplit) {
+#pragma unroll
+                for (int e = 0; e < kMaxVec; ++e)
+                    if (z0 + u == 0) x[e] = t[u][e];
+                    else { x[e].x += t[u][e].x; x[e].y += t[u][e].y; x[e].z += t[u][e].z; x[e].w += t[u][e].w; }
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < kMaxVec; ++e) {
+        const int c4 = lane + 64 * e;
+        if (c4 < nv) {
+            const f32x4 s = x[e];
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(residual + (int64_t)i * ldr + 4 * c4);
+            x[e].x = (s.x + bb.x) + rr.x; x[e].y = (s.y + bb.y) + rr.y; x[e].z = (s.z + bb.z) + rr.z; x[e].w = (s.w + bb.w) + rr.w;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < kMaxVec; ++e)
+        if (lane + 64 * e < nv) s += (x[e].x + x[e].y) + (x[e].z + x[e].w);
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < kMaxVec; ++e)
+        if (lane + 64 * e < nv) {
+            const float d0 = x[e].x - mean, d1 = x[e].y - mean, d2 = x[e].z - mean, d3 = x[e].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    const float var = wave_sum(q) / (float)H;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < kMaxVec; ++e) {
+        const int c4 = lane + 64 * e;
+        if (c4 < nv) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * c4);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 4 * c4);
+            f32x4 y;
+            y.x = (x[e].x - mean) * rstd * gg.x + bb.x;
+            y.y = (x[e].y - mean) * rstd * gg.y + bb.y;
+            y.z = (x[e].z - mean) * rstd * gg.z + bb.z;
+            y.w = (x[e].w - mean) * rstd * gg.w + bb.w;
+            x[e] = y;
+            ss = fmaf(y.x, y.x, ss); ss = fmaf(y.y, y.y, ss); ss = fmaf(y.z, y.z, ss); ss = fmaf(y.w, y.w, ss);
+        }
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+#pragma unroll
+    for (int e = 0; e < kMaxVec; ++e) {
+        const int c4 = lane + 64 * e;
+        if (c4 < nv) {
+            f32x4 y = x[e];
+            y.x = y.x / nrm; y.y = y.y / nrm; y.z = y.z / nrm; y.w = y.w / nrm;
+            float* dst = out + (int64_t)i * ldo + 4 * c4;
+            dst[0] = y.x; dst[1] = y.y; dst[2] = y.z; dst[3] = y.w;                   // (ldo need not be a multiple of 4)
+        }
+    }
+    for (int c = H + lane; c < ldo; c += 64) out[(int64_t)i * ldo + c] = 0.f;
+}
+
 // last_hidden_state[:, 0, :] -> F.normalize(p=2, dim=1, eps=1e-12)
 __global__ __launch_bounds__(256) void cls_normalize_kernel(const float* x, int b, int S, int H, float* out,
                                                             int64_t ldo) {
@@ -190,7 +280,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
 // lane = output dim for the P.V reduction; K tile rows padded to 65 floats (conflict-free column reads).
 // ROPE (ModernBERT): the CLS query is at position 0, whose rotation is the identity, so only the keys rotate;
 // window >= 0: only keys at positions <= window are visible to it.
-template <bool ROPE, int DHT = 64>
+template <bool ROPE, int DHT = 64, int KTT = KT>     // KTT: keys per LDS tile (32 when no sequence is longer: half the LDS, twice the waves per CU)
 __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, const int64_t* mask, int S_, int H,
                                                            float scale, float* ctx_cls, const float* rope_cos,
                                                            const float* rope_sin, int window,
@@ -198,10 +288,10 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
                                                            const float* __restrict__ q_cls = nullptr) {
     // q_cls: the b CLS queries as compact [b, H] rows (BERT's last layer projects Q for those rows only); else column block 0 of qkv
     static_assert(DHT == 64 || (DHT == 32 && !ROPE), "head dim 64, or 32 without RoPE");
-    __shared__ float Ks[KT][DHT + 1];
-    __shared__ __attribute__((aligned(16))) float Vs[KT][DHT];
+    __shared__ float Ks[KTT][DHT + 1];
+    __shared__ __attribute__((aligned(16))) float Vs[KTT][DHT];
     __shared__ float qs[DHT];
-    __shared__ float ps[KT];
+    __shared__ float ps[KTT];
     const int lane = threadIdx.x;
     const int head = blockIdx.x, bi = blockIdx.y;
     const int64_t ld = 3 * (int64_t)H;
@@ -211,11 +301,12 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
     if (lane < DHT) qs[lane] = (q_cls ? q_cls[(int64_t)bi * H + head * DHT + lane] : base[lane]) * scale;     // CLS token = row 0 of the sequence
     float m = -INFINITY, l = 0.f, o = 0.f;      // o: output dim `lane`
     const int Svis = (window >= 0 && window + 1 < S) ? window + 1 : S;     // keys the CLS query can see
-    for (int k0 = 0; k0 < Svis; k0 += KT) {
-        const int nk = (Svis - k0) < KT ? (Svis - k0) : KT;
+    for (int k0 = 0; k0 < Svis; k0 += KTT) {
+        const int nk = (Svis - k0) < KTT ? (Svis - k0) : KTT;
+        const int kl = lane < KTT ? lane : 0;          // (lanes beyond the tile: a valid row, their score is masked)
         __syncthreads();
         constexpr int LPR = DHT / 4;                     // lanes per key row (a float4 each)
-        for (int r = lane / LPR; r < KT; r += 64 / LPR) {
+        for (int r = lane / LPR; r < KTT; r += 64 / LPR) {
             const int c = (lane % LPR) * 4;
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
             if (r < nk) {
@@ -235,13 +326,13 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
             const float* sn = rope_sin + (int64_t)pos * 32;
 #pragma unroll 8
             for (int d = 0; d < 32; ++d) {
-                const float lo = Ks[lane][d], hi = Ks[lane][d + 32], c = cs[d], sv = sn[d];
+                const float lo = Ks[kl][d], hi = Ks[kl][d + 32], c = cs[d], sv = sn[d];
                 sc = fmaf(qs[d], lo * c + (-hi) * sv, sc);
                 sc = fmaf(qs[d + 32], hi * c + lo * sv, sc);
             }
         } else {
 #pragma unroll 16
-            for (int d = 0; d < DHT; ++d) sc = fmaf(qs[d], Ks[lane][d], sc);
+            for (int d = 0; d < DHT; ++d) sc = fmaf(qs[d], Ks[kl][d], sc);
         }
         sc = valid ? sc : -INFINITY;
         float cmax = sc;
@@ -251,7 +342,7 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(const float* qkv, con
         if (m_new == -INFINITY) continue;        // wave-uniform
         const float corr = expf(m - m_new);
         const float p = expf(sc - m_new);        // masked -> 0
-        ps[lane] = p;
+        if (lane < KTT) ps[lane] = p;
         float psum = p;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) psum += __shfl_xor(psum, off);
@@ -387,6 +478,12 @@ __global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __re
                                                              unsigned* __restrict__ zero_b, int zero_b_words, unsigned* __restrict__ verdict,
                                                              int clear_verdict, int32_t* host_slot, int epoch) {
     extern __shared__ int32_t pk_lds[];                 // lens[b] | cu[b + 1]
+#ifdef AC_PROLOGUE_STAMPS
+#define PK_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(info + 16)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PK_STAMP(i) do {} while (0)
+#endif
+    PK_STAMP(0);
     __shared__ int part[16];
     __shared__ int s_bad, s_longest;
     int32_t* lens = pk_lds;
@@ -401,24 +498,30 @@ __global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __re
         if (clear_verdict) { verdict[0] = 0u; verdict[1] = 0u; }
         else { verdict[1] |= verdict[0]; verdict[0] = 0u; }
     }
+    PK_STAMP(1);
     int bad = 0;
-    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {        // ones form a prefix of the row <=> no one right after a zero
-        int64_t m[4], mp[4];
+    for (int i0 = 8 * tid; i0 < n; i0 += 8 * 1024) {    // ones form a prefix of the row <=> no one right after a zero
+        int64_t m[9];                                   // this thread's eight consecutive elements and the one before them:
+        m[0] = i0 > 0 ? mask[i0 - 1] : 1;               // nine independent loads in flight (8.7 -> 3 us against two dependent
+#pragma unroll                                          //  rounds of strided single elements)
+        for (int u = 0; u < 8; ++u) m[u + 1] = i0 + u < n ? mask[i0 + u] : 0;
+        int row = i0 / S, p = i0 - row * S, ones = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                   // (eight independent loads in flight before the first use)
-            const int i = i0 + 1024 * u;
-            m[u] = i < n ? mask[i] : 0;
-            mp[u] = (i < n && (i % S) > 0) ? mask[i - 1] : 1;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (m[u] != 0) {
-                atomicAdd(&lens[(i0 + 1024 * u) / S], 1);
-                if (mp[u] == 0) bad = 1;
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u < n && m[u + 1] != 0) {
+                ++ones;
+                if (p > 0 && m[u] == 0) bad = 1;
             }
+            if (++p == S) {                             // (one LDS atomic per thread and row, not per element)
+                if (ones) atomicAdd(&lens[row], ones);
+                p = 0; ++row; ones = 0;
+            }
+        }
+        if (ones) atomicAdd(&lens[row], ones);
     }
     if (bad) s_bad = 1;
     __syncthreads();
+    PK_STAMP(2);
     const int per = (b + 1023) / 1024;
     int sum = 0, mx = 0;
     for (int i = tid * per; i < (tid + 1) * per && i < b; ++i) {
@@ -427,7 +530,9 @@ __global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __re
         if (l == 0) bad = 1;
     }
     if (bad) s_bad = 1;
-    if (mx) atomicMax(&s_longest, mx);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }
+    if ((tid & 63) == 0 && mx) atomicMax(&s_longest, mx);        // (one atomic per wave: 256 on one LDS word cost 3 us)
     // inclusive scan of the 1024 partial sums: inside each wave on shuffles, then the 16 wave totals (two barriers instead of the
     // twenty of a Hillis-Steele pass over LDS)
     int incl = sum;
@@ -449,6 +554,7 @@ __global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __re
     int run = incl - sum;
     for (int i = tid * per; i < (tid + 1) * per && i < b; ++i) { cus[i] = run; cu[i] = run; run += lens[i]; }
     const int total = grand;
+    PK_STAMP(3);
     if (tid == 0) {
         cus[b] = total; cu[b] = total; info[0] = total; info[1] = s_bad; info[2] = s_longest; info[3] = 0;
         if (host_slot) {                                // the host's copy leaves now: it sizes the GEMM launches while the rest runs
@@ -458,10 +564,12 @@ __global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __re
         }
     }
     __syncthreads();
+    PK_STAMP(4);
     for (int i = tid; i < n; i += 1024) {
         const int q = i / S, p = i - q * S;
         if (p < lens[q]) tok_src[cus[q] + p] = i;
     }
+    PK_STAMP(5);
     // the row-tile table (gemm_pipe.hip qkv_attn_tile_seq_kernel): a wave per tile
     const int ntiles = (total + ac::kQkvAttnRows - 1) / ac::kQkvAttnRows, lane = tid & 63;
     for (int t = tid >> 6; t < ntiles; t += 16) {
@@ -474,6 +582,7 @@ __global__ __launch_bounds__(1024) void pack_prologue_kernel(const int64_t* __re
             tile_seq[(size_t)t * ac::kQkvAttnCu + i] = v;
         }
     }
+    PK_STAMP(6);
 }
 // The verdict of the fused-LayerNorm GEMM epilogues sits at offset 0 of the workspace WHATEVER (b, S) the workspace is used
 // with: word 0 = "a panel of the CURRENT call gave up" (set by the kernels; later launches of the call stop waiting at their first
@@ -553,6 +662,11 @@ namespace {
 
 // shared body of ac_bert_encode_cls (cu == nullptr: the [b, S] rows incl. padding, T = b * S) and
 // ac_bert_encode_cls_packed (cu / tok_src from ac_bert_pack: T = cu[b] real-token rows, no mask)
+// AC_BERT_TAIL_FUSED=0: the last layer ends with gemm_splitk_reduce -> ln_kernel_t -> cls_normalize_kernel (A/B runs, the equivalence test)
+static bool tail_fused() {
+    const char* e = getenv("AC_BERT_TAIL_FUSED");
+    return !(e && atoi(e) == 0);
+}
 // What of a forward is decided by the token-row count alone: operand planes between the GEMMs, fp16x2 planes
 struct EncodePlan { bool wplanes, pl, f16; };
 EncodePlan encode_plan(const ac_bert_config& c, const ac_bert_weights* w, int T) {
@@ -699,7 +813,10 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
             // (context rows are already in ctxp)
         } else if (last) {
             const float* qc = q_cls_only ? y : nullptr;
-            if (dh == 64)
+            if (dh == 64 && Smax <= 32)
+                hipLaunchKernelGGL((attention_cls_kernel<false, 64, 32>), dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale,
+                                   ctx, nullptr, nullptr, -1, cu, qc);
+            else if (dh == 64)
                 hipLaunchKernelGGL((attention_cls_kernel<false, 64>), dim3(c.heads, b), dim3(64), 0, stream, qkv, d_mask, S, H, scale,
                                    ctx, nullptr, nullptr, -1, cu, qc);
             else
@@ -744,6 +861,23 @@ int bert_encode_impl(const ac_bert_config* cfg, const ac_bert_weights* w, const 
                                          base + ws.lnpart, ln_count + (size_t)(2 * l + 1) * ln_panels, ln_abort, xp, stream, (int)f16);
             if (rc) return rc;
             continue;
+        }
+        if (last && tail_fused()) {
+            // the forward's last three launches as one: K slices + bias + residual -> LayerNorm -> F.normalize -> d_out
+            int ks = 0;
+            rc = ac::linear_f32_splitk(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, ff2_w3, qkv,
+                                       (size_t)T * 3 * H * sizeof(float), stream, 0, &ks);
+            if (rc) return rc;
+            if (ks > 0) {
+                // (a wave per CLS row, a workgroup each: spread over the CUs)
+                hipLaunchKernelGGL(splitk_ln_normalize_kernel, dim3(b), dim3(64), 0, stream, qkv, ks, b, H, w->ff2_b[l], x1, (int64_t)H,
+                                   w->ln2_g[l], w->ln2_b[l], c.ln_eps, d_out, ldo);
+                AC_LAUNCH_CHECK();
+                return AC_OK;
+            }
+            launch_ln(f16, lblocks, stream, y, Ml, H, w->ln2_g[l], w->ln2_b[l], c.ln_eps, x, nullptr, (int64_t)H);
+            AC_LAUNCH_CHECK();
+            break;                                     // (the product did not take the split-K form: the separate kernels)
         }
         rc = last ? ac::linear_f32_splitk(ffn, I, w->ff2_w[l], I, w->ff2_b[l], x1, H, y, H, Ml, H, I, 0, ff2_w3, qkv,
                                           (size_t)T * 3 * H * sizeof(float), stream)

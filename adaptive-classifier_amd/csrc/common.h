@@ -82,7 +82,7 @@ int linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const f
 // split-K form of linear_f32 for GEMMs with few output tiles (W planes required, scratch = ksplit * M * N floats)
 int linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,
                       int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act, const uint16_t* W_planes, float* scratch,
-                      size_t scratch_bytes, hipStream_t stream, int64_t w_plane_rows = 0);
+                      size_t scratch_bytes, hipStream_t stream, int64_t w_plane_rows = 0, int* partials_only = nullptr);
 // gemm_pipe.hip:
 // bias + residual + LayerNorm fused into the epilogue (one-round launches of the 128 x 128 tile only: see gemm_pipe.hip);
 // `count` = one zeroed word per 128-row panel, `part` = pipe_ln_part_bytes() of scratch, C may alias the residual

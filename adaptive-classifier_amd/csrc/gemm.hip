@@ -993,7 +993,11 @@ int linear_f16x2(const uint16_t* Ap, const uint16_t* Wp, const float* bias, cons
 // linear_f32 when the shape has enough tiles, the arithmetic is not bf16x3, or the scratch is too small.
 int linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,
                       int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int act, const uint16_t* Wp, float* scratch,
-                      size_t scratch_bytes, hipStream_t stream, int64_t w_plane_rows) {
+                      size_t scratch_bytes, hipStream_t stream, int64_t w_plane_rows, int* partials_only) {
+    // partials_only: the caller finishes a split-K product itself (bert.hip splitk_ln_kernel: slices + bias + residual + LayerNorm in
+    // one launch): on return *partials_only = the number of [M, N] slices left in `scratch` and NOTHING was written to C -- or 0, and
+    // the whole linear ran as usual
+    if (partials_only) *partials_only = 0;
     const int cus = dev_info().cus;
     const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + BN - 1) / BN);
     int ksplit = 1;
@@ -1012,6 +1016,7 @@ int linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, 
     hipLaunchKernelGGL(gemm_planes_splitk_nt, dim3((unsigned)(tiles * ksplit)), dim3(256), 0, stream, A, lda, Wp,
                        w_plane_rows > 0 ? w_plane_rows : (int64_t)N, scratch, M, N, K, ksplit);
     AC_LAUNCH_CHECK();
+    if (partials_only) { *partials_only = ksplit; return AC_OK; }
     Epilogue e;
     e.bias = bias; e.residual = residual; e.ldr = ldr; e.act = act; e.alpha = 1.f; e.beta = 0.f;
     e.mask = nullptr; e.mask_scale = 1.f; e.gate = nullptr; e.ldg = 0; e.gate_scale = 1.f; e.drop_p = 0.f; e.drop_seed = 0;

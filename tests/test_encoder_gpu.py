@@ -651,3 +651,27 @@ def test_unpad_one_call_equals_pack_then_encode(cuda_dev, monkeypatch):
     rc = nv.lib().ac_bert_encode_cls_unpad(ctypes.byref(cfg), ctypes.byref(enc.weights), nv.ptr(idd), None, None, 6, 24, nv.ptr(out), 768,
                                            nv.ptr(enc._ws), enc._ws.numel(), 1, ctypes.byref(total), ctypes.byref(path), nv.stream_ptr(cuda_dev))
     assert rc == -1
+
+
+@pytest.mark.parametrize("hidden,layers,heads,inter,b,S", [(768, 2, 12, 3072, 256, 32), (768, 2, 12, 3072, 70, 48), (1024, 2, 16, 4096, 96, 24),
+                                                            (384, 2, 12, 1536, 130, 16)])
+def test_last_layer_tail_in_one_launch(hidden, layers, heads, inter, b, S, cuda_dev, monkeypatch):
+    """The CLS-only last layer ends with ONE launch (splitk_ln_normalize_kernel: the K slices of the FFN-down product + bias +
+    residual, LayerNorm, F.normalize) instead of reduce -> LayerNorm -> normalize (AC_BERT_TAIL_FUSED=0), and its CLS attention
+    runs on 32-key tiles when no sequence is longer: the same unit vectors to fp32 rounding (bar 2e-6: the norm's sum runs in a
+    different lane order), 1e-4 from transformers, also into a wider output buffer (the padding columns are zeroed)."""
+    from adaptive_classifier.encoder import HipBertEncoder
+    from oracle import bert_oracle
+    model = bert_oracle.make_bert(hidden, layers, heads, inter, vocab=3000, seed=4)
+    ids, types, mask = bert_oracle.synthetic_batch(b, S, vocab=3000, seed=21, ragged=True)
+    enc = HipBertEncoder(model, device=cuda_dev)
+    monkeypatch.setenv("AC_BERT_TAIL_FUSED", "0")
+    a = enc.encode_cls(ids, types, mask).clone()
+    monkeypatch.setenv("AC_BERT_TAIL_FUSED", "1")
+    c = enc.encode_cls(ids, types, mask).clone()
+    assert torch.isfinite(c).all()
+    assert (a - c).abs().max().item() <= 2e-6, (a - c).abs().max().item()
+    assert (c.cpu() - bert_oracle.encode_cls(model, ids, types, mask)).abs().max().item() < 1e-4
+    wide = torch.full((b, hidden + 24), 7.0, device=cuda_dev)
+    enc.encode_cls(ids, types, mask, out=wide)
+    assert torch.equal(wide[:, :hidden], c) and bool((wide[:, hidden:] == 0).all())
