@@ -775,7 +775,7 @@ class AdaptiveClassifier:
             cmap = (None, 0, None, 0)
             if self.memory.index.ntotal > 0 or self.memory.updates_since_rebuild >= self.config.prototype_update_frequency:
                 D, I = self.memory.search_raw(emb, k_proto)
-                D, I = D.contiguous(), I.contiguous()
+                D, I = D.to(torch.float32).contiguous(), I.to(torch.int64).contiguous()
                 cmap = self.memory.class_map(self.label_to_id, emb.device)
             # (the head's three launches on a side stream under the search's seven: overlapped in the trace, 0.04 ms SLOWER per step --
             #  two cross-stream waits cost more than 25 us of small kernels; profiles/r06/head_side_stream.txt)
@@ -784,6 +784,19 @@ class AdaptiveClassifier:
                 head = self._head_outputs(emb).contiguous()
         if D is None and head is None:
             return [[] for _ in range(b)]
+        stage, view, need, layout = self._post_launch(D, I, cmap, head, k, regular, host=mode != "2")
+        if mode == "2":                 # (A/B: the fused kernel with an ordinary D2H copy of its result)
+            return self._unpack(stage[:need].cpu().numpy(), layout, k, check)
+        return self._unpack(view[:need], layout, k, check)
+
+    def _post_launch(self, D, I, cmap, head, k: int, regular: bool, host: bool = True):
+        """ac_predict_post over one batch's search result (D, I: may be None), class map and head outputs (may be None).
+        host=True: returns when the packed result is readable in this classifier's host-mapped buffer (no stream
+        synchronisation); host=False: asynchronous, the result stays in the device buffer.
+        -> (device buffer, host view, bytes, layout for _unpack)."""
+        C = len(self.id_to_label)
+        dev = (D if D is not None else head).device
+        b = (D if D is not None else head).shape[0]
         kp = 0 if D is None else D.shape[1]
         kk = max(1, min(k, C))
         w = self._blend_weights(regular)
@@ -791,17 +804,15 @@ class AdaptiveClassifier:
         off_cls = 4 * b
         off_val = (off_cls + 4 * b * kk + 7) // 8 * 8
         need = (off_val + 8 * b * kk + 15) // 16 * 16
-        addr, view = self._post_buffer(need)
+        addr, view = self._post_buffer(need) if host else (None, None)
         stage = getattr(self, "_post_stage", None)
-        if stage is None or stage.numel() < need or stage.device != emb.device:
-            stage = self._post_stage = torch.empty(max(1 << 16, 2 * need), dtype=torch.uint8, device=emb.device)
-        with torch.cuda.device(emb.device):
+        if stage is None or stage.numel() < need or stage.device != dev:
+            stage = self._post_stage = torch.empty(max(1 << 16, 2 * need), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
             nv.check(nv.lib().ac_predict_post(nv.ptr(D), nv.ptr(I), kp, nv.ptr(cmap[0]), cmap[1], nv.ptr(cmap[2]), cmap[3],
                                               nv.ptr(head), C, 1, w[0].data_ptr(), w[1].data_ptr(), ncls, kk, b, nv.ptr(stage), need,
-                                              None if mode == "2" else addr, nv.stream_ptr(emb.device)), "ac_predict_post")
-        if mode == "2":                 # (A/B: the fused kernel with an ordinary D2H copy of its result)
-            return self._unpack(stage[:need].cpu().numpy(), (b, kk, off_cls, off_val, C), k, check)
-        return self._unpack(view[:need], (b, kk, off_cls, off_val, C), k, check)
+                                              addr, nv.stream_ptr(dev)), "ac_predict_post")
+        return stage, view, need, (b, kk, off_cls, off_val, C)
 
     def predict_embeddings(self, emb: torch.Tensor, k: int = 5) -> List[List[Tuple[str, float]]]:
         """predict_batch() after the encoder: device kNN + head, then the blend of :1359-1384."""

@@ -108,24 +108,27 @@ def predict_step(clf, ids, types, mask):
 
 
 def time_stages(clf, ids, types, mask, reps=5):
-    """HIP-event timing of the device stages of one step (current stream)."""
-    from adaptive_classifier.ops import softmax_rows
+    """HIP-event timing of the device stages of one step (current stream), launched as predict_tokens launches them: the encoder
+    (ac_bert_encode_cls_unpad: packing + forward, no stream synchronisation), the search (distances + row ids), the head's forward,
+    and ac_predict_post (scores, hit classes, softmax, blend, top-k: here in its asynchronous form, result left on the device)."""
     ev = lambda: torch.cuda.Event(enable_timing=True)
     out = {}
-    e = [ev() for _ in range(4)]
-    tot = np.zeros(3)
+    e = [ev() for _ in range(5)]
+    tot = np.zeros(4)
     for _ in range(reps):
         e[0].record()
         emb = clf.model.encode_cls(ids, types, mask, verify=False)
         e[1].record()
-        S, I, D = clf.memory.search_batch(emb, KNN_K)
+        D, I = clf.memory.search_raw(emb, KNN_K)
         e[2].record()
-        probs = softmax_rows(clf.adaptive_head.forward_native(emb))
+        head = clf._head_outputs(emb)
         e[3].record()
+        clf._post_launch(D.contiguous(), I.contiguous(), clf.memory.class_map(clf.label_to_id, emb.device), head.contiguous(), KNN_K, False, host=False)
+        e[4].record()
         torch.cuda.synchronize()
-        tot += [e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])]
+        tot += [e[i].elapsed_time(e[i + 1]) for i in range(4)]
     tot /= reps
-    out["encode_ms"], out["knn_ms"], out["head_ms"] = [float(x) for x in tot]
+    out["encode_ms"], out["knn_ms"], out["head_ms"], out["post_ms"] = [float(x) for x in tot]
     # same box, same process, same loop (2 x reps forwards back to back): the encoder as it ships, and with the self-attention as
     # its own launch (the round-5 form; AC_QKV_ATTN_FUSION is read at every call) -- what the attention epilogue of the QKV GEMM
     # (gemm_pipe.hip EPI_QKV_ATTN) is worth on THIS box
@@ -1378,6 +1381,11 @@ def main():
                    "length_distribution": {"kind": "uniform integer [8, 32], first text 32", "min": int(lens_h.min()),
                                            "mean": float(lens_h.mean()), "max": int(lens_h.max())},
                    "padding_free": bool(unpadded),
+                   "step_pipeline": ("predict_tokens: ac_bert_encode_cls_unpad (packing + forward, the token count reaches the host through a "
+                                     "mapped slot while the embedding kernel runs: no stream synchronisation) -> search (distances, row ids) -> "
+                                     "head forward (3 launches) -> ac_predict_post (scores, hit classes, softmax, blend, top-k in one launch; the "
+                                     "packed result is copied to host-mapped memory by the last workgroup and the host waits on its flag) -> "
+                                     "_hostfast.unpack (the reference's lists, one C pass)"),
                    "gc_frozen": True,
                    "value_gc_unfrozen": BATCH * args.steps / dt_unfrozen,
                    "prototypes": NPROTO, "dim": DIM, "k": KNN_K, "classes": NCLASS, "parallelism": "dp1",

@@ -15,14 +15,14 @@ f = glob.glob("$T/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [re.sub(r"\(anonymous namespace\)::|^void ", "", r["Kernel_Name"]).split("(")[0][:64] for r in rows]
-starts = [i for i, n in enumerate(names) if n.startswith("embed_ln_kernel")]
+starts = [i for i, n in enumerate(names) if n.startswith("pack_prologue_kernel")]
 fw = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)][-9:]
 out = {"forwards_analysed": len(fw)}
 tot_k = tot_gap = tot_wall = 0.0
 per = collections.defaultdict(lambda: [0, 0.0])
 gaps = []
 for a, b in fw:
-    end = max(i for i in range(a, b) if names[i].startswith("cls_normalize_kernel"))
+    end = max(i for i in range(a, b) if names[i].startswith(("splitk_ln_normalize_kernel", "cls_normalize_kernel")))
     seg = rows[a:end + 1]
     k = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg)
     wall = int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])
@@ -51,7 +51,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$T/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = re.sub(r"\(anonymous namespace\)::|^void ", "", r["Kernel_Name"]).split("(")[0][:64]
-        if n.startswith(("gemm_", "attention", "embed", "ln_kernel")):
+        if n.startswith(("gemm_", "attention", "embed", "ln_kernel", "pack_prologue", "splitk_ln")):
             agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for n, cs in agg.items():
