@@ -240,9 +240,15 @@ class HipBertEncoder:
         return self
 
     def workspace_bytes(self, b, S):
-        need = ctypes.c_size_t(0)
-        nv.check(nv.lib().ac_bert_workspace(ctypes.byref(self.ccfg), b, S, ctypes.byref(need)), "ac_bert_workspace")
-        return need.value
+        cache = self.__dict__.setdefault("_ws_bytes_cache", {})       # (a function of the architecture and (b, S) only: the
+        got = cache.get((b, S))                                        #  predict path asks with the same pair at every step)
+        if got is None:
+            need = ctypes.c_size_t(0)
+            nv.check(nv.lib().ac_bert_workspace(ctypes.byref(self.ccfg), b, S, ctypes.byref(need)), "ac_bert_workspace")
+            if len(cache) > 256:
+                cache.clear()
+            got = cache[(b, S)] = need.value
+        return got
 
     def encode_cls(self, input_ids, token_type_ids=None, attention_mask=None, out=None, verify=True, force_layered=False,
                    verify_small=None, arith=None):

@@ -229,6 +229,29 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + r);
 }
 
+// Two at a time on the packed fp32 ALU (v_pk_mul / v_pk_fma / v_pk_add_f32: two IEEE fp32 operations per lane and issue slot --
+// the same operations in the same order as gelu_erf, hence the same bits; only v_exp_f32 and the sign transfer stay scalar).  The
+// FFN1 epilogue is VALU-bound (128 evaluations per lane under an idle matrix pipe): 34 -> 21 issue slots per pair.
+typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f32x2 gelu_erf2(gelu_f32x2 x) {
+    const gelu_f32x2 t = x * 0.70710678118654752440f;
+    const gelu_f32x2 a = __builtin_elementwise_min(__builtin_elementwise_abs(t), (gelu_f32x2){4.0f, 4.0f});
+    gelu_f32x2 p = {-1.160484225692926e-05f, -1.160484225692926e-05f};
+    p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.00015296465426217765f, 0.00015296465426217765f});
+    p = __builtin_elementwise_fma(p, a, (gelu_f32x2){-0.0008482354460284114f, -0.0008482354460284114f});
+    p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.002274787751957774f, 0.002274787751957774f});
+    p = __builtin_elementwise_fma(p, a, (gelu_f32x2){-8.480761607643217e-05f, -8.480761607643217e-05f});
+    p = __builtin_elementwise_fma(p, a, (gelu_f32x2){-0.027724474668502808f, -0.027724474668502808f});
+    p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.1483079046010971f, 0.1483079046010971f});
+    p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.9184429049491882f, 0.9184429049491882f});
+    p = __builtin_elementwise_fma(p, a, (gelu_f32x2){1.6279072761535645f, 1.6279072761535645f});
+    const gelu_f32x2 pa = p * a;
+    const gelu_f32x2 e = {__builtin_amdgcn_exp2f(-pa[0]), __builtin_amdgcn_exp2f(-pa[1])};
+    const gelu_f32x2 om = (gelu_f32x2){1.0f, 1.0f} - e;
+    const gelu_f32x2 r = {__builtin_copysignf(om[0], t[0]), __builtin_copysignf(om[1], t[1])};
+    return (x * 0.5f) * ((gelu_f32x2){1.0f, 1.0f} + r);
+}
+
 // element offset (uint16 units) of (row, k) inside one plane of a [rows, K] operand: planes[p][k/8][row][k%8]
 __device__ __forceinline__ int64_t plane_off(int64_t rows, int64_t row, int k) {
     return ((int64_t)(k >> 3) * rows + row) * 8 + (k & 7);

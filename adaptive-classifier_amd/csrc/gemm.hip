@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void gemm_direct_pair(DirectProblem p1, Direct
 }
 
 // ---------------------------------------------------------------------------------------------
-// few-tile NT kernel (65 <= M <= 1024 with fewer 64 x 128 tiles than half the CUs: the head's three layers over a predict
+// few-tile NT kernel (65 <= M <= 512 with fewer 64 x 128 tiles than half the CUs: the head's three layers over a predict
 // batch, the CLS-row GEMMs of the encoder's last layer).  Such a shape is latency-bound, not pipe-bound: the tiled kernels put
 // 256 x 768 x 768 on 24 workgroups (30 us), split-K over operand planes needs a reduce launch (10 + 6 us).  Here one workgroup
 // owns a 32 x 32 output tile (256 x 768 -> 192 workgroups), its 8 waves split K in interleaved 16-column slots (a lane reads
@@ -704,7 +704,9 @@ __global__ __launch_bounds__(kFtWaves * 64) void gemm_fewtiles_nt(const float* _
 static bool fewtiles_takes(int M, int N, int K, bool aligned) {
     if (const char* e = getenv("AC_GEMM_FEWTILES")) { if (atoi(e) == 0) return false; }
     const int64_t t64 = (int64_t)((M + 63) / 64) * ((N + BN - 1) / BN);
-    return aligned && M >= 65 && M <= 1024 && (K % 8) == 0 && K >= 64 && 2 * t64 <= ac::dev_info().cus;
+    // (<= 512 rows and <= 2^30 multiply-adds: beyond, the fp32 matrix pipe -- 1/16 of the bf16 one -- is the bound, not latency)
+    return aligned && M >= 65 && M <= 512 && (K % 8) == 0 && K >= 64 && 2 * t64 <= ac::dev_info().cus &&
+           (int64_t)M * N * K <= ((int64_t)1 << 30);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -180,16 +180,26 @@ __device__ __forceinline__ void store_tile_planes(f32x16 (&acc)[TM][TN], uint16_
             const int64_t rbase = m0 + wm * (32 * TM) + mi * 32;
             const float bias = (EPI != EPI_IDENT && col < N) ? epi.bias[col] : 0.f;
             const float bias_g = (GLU && col + 32 < N) ? epi.bias[col + 32] : 0.f;
+            if constexpr (EPI == EPI_BIAS_GELU) {                    // two accumulators per packed-fp32 evaluation (ac::gelu_erf2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v;
-                if (GLU) {
-                    const float x = acc[mi][0][r] + bias;
-                    v = ac::gelu_erf(x) * (acc[mi][1][r] + bias_g);
-                } else {
-                    v = fast_epilogue<EPI>(acc[mi][ni][r], bias, 0.f);
+                for (int r = 0; r < 16; r += 2) {
+                    const ac::gelu_f32x2 xv = {acc[mi][ni][r] + bias, acc[mi][ni][r + 1] + bias};
+                    const ac::gelu_f32x2 gv = ac::gelu_erf2(xv);
+                    scratch[acc_row32(r, lane) * kTrLd + (lane & 31)] = gv[0];
+                    scratch[acc_row32(r + 1, lane) * kTrLd + (lane & 31)] = gv[1];
                 }
-                scratch[acc_row32(r, lane) * kTrLd + (lane & 31)] = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v;
+                    if (GLU) {
+                        const float x = acc[mi][0][r] + bias;
+                        v = ac::gelu_erf(x) * (acc[mi][1][r] + bias_g);
+                    } else {
+                        v = fast_epilogue<EPI>(acc[mi][ni][r], bias, 0.f);
+                    }
+                    scratch[acc_row32(r, lane) * kTrLd + (lane & 31)] = v;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
