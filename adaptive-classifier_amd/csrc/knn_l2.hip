@@ -1233,14 +1233,16 @@ constexpr int kFbRound = 32;          // rows per wave between barriers
 // grid = (fb_S, nq): block (s, q) scans row slab s of a flagged query and writes its exact top-k to the
 // query's slot; knn_exact_fb_merge then merges the slabs.  A flagged query without a slot (more than fb_F
 // failures in one call) is handled by its s == 0 block alone over the whole store.
-__global__ __launch_bounds__(kFbThreads) void knn_exact_fallback(MergeParams prm) {
-    const int q = blockIdx.y, slab = blockIdx.x;
+// (round 6: the grid is (fb_S, min(nq, kFbQueryGroups)) and a block walks the queries q = blockIdx.y, + gridDim.y, ...: with
+//  no query flagged -- every call of an ordinary batch -- dispatching fb_S x nq = 16 384 empty 512-thread blocks cost 8.5 us;
+//  fb_S x 8 cost 2.  A device holds <= ~1000 of these blocks at once, so flagged batches lose nothing.)
+constexpr int kFbQueryGroups = 8, kFbMergeGroups = 32;
+__device__ __forceinline__ void knn_exact_fallback_query(const MergeParams& prm, const int q, const int slab, char* smem) {
     const int flag = prm.flags[q];
     if (flag == 0 || (flag < 0 && slab != 0)) return;
     const bool direct = flag < 0;
     const int64_t row_lo = direct ? 0 : (prm.N * slab) / prm.fb_S;
     const int64_t row_hi = direct ? prm.N : (prm.N * (slab + 1)) / prm.fb_S;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* ld = reinterpret_cast<double*>(smem);                  // [kFbCap]
     int32_t* li = reinterpret_cast<int32_t*>(ld + kFbCap);         // [kFbCap]
@@ -1328,13 +1330,19 @@ __global__ __launch_bounds__(kFbThreads) void knn_exact_fallback(MergeParams prm
         }
     }
 }
+__global__ __launch_bounds__(kFbThreads) void knn_exact_fallback(MergeParams prm, int nq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int q = blockIdx.y; q < nq; q += gridDim.y) {
+        knn_exact_fallback_query(prm, q, blockIdx.x, smem);
+        __syncthreads();                                            // (the next query reuses the lists)
+    }
+}
 
 // merge the fb_S slab results of a flagged query: bitonic sort of fb_S * k (<= 4096) exact entries
-__global__ __launch_bounds__(256) void knn_exact_fb_merge(MergeParams prm, int npow2) {
-    const int q = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void knn_exact_fb_merge_query(const MergeParams& prm, const int npow2, const int q, char* smem) {
+    const int tid = threadIdx.x;
     const int flag = prm.flags[q];
     if (flag <= 0) return;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     double* ds = reinterpret_cast<double*>(smem);
     int32_t* is = reinterpret_cast<int32_t*>(ds + npow2);
     const int n = prm.fb_S * prm.k;
@@ -1362,6 +1370,13 @@ __global__ __launch_bounds__(256) void knn_exact_fb_merge(MergeParams prm, int n
         prm.outD[(size_t)q * prm.k + t] = real ? (float)ds[t] : FLT_MAX;
         if (prm.outD64) prm.outD64[(size_t)q * prm.k + t] = real ? ds[t] : (double)INFINITY;
         prm.outI[(size_t)q * prm.k + t] = real ? (int64_t)is[t] + prm.row_offset : -1;
+    }
+}
+__global__ __launch_bounds__(256) void knn_exact_fb_merge(MergeParams prm, int npow2, int nq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+        knn_exact_fb_merge_query(prm, npow2, q, smem);
+        __syncthreads();
     }
 }
 
@@ -1725,11 +1740,11 @@ extern "C" int ac_knn_l2_topk_x(const float* d_P, int64_t N, int64_t ldP, int D,
     if (N > 0) {
         (void)hipFuncSetAttribute((const void*)knn_exact_fallback, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)pl.fb_lds);
-        hipLaunchKernelGGL(knn_exact_fallback, dim3(pl.fb_S, nq), dim3(kFbThreads), pl.fb_lds, stream, mp);
+        hipLaunchKernelGGL(knn_exact_fallback, dim3(pl.fb_S, nq < kFbQueryGroups ? nq : kFbQueryGroups), dim3(kFbThreads), pl.fb_lds, stream, mp, nq);
         AC_LAUNCH_CHECK();
         const int np2 = next_pow2(pl.fb_S * k > 2 ? pl.fb_S * k : 2);
         (void)hipFuncSetAttribute((const void*)knn_exact_fb_merge, hipFuncAttributeMaxDynamicSharedMemorySize, np2 * 12);
-        hipLaunchKernelGGL(knn_exact_fb_merge, dim3(nq), dim3(256), (size_t)np2 * 12, stream, mp, np2);
+        hipLaunchKernelGGL(knn_exact_fb_merge, dim3(nq < kFbMergeGroups ? nq : kFbMergeGroups), dim3(256), (size_t)np2 * 12, stream, mp, np2, nq);
         AC_LAUNCH_CHECK();
     }
     return AC_OK;
@@ -1943,11 +1958,11 @@ int plane_search(const PlanePlan& pp, const float* d_P, int64_t N, int64_t ldP, 
     hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), pp.merge_lds, stream, mp);
     AC_LAUNCH_CHECK();
     (void)hipFuncSetAttribute((const void*)knn_exact_fallback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.fb_lds);
-    hipLaunchKernelGGL(knn_exact_fallback, dim3(pp.fb_S, nq), dim3(kFbThreads), pp.fb_lds, stream, mp);
+    hipLaunchKernelGGL(knn_exact_fallback, dim3(pp.fb_S, nq < kFbQueryGroups ? nq : kFbQueryGroups), dim3(kFbThreads), pp.fb_lds, stream, mp, nq);
     AC_LAUNCH_CHECK();
     const int np2 = next_pow2(pp.fb_S * k > 2 ? pp.fb_S * k : 2);
     (void)hipFuncSetAttribute((const void*)knn_exact_fb_merge, hipFuncAttributeMaxDynamicSharedMemorySize, np2 * 12);
-    hipLaunchKernelGGL(knn_exact_fb_merge, dim3(nq), dim3(256), (size_t)np2 * 12, stream, mp, np2);
+    hipLaunchKernelGGL(knn_exact_fb_merge, dim3(nq < kFbMergeGroups ? nq : kFbMergeGroups), dim3(256), (size_t)np2 * 12, stream, mp, np2, nq);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
@@ -2102,11 +2117,11 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     hipLaunchKernelGGL(knn_merge_rerank, dim3(nq), dim3(kMergeThreads), mlds, stream, mp);
     AC_LAUNCH_CHECK();
     (void)hipFuncSetAttribute((const void*)knn_exact_fallback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.fb_lds);
-    hipLaunchKernelGGL(knn_exact_fallback, dim3(bp.fb_S, nq), dim3(kFbThreads), bp.fb_lds, stream, mp);
+    hipLaunchKernelGGL(knn_exact_fallback, dim3(bp.fb_S, nq < kFbQueryGroups ? nq : kFbQueryGroups), dim3(kFbThreads), bp.fb_lds, stream, mp, nq);
     AC_LAUNCH_CHECK();
     const int np2 = next_pow2(bp.fb_S * k > 2 ? bp.fb_S * k : 2);
     (void)hipFuncSetAttribute((const void*)knn_exact_fb_merge, hipFuncAttributeMaxDynamicSharedMemorySize, np2 * 12);
-    hipLaunchKernelGGL(knn_exact_fb_merge, dim3(nq), dim3(256), (size_t)np2 * 12, stream, mp, np2);
+    hipLaunchKernelGGL(knn_exact_fb_merge, dim3(nq < kFbMergeGroups ? nq : kFbMergeGroups), dim3(256), (size_t)np2 * 12, stream, mp, np2, nq);
     AC_LAUNCH_CHECK();
     return AC_OK;
 }
