@@ -3,9 +3,6 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$REPO/gpurun_out/r06; mkdir -p $O
 cd $REPO
-timeout 2400 python -m pytest tests/test_knn_gpu.py tests/test_knn_batch_gpu.py tests/test_knn_baseline_gpu.py tests/test_sharded_gpu.py tests/test_poisoned_workspace_gpu.py -x -q -m gpu 2>&1 | tail -4 | tee $O/pytest_knn_fb.txt
-cd /tmp && export TMPDIR=/tmp
-T=/tmp/prof_step6; rm -rf $T
 cat > /tmp/step_only.py <<'PY'
 import os, sys, time
 R = os.environ["GRAFT_REPO_ROOT"] if "GRAFT_REPO_ROOT" in os.environ else "/root/repo"
@@ -21,6 +18,13 @@ for _ in range(100): bench.predict_step(clf, ids, types, mask)
 torch.cuda.synchronize()
 print("ms per step", (time.perf_counter() - t0) / 100 * 1e3)
 PY
+cp /tmp/step_only.py /tmp/step_only_pre.py
+timeout 2400 python -m pytest tests/test_knn_gpu.py tests/test_knn_batch_gpu.py tests/test_knn_baseline_gpu.py tests/test_sharded_gpu.py tests/test_poisoned_workspace_gpu.py tests/test_classifier_gpu.py tests/test_golden_gpu.py -x -q -m gpu 2>&1 | tail -4 | tee $O/pytest_knn_fb.txt
+AC_KNN_THR_EXACT=1 python /tmp/step_only_pre.py 2>&1 | grep "ms per step"
+cd /tmp && export TMPDIR=/tmp
+T=/tmp/prof_step6; rm -rf $T
+python /tmp/step_only.py 2>&1 | grep "ms per step"
+AC_KNN_THR_EXACT=1 python /tmp/step_only.py 2>&1 | grep "ms per step"
 python /tmp/step_only.py 2>&1 | grep "ms per step"
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $T -o t -- python /tmp/step_only.py > /dev/null 2>&1
 python $REPO/tools/r06_step_seq.py $(find $T -name "*kernel_trace.csv" | head -1) pack_prologue_kernel > $O/step_launch_sequence_6.txt; tail -14 $O/step_launch_sequence_6.txt
