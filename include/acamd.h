@@ -249,8 +249,10 @@ int ac_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
  * library: they return AC_EUNSUPPORTED (ac_set_persistent_kernels: the unchanged mask) and change nothing.  The product never
  * calls them: what a call computes is decided by its arguments (ac_bert_config / ac_modernbert_config *_opt words, AC_LOSS_STEPWISE,
  * AC_BERT_LAYERED) and by configuration variables read once at load (AC_GEMM_ARITH, AC_LN_FUSION, AC_GEMM_VARIANT,
- * AC_HEAD_PERSISTENT, AC_BERT_SMALL, AC_QKV_ATTN_FUSION, AC_ACTIVE_CUS) -- SURVEY 8b: no global mutable state besides the
- * per-thread error string.  Queries (ac_gemm_get_arith, ac_set_persistent_kernels(-1), the *_launches counters) always answer. */
+ * AC_HEAD_PERSISTENT, AC_BERT_SMALL, AC_ACTIVE_CUS, AC_EXCHANGE_FENCES, AC_KNN_THR_EXACT) or at the call (the A/B switches of
+ * equivalent forms, all default ON: AC_QKV_ATTN_FUSION, AC_QKV_ATTN_EXCHANGE, AC_BERT_TAIL_FUSED, AC_GEMM_FEWTILES; in the Python
+ * host layer AC_BERT_UNPAD_ONE_CALL, AC_PREDICT_POST) -- SURVEY 8b: no global mutable state besides the per-thread error
+ * string.  Queries (ac_gemm_get_arith, ac_set_persistent_kernels(-1), the *_launches counters) always answer. */
 int ac_gemm_set_arith(int mode);
 int ac_gemm_get_arith(void);
 /* Diagnostic / A-B switch for the large-M pre-split GEMM: 0 = default dispatch (per-shape choice between the two-buffer
