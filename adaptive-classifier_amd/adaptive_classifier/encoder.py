@@ -225,6 +225,17 @@ class HipBertEncoder:
                                  0 if a is None else a + 1,
                                  0 if self.ln_fusion is None else (2 if self.ln_fusion else 1), 0)
 
+    def _call_cfg_shared(self, arith=None):
+        """_call_cfg for encode_cls's own use: one struct per (arithmetic, fusion) state, never handed out, never modified."""
+        a = arith_mode(arith)
+        if a is None:
+            a = self.arith
+        key = (a, self.ln_fusion)
+        cached = self.__dict__.get("_cfg_cache")
+        if cached is None or cached[0] != key:
+            cached = self._cfg_cache = (key, self._call_cfg(arith))
+        return cached[1]
+
     # -- the nn.Module-ish surface classifier.py touches (:1253-1255,1278-1279,1215) ----------
     def eval(self):
         self.training = False
@@ -238,6 +249,12 @@ class HipBertEncoder:
         if torch.device(device) != self.device:
             raise nv.NativeError("HipBertEncoder is bound to its GPU; build a new one for another device")
         return self
+
+    def _as_ids(self, t):
+        """int64, contiguous, on this encoder's device (already so on the predict paths: three attribute reads, no dispatch)."""
+        if t.dtype is torch.int64 and t.device == self.device and t.is_contiguous():
+            return t
+        return t.to(device=self.device, dtype=torch.int64).contiguous()
 
     def workspace_bytes(self, b, S):
         cache = self.__dict__.setdefault("_ws_bytes_cache", {})       # (a function of the architecture and (b, S) only: the
@@ -267,12 +284,12 @@ class HipBertEncoder:
         `ln_fusion_aborted()` / `last_one_launch` and call again.  verify_small: older name of `verify`."""
         if verify_small is not None:
             verify = verify_small
-        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        ids = self._as_ids(input_ids)
         b, S = ids.shape
         if not self._has_types:
             token_type_ids = None           # DistilBERT has no segment embeddings (tokenizer may still emit ids)
-        tt = None if token_type_ids is None else token_type_ids.to(device=self.device, dtype=torch.int64).contiguous()
-        mk = None if attention_mask is None else attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        tt = None if token_type_ids is None else self._as_ids(token_type_ids)
+        mk = None if attention_mask is None else self._as_ids(attention_mask)
         H = self.ccfg.hidden
         if out is None:
             out = torch.empty((b, H), dtype=torch.float32, device=self.device)
@@ -285,7 +302,7 @@ class HipBertEncoder:
             # layer by layer (bert-large: no one-launch kernel; a one-launch abort retried layered) reads them below without
             # having cleared them, and torch.empty memory is garbage -- a spurious "gave up" would switch the fusion off
             self._ws[:256].zero_()
-        cfg = self._call_cfg(arith)
+        cfg = self._call_cfg_shared(arith)
         with torch.cuda.device(self.device):
             # the fused-LayerNorm verdict of this call starts clean (sticky over the chunks below; include/acamd.h); a call
             # that runs as the one persistent launch has no such epilogue (and is the latency path: no extra launch)
@@ -297,7 +314,7 @@ class HipBertEncoder:
                     "CU-masked?); LayerNorm fusion is now off for this encoder and the batch is encoded again")
                 self.ln_gave_up += 1
                 self.disable_ln_fusion()
-                cfg = self._call_cfg(arith)
+                cfg = self._call_cfg_shared(arith)
                 self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg, clear=True)
             if verify and layered and self.f16x2_active(arith) and not bool(torch.isfinite(out).all()):
                 # an activation beyond fp16's range at scale 2^6 turned its rows into NaN (never into a wrong number)
@@ -312,7 +329,7 @@ class HipBertEncoder:
                 # an encoder-level or process-level f16x2 becomes an encoder-level bf16x3
                 if arith_mode(arith) is None:
                     self.arith = nv.AC_GEMM_BF16X3
-                cfg = self._call_cfg(nv.AC_GEMM_BF16X3)
+                cfg = self._call_cfg_shared(nv.AC_GEMM_BF16X3)
                 self._run_chunks(ids, tt, mk, b, S, cb, out, verify, force_layered, cfg)
         return out
 
@@ -340,9 +357,11 @@ class HipBertEncoder:
             unpad = self.unpad and mk is not None and S > 1 and nb * S > SMALL_TOKENS
             if unpad and one_call and nb <= self._UNPAD_MAX_SEQS:
                 total, path = ctypes.c_int(0), ctypes.c_int(0)
+                whole = nb == b                 # (one chunk -- every predict batch: no tensor views, ~2 us of interpreter each)
                 nv.check(nv.lib().ac_bert_encode_cls_unpad(
-                    ctypes.byref(cfg), ctypes.byref(self.weights), nv.ptr(ids[r0:r1]), nv.ptr(None if tt is None else tt[r0:r1]),
-                    nv.ptr(mk[r0:r1]), nb, S, nv.ptr(out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(),
+                    ctypes.byref(cfg), ctypes.byref(self.weights), nv.ptr(ids if whole else ids[r0:r1]),
+                    nv.ptr(None if tt is None else (tt if whole else tt[r0:r1])), nv.ptr(mk if whole else mk[r0:r1]), nb, S,
+                    nv.ptr(out if whole else out[r0:r1]), out.stride(0), nv.ptr(self._ws), self._ws.numel(),
                     1 if clear else 0, ctypes.byref(total), ctypes.byref(path), nv.stream_ptr(self.device)),
                     "ac_bert_encode_cls_unpad")
                 clear = False
