@@ -976,7 +976,7 @@ namespace {
 int32_t* info_slot(int* epoch_out) {
     static int32_t* base = [] {
         void* p = nullptr;
-        if (hipHostMalloc(&p, 64 * 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return (int32_t*)nullptr; }
+        if (hipHostMalloc(&p, 64 * 64, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return (int32_t*)nullptr; }
         memset(p, 0, 64 * 64);
         return (int32_t*)p;
     }();

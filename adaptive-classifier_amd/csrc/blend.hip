@@ -8,6 +8,7 @@
 #include "common.h"
 #include "grid_sync.h"
 #include <atomic>
+#include <mutex>
 #include <string.h>
 
 namespace {
@@ -247,21 +248,32 @@ __global__ __launch_bounds__(64) void predict_post_kernel(const float* __restric
 // completion slots of ac_predict_post(wait_host = 1): a host-mapped flag + a device counter each, handed out round-robin
 struct PostSlot { int* flag; unsigned* done; };
 PostSlot post_slot(int* epoch_out) {
-    static int* flags = nullptr;
-    static unsigned* counters = nullptr;
-    static const bool ok = [] {
-        void* h = nullptr; void* d = nullptr;
-        if (hipHostMalloc(&h, 64 * 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (hipMalloc(&d, 64 * 64) != hipSuccess || hipMemset(d, 0, 64 * 64) != hipSuccess) { (void)hipGetLastError(); return false; }
-        memset(h, 0, 64 * 64);
-        flags = (int*)h; counters = (unsigned*)d;
-        return true;
-    }();
+    // per device: the counters are device memory of the device the kernel runs on (a process that drives several GPUs)
+    struct PerDev { int* flags = nullptr; unsigned* counters = nullptr; bool tried = false; };
+    static PerDev devs[64];
+    static std::mutex mu;
     static std::atomic<unsigned> next{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    PerDev& d = devs[dev];
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!d.tried) {
+            d.tried = true;
+            void* h = nullptr; void* c = nullptr;
+            if (hipHostMalloc(&h, 64 * 64, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
+                hipMalloc(&c, 64 * 64) == hipSuccess && hipMemset(c, 0, 64 * 64) == hipSuccess) {
+                memset(h, 0, 64 * 64);
+                d.flags = (int*)h; d.counters = (unsigned*)c;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
     const unsigned n = next.fetch_add(1, std::memory_order_relaxed) + 1;
     *epoch_out = (int)(n & 0x3fffffff) + 1;
     PostSlot s{nullptr, nullptr};
-    if (ok) { s.flag = flags + 16 * (n & 63); s.done = counters + 16 * (n & 63); }
+    if (d.flags) { s.flag = d.flags + 16 * (n & 63); s.done = d.counters + 16 * (n & 63); }
     return s;
 }
 
@@ -270,7 +282,7 @@ PostSlot post_slot(int* epoch_out) {
 extern "C" int ac_host_alloc(size_t bytes, void** p) {
     AC_REQUIRE(p && bytes > 0, AC_EINVAL, "host_alloc: bad arguments");
     *p = nullptr;
-    AC_HIP_CHECK(hipHostMalloc(p, bytes, hipHostMallocCoherent | hipHostMallocMapped));
+    AC_HIP_CHECK(hipHostMalloc(p, bytes, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable));
     return AC_OK;
 }
 extern "C" int ac_host_free(void* p) {
