@@ -271,7 +271,10 @@ int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t l
 int64_t knn_sample_rows(int64_t N, int64_t stride);
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
                      const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int segs, int64_t row_stride,
-                     int best_only, hipStream_t stream, int32_t* clear_ctr = nullptr, int32_t* clear_stats = nullptr);
+                     int best_only, hipStream_t stream, int32_t* clear_ctr = nullptr, int32_t* clear_stats = nullptr,
+                     int two_phase_kp = 0, unsigned* wgmin = nullptr, void* ctl = nullptr);
+bool knn_batch_two_phase_applies(int64_t N, int nq, int kp, int segs);
+size_t knn_batch_two_phase_bytes();
 
 // Per-call options (ac_bert_config.gemm_arith_opt / ln_fusion_opt / one_launch_opt): for the duration of ONE native call on the
 // calling thread they take precedence over the process-wide switches (ac_gemm_set_arith, ac_gemm_set_ln_fusion,

@@ -30,6 +30,7 @@
 // fp64 fallback.
 #include "common.h"
 #include "gemm_common.h"
+#include "grid_sync.h"
 
 #include <float.h>
 #include <math.h>
@@ -146,6 +147,16 @@ struct BatchParams {
     int segs, segcap;                        // a query's list = segs segments of segcap = cap / segs entries, one counter each
     int32_t* clear_ctr;                      // (main sweep) [64] fallback slot counter and [4] caller's d_stats, zeroed by workgroup 0 here
     int32_t* clear_stats;                    //   instead of by two memset launches in front of the merge; NULL = leave alone
+    // two_phase (round 6; one query tile, every workgroup owns at least one row tile, the whole grid resident): the thresholds come
+    // from THIS launch -- after its first row tile every workgroup publishes, per query, the smallest sweep value of its 256 rows;
+    // a grid barrier; workgroup g takes the k'-th smallest of the G minima of query g (G real rows' values: at least k' rows of
+    // the store pass) one ulp up as thr[g]; a second barrier; then the first tile is filtered like every later one.  No sample
+    // sweep, no threshold merge: two launches and ~40 us less for a 256 x 100k call.
+    int two_phase;
+    int kp, nq_real;
+    float* thr_rw;                           // = thr
+    unsigned* wgmin;                         // [gridDim.x][256] monotone keys of the per-workgroup minima
+    acp::GridCtl* ctl;                       // zeroed before the launch
 };
 
 typedef const BatchParams __attribute__((address_space(4)))* KArgs;
@@ -163,13 +174,17 @@ template <int N> __device__ __forceinline__ void bwait_vm() { asm volatile("s_wa
 // (Measured and dropped in round 6, profiles/r06/knn_batch_nt_pmc_rejected.json, knn_batch_qplane_pmc_rejected.json: the store
 //  plane's DMA with the non-temporal bit -- the workgroups that share a row tile then each fetch it themselves, 159 / 130 GB of
 //  fabric reads at 4096 x 10M against 75 / 80 -- and a tile-major QUERY plane, 106 / 90 GB.)
-template <int BNS, int NWV, bool BURST>        // ring depth, waves
+template <int BNS, int NWV, bool BURST, bool TWO_PHASE = false>        // ring depth, waves; TWO_PHASE: BatchParams::two_phase (its own instantiation)
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams prm) {
     constexpr int WMW = NWV / 2, TM = BBM / (32 * WMW), TN = 4;    // wave grid WMW x 2, wave tile (32 TM) x 128
     constexpr int GPW = BGA / NWV;                                  // store / query groups each wave stages
     constexpr int PPW = 4 * GPW;                                    // DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];    // [BNS][2 chunks][BRG groups][64 lanes]
+    __shared__ unsigned tp_min[256], tp_vals[64 * NWV], tp_flag;   // (two_phase: per-query minima of this workgroup, the G minima of one query)
+    auto tp_key = [](float f) { const unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); };
+    auto tp_key_inv = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); };
     const int tid = threadIdx.x, lane = tid & 63;
+    if (BURST && TWO_PHASE && tid < 256) tp_min[tid] = 0xffffffffu;             // (visible long before its first use: the k-loop's barriers)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int i32 = lane & 31, kg = lane >> 5;
@@ -315,8 +330,60 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void knn_batch_sweep(BatchParams
         };
         float thr[4], qf[4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) { thr[ni] = f_thr[qcol0 + 32 * ni]; qf[ni] = f_qfac[qcol0 + 32 * ni]; }
-        if (BURST && f_best_only) {
+        for (int ni = 0; ni < 4; ++ni) qf[ni] = f_qfac[qcol0 + 32 * ni];
+        if constexpr (BURST && TWO_PHASE) {
+            if (it == 0) {
+                // (1) this lane's smallest value per query column over its 32 * TM rows -> the workgroup's, through LDS
+                float best[4];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) best[ni] = INFINITY;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    float pn[16];
+                    load_pn(mi, pn);
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) best[ni] = fminf(best[ni], fmaf(acc[mi][ni][r], qf[ni], pn[r]));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) atomicMin(&tp_min[wn * 128 + i32 + 32 * ni], tp_key(best[ni]));
+                __syncthreads();
+                // (the thread id rebuilt from what the loop keeps live, the block id laundered: nothing of this once-per-launch
+                //  block may hold a register -- or a spill slot -- across the k-loop)
+                const int t = (((wm << 1) | wn) << 6) | (kg << 5) | i32;
+                unsigned bx = blockIdx.x;
+                asm volatile("" : "+s"(bx));
+                unsigned* const wgmin = ka->wgmin;
+                acp::GridCtl* const ctl = ka->ctl;
+                const unsigned Gall = gridDim.x;
+                if (t < 256) __hip_atomic_store(wgmin + (size_t)bx * 256 + t, tp_min[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool ok = acp::grid_barrier<false>(ctl, 1u, Gall, &tp_flag);
+                // (2) workgroup b: queries b, b + G, ...: the k'-th smallest of the G minima
+                const int kp = ka->kp, nq_real = ka->nq_real;
+                float* const thr_rw = ka->thr_rw;
+                for (int q = (int)bx; q < 256; q += (int)Gall) {
+                    __syncthreads();
+                    if (t < (int)Gall) tp_vals[t] = __hip_atomic_load(wgmin + (size_t)t * 256 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    if (t < (int)Gall && q < nq_real) {
+                        const unsigned my = tp_vals[t];
+                        int rank = 0;
+                        for (int j = 0; j < (int)Gall; ++j) { const unsigned v = tp_vals[j]; rank += (v < my || (v == my && j < t)) ? 1 : 0; }
+                        if (rank == kp - 1) acp::st_sc1(thr_rw + q, ok ? nextafterf(tp_key_inv(my), INFINITY) : INFINITY);
+                    }
+                }
+                ok = acp::grid_barrier<false>(ctl, 2u, Gall, &tp_flag) && ok;
+                (void)ok;                                            // (a barrier that gave up leaves +inf thresholds: overflow -> exact fallback)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the ring's DMA accounting below only ever waits for FEWER operations)
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) thr[ni] = acp::ld_sc1(f_thr + qcol0 + 32 * ni);       // (written inside this launch)
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) thr[ni] = f_thr[qcol0 + 32 * ni];
+        }
+        if (BURST && !TWO_PHASE && f_best_only) {                    // (a two-phase launch is never a sample stage)
             // The first threshold stage has no threshold yet.  Any k' rows bound the k'-th smallest distance from above, so
             // instead of offering all of the sample (a million appends from the few workgroups a 4096-row sample occupies)
             // every lane offers the best of the 32 * TM rows it holds per query column: 8 offers per (query, 256-row tile).
@@ -533,9 +600,22 @@ int knn_prepare_queries(const double* sampleD, int kp, const float* Q, int64_t l
 }
 
 // N = rows of the prepared store, row_stride >= 1: sweep the knn_sample_rows(N, row_stride) logical rows (BatchParams::row_stride)
+// true when a whole-store sweep of (N, nq) with `segs` segments and re-rank width kp can take its thresholds from its own first
+// tile round (BatchParams::two_phase): one query tile, a row tile for every workgroup, k' minima available, the burst kernel
+bool knn_batch_two_phase_applies(int64_t N, int nq, int kp, int segs) {
+    const char* e = getenv("AC_KNN_TWO_PHASE");               // (per call: the equivalence test switches between the two forms)
+    const bool off = e && atoi(e) == 0;
+    int nblk = ac::dev_info().cus / 8 * 8;
+    if (nblk < 8) nblk = 8;
+    const int64_t ntiles = (N + BBM - 1) / BBM;
+    return !off && nq <= BBN && ntiles >= nblk && kp <= nblk && nblk <= 64 * 8 && segs > 1;
+}
+size_t knn_batch_two_phase_bytes() { return (size_t)64 * 8 * 256 * sizeof(unsigned); }       // wgmin for the largest grid
+
 int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, const uint16_t* Qp, int nq, const float* thr,
                      const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int segs, int64_t row_stride,
-                     int best_only, hipStream_t stream, int32_t* clear_ctr, int32_t* clear_stats) {
+                     int best_only, hipStream_t stream, int32_t* clear_ctr, int32_t* clear_stats, int two_phase_kp, unsigned* wgmin,
+                     void* ctl) {
     // (measured and dropped, profiles/r03/knn_batch_probe*.txt: a ring of 5 slots -- no change, the DMA depth is not the limit;
     //  2 x 2 waves of 128 x 128 with the 512-register budget, one wave per SIMD -- 120 vs 80 ms at 4096 x 10M: hipcc shuffles
     //  ~200 accumulator registers per iteration and a lone wave per SIMD hides nothing)
@@ -544,6 +624,7 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
     // (per call, like the launch sites of knn_l2.hip: function attributes are per device, and a cached flag is neither)
     AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_batch_sweep<ns, nwv, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     BatchParams p;
     p.Pp = Pp; p.p_rows = (N + 255) / 256 * 256; p.pnorm = pnorm;
     p.q_rows = ((int64_t)nq + 255) / 256 * 256;
@@ -553,6 +634,10 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
     p.ntiles = (p.N + BBM - 1) / BBM;
     AC_REQUIRE(N < (int64_t)1 << 31, AC_EUNSUPPORTED, "knn batch: %lld rows (row indices are 32-bit here)", (long long)N);
     p.cap = cap; p.segs = segs; p.segcap = cap / segs;
+    p.two_phase = two_phase_kp > 0 ? 1 : 0; p.kp = two_phase_kp; p.nq_real = nq; p.thr_rw = const_cast<float*>(thr); p.wgmin = wgmin;
+    p.ctl = (acp::GridCtl*)ctl;
+    AC_REQUIRE(!p.two_phase || (wgmin && ctl && row_stride <= 1 && !best_only && knn_batch_two_phase_applies(N, nq, two_phase_kp, segs)),
+               AC_EINVAL, "knn batch: two-phase thresholds asked for a launch that cannot take them");
     // one persistent workgroup per CU (128 KB of LDS); the grid is a multiple of 8 so every XCD gets the same share
     int nblk = ac::dev_info().cus / 8 * 8;
     if (nblk < 8) nblk = 8;
@@ -577,7 +662,8 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
         p.cand_d = cand_d + qoff * cap; p.cand_i = cand_i + qoff * cap; p.cand_cnt = cand_cnt + qoff * segs;
         p.clear_ctr = t0 == 0 ? clear_ctr : nullptr; p.clear_stats = t0 == 0 ? clear_stats : nullptr;
         const dim3 grid((unsigned)nblk), block(64 * nwv);
-        if (segs > 1 || p.row_stride > 1 || best_only) hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, true>), grid, block, lds, stream, p);
+        if (p.two_phase) hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, true, true>), grid, block, lds, stream, p);
+        else if (segs > 1 || p.row_stride > 1 || best_only) hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((knn_batch_sweep<ns, nwv, false>), grid, block, lds, stream, p);
         AC_LAUNCH_CHECK();
     }

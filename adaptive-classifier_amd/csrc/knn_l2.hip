@@ -1773,12 +1773,13 @@ constexpr int kBatchPad = 24;            // k' = k + 24 candidates re-ranked per
 constexpr int kBatchMaxK = 100;
 constexpr int64_t kBatchMinRows = 65536;
 
+constexpr int kTwoPhaseCtlInts = 512;       // >= sizeof(acp::GridCtl) / 4
 struct BatchPlan {
     int kp, cap, Dp;
     int64_t stride, stride_a, S, q_rows;
     int segs;
-    size_t off_sD32, off_sD64, off_sI, off_thr, off_qfac, off_cnt, off_qp, off_cd, off_ci, off_flags, off_fb_d, off_fb_i, off_fb_ctr,
-        off_sub, sub_bytes, total;
+    size_t off_sD32, off_sD64, off_sI, off_thr, off_qfac, off_cnt, off_ctl, off_wgmin, off_qp, off_cd, off_ci, off_flags, off_fb_d, off_fb_i,
+        off_fb_ctr, off_sub, sub_bytes, total;
     int fb_S, fb_F;
     size_t merge_lds, fb_lds;
 };
@@ -1842,6 +1843,8 @@ int make_batch_plan(int64_t N, int D, int nq, int k, BatchPlan* bp) {
     bp->off_thr = take((size_t)bp->q_rows * 4);
     bp->off_qfac = take((size_t)bp->q_rows * 4);
     bp->off_cnt = take((size_t)bp->q_rows * 4 * bp->segs);
+    bp->off_ctl = take(kTwoPhaseCtlInts * 4);             // (right behind the counters: zeroed by the same launch) grid-barrier words
+    bp->off_wgmin = take(ac::knn_batch_two_phase_bytes());   // two-phase thresholds (knn_batch.hip): per-workgroup minima
     bp->off_qp = take(ac::knn_planes_bytes(nq, D));
     bp->off_cd = take((size_t)bp->q_rows * cap * 4);
     bp->off_ci = take((size_t)bp->q_rows * cap * 4);
@@ -2059,7 +2062,7 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     //    (the same launch zeroes the candidate counters of every segmentation this call uses: no memset launches below)
     rc = ac::knn_prepare_queries(nullptr, bp.kp, d_Q, ldQ, D, nq, d_maxnorm, gamma,
                                  (uint16_t*)(ws + bp.off_qp), (float*)(ws + bp.off_thr), (float*)(ws + bp.off_qfac), stream,
-                                 (int32_t*)(ws + bp.off_cnt), (int64_t)bp.q_rows * bp.segs);
+                                 (int32_t*)(ws + bp.off_cnt), (int64_t)bp.q_rows * bp.segs + kTwoPhaseCtlInts);
     if (rc != AC_OK) return rc;
     // 2. threshold stages: sweep a strided sample, re-rank its k' best exactly (knn_merge_rerank in candidate mode, asked for
     //    k' results; its certificate is irrelevant here -- ANY k' rows bound the k'-th smallest distance from above)
@@ -2080,7 +2083,9 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     AC_HIP_CHECK(hipFuncSetAttribute((const void*)knn_merge_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.merge_lds));
     static const bool dbg = getenv("AC_KNN_BATCH_DEBUG") != nullptr;
     const int64_t stage_stride[2] = {bp.stride_a, bp.stride};
-    const int nstages = bp.stride_a > bp.stride ? 2 : 1;
+    // the main sweep takes its thresholds from its own first tile round where it can (knn_batch.hip two_phase): no sample stages
+    const bool two_phase = ac::knn_batch_two_phase_applies(N, nq, bp.kp, batch_segs(bp, N, nq));
+    const int nstages = two_phase ? 0 : (bp.stride_a > bp.stride ? 2 : 1);
     for (int st = 0; st < nstages; ++st) {
         const int64_t sst = stage_stride[st];
         const int segs = batch_segs(bp, ac::knn_sample_rows(N, sst), nq);
@@ -2111,7 +2116,7 @@ extern "C" int ac_knn_l2_topk_batch(const float* d_P, int64_t N, int64_t ldP, in
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_start, stream));
     rc = ac::knn_batch_launch(d_planes, d_norms, N, D, (const uint16_t*)(ws + bp.off_qp), nq, (const float*)(ws + bp.off_thr),
                               (const float*)(ws + bp.off_qfac), (float*)(ws + bp.off_cd), (int32_t*)(ws + bp.off_ci), (int32_t*)(ws + bp.off_cnt), bp.cap, msegs, 1, 0, stream,
-                              (int32_t*)(ws + bp.off_fb_ctr), d_stats);
+                              (int32_t*)(ws + bp.off_fb_ctr), d_stats, two_phase ? bp.kp : 0, (unsigned*)(ws + bp.off_wgmin), ws + bp.off_ctl);
     if (rc != AC_OK) return rc;
     if (g_prof_start && g_prof_stop) AC_HIP_CHECK(hipEventRecord(g_prof_stop, stream));
     // 4. merge + exact re-rank + certificate, then the exact fallback for uncertified queries

@@ -99,6 +99,40 @@ def test_batched_path_candidate_overflow_goes_to_exact_fallback(cuda_dev):
     assert nfb == 64
 
 
+@pytest.mark.parametrize("two_phase", ["1", "0"])
+def test_batched_path_thresholds_from_the_sweep_itself(two_phase, cuda_dev, monkeypatch):
+    """65 .. 256 queries on a store of >= 256 row tiles take their thresholds from the main sweep's own first tile round
+    (knn_batch.hip two_phase: per-workgroup minima, two grid barriers, the k'-th smallest of 256 minima per query) instead of a
+    sample stage (AC_KNN_TWO_PHASE=0).  Both forms must return the exact-definition answer on the stores that stress the
+    thresholds: near-ties and exact duplicates (many rows at the threshold), one tight cluster (every row passes: overflow ->
+    exact fallback for every query), far-from-unit norms, k at the path's maximum (k' = 116 of 256 minima), a ragged last tile."""
+    from oracle import c_oracle, synth
+    monkeypatch.setenv("AC_KNN_TWO_PHASE", two_phase)
+    D, k = 768, 16
+    Ph, centres = near_tie_store(90_000, D, 7)
+    Ph[50_000:50_300] = Ph[100:400]
+    nc = min(50, len(centres))
+    Qh = np.concatenate([(centres[:nc] + synth.synth_unit_rows(nc, D, 8) * 1e-3), Ph[100:100 + 100 - nc]]).astype(np.float32)     # 100 queries
+    d, i, nfb = _run(Ph, Qh, k, cuda_dev)
+    oD, oI = c_oracle.knn_l2_topk_batch(Ph, Qh, k)
+    assert np.array_equal(i, oI) and _ulp_close(d, oD)
+    # one tight cluster: everything passes every threshold
+    D2, N2 = 128, 70_000
+    c = synth.synth_unit_rows(1, D2, 3)
+    rng = np.random.default_rng(1)
+    P2 = (c + rng.standard_normal((N2, D2)).astype(np.float32) * 1e-4).astype(np.float32)
+    Q2 = (c + rng.standard_normal((80, D2)).astype(np.float32) * 1e-4).astype(np.float32)
+    d, i, nfb = _run(P2, Q2, 8, cuda_dev)
+    oD, oI = c_oracle.knn_l2_topk_batch(P2, Q2, 8)
+    assert np.array_equal(i, oI) and _ulp_close(d, oD) and nfb == 80
+    # unnormalised rows, the largest k, a ragged last row tile, 256 queries
+    P3 = (rng.standard_normal((66_001, 96)) * 3 + 0.5).astype(np.float32)
+    Q3 = (rng.standard_normal((256, 96)) * 0.3).astype(np.float32)
+    d, i, _ = _run(P3, Q3, 100, cuda_dev)
+    oD, oI = c_oracle.knn_l2_topk_batch(P3, Q3, 100)
+    assert np.array_equal(i, oI) and _ulp_close(d, oD)
+
+
 def test_index_uses_the_batched_path_and_invalidates_on_change(cuda_dev, request):
     """HipFlatL2Index prepares the store lazily for many-query searches; the plane follows in-place row updates and is dropped
     by a compaction (remove_ids)."""

@@ -7,6 +7,10 @@ nm = lambda r: re.sub(r"\(anonymous namespace\)::|^void ", "", r["Kernel_Name"])
 first = sys.argv[2] if len(sys.argv) > 2 else "pack_scan_kernel"
 st = [i for i, r in enumerate(rows) if nm(r).startswith(first)]
 a, b = st[-3], st[-2]
+for i in range(len(st) - 2, 0, -1):          # the last segment that is a whole step (ends in the post kernel), not an encoder-only forward
+    if any(nm(r).startswith("predict_post_kernel") for r in rows[st[i - 1]:st[i]]):
+        a, b = st[i - 1], st[i]
+        break
 t0 = int(rows[a]["Start_Timestamp"]); prev = None
 for r in rows[a:b + 1]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
