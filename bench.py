@@ -1405,8 +1405,9 @@ def main():
         "roofline_knn_batch": {"bound": "mfma", "achieved": knn_flops / stages["knn_ms"] / 1e9,
                                "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                "frac": knn_flops / stages["knn_ms"] / 1e9 / BF16_MFMA_PEAK_TF,
-                               "note": "the WHOLE kNN stage of the timed step (threshold stage, fp16 one-product sweep, merges / "
-                                       "exact re-rank) against the fp16 dense MFMA peak: at 256 queries x 100k rows the stage is "
+                               "note": "the WHOLE kNN stage of the timed step (query plane, fp16 one-product sweep with its thresholds taken from "
+                                       "its own first tile round, merge / exact re-rank, the two exact-fallback launches) against the fp16 "
+                                       "dense MFMA peak: at 256 queries x 100k rows the stage is "
                                        "launch- and append-bound, not MFMA-bound (the sweep kernel alone reaches 0.38 of that peak "
                                        "at 4096 x 10M: profiles/r03/knn_batch_sweep_pmc.json)"},
     }
