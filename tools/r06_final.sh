@@ -30,6 +30,7 @@ python tools/r06_attn_stamps_probe.py 2>&1 | grep -v amdgpu.ids > $O/attn_stamps
   AC_GEMM_ARITH=f16x2 timeout 600 python -m pytest tests/test_encoder_gpu.py tests/test_classifier_gpu.py tests/test_golden_gpu.py tests/test_e2e_reference_gpu.py -q -m gpu -k "not per_call and not residency and not modernbert_gemm_arith" 2>&1 | tail -1
   AC_LN_FUSION=0 timeout 600 python -m pytest tests/test_encoder_gpu.py tests/test_classifier_gpu.py tests/test_e2e_reference_gpu.py -q -m gpu -k "not starved and not sticky and not fused_into and not gave_up and not per_call and not residency" 2>&1 | tail -1
   AC_KNN_RING=0 timeout 300 python -m pytest tests/test_knn_gpu.py -q -m gpu -k "not lds_ring" 2>&1 | tail -1
+  AC_KNN_TWO_PHASE=0 AC_KNN_THR_EXACT=1 timeout 600 python -m pytest tests/test_knn_batch_gpu.py tests/test_knn_gpu.py tests/test_classifier_gpu.py tests/test_golden_gpu.py -q -m gpu 2>&1 | tail -1
   AC_EXCHANGE_FENCES=1 timeout 600 python -m pytest tests/test_encoder_gpu.py tests/test_e2e_reference_gpu.py -q -m gpu 2>&1 | tail -1
   AC_BERT_UNPAD_ONE_CALL=0 timeout 600 python -m pytest tests/test_encoder_gpu.py tests/test_e2e_reference_gpu.py tests/test_classifier_gpu.py -q -m gpu 2>&1 | tail -1
   AC_PREDICT_POST=0 timeout 600 python -m pytest tests/test_classifier_gpu.py tests/test_multilabel_gpu.py tests/test_e2e_reference_gpu.py tests/test_golden_gpu.py -q -m gpu 2>&1 | tail -1
