@@ -273,6 +273,7 @@ int knn_batch_launch(const uint16_t* Pp, const float* pnorm, int64_t N, int D, c
                      const float* qfac, float* cand_d, int32_t* cand_i, int32_t* cand_cnt, int cap, int segs, int64_t row_stride,
                      int best_only, hipStream_t stream, int32_t* clear_ctr = nullptr, int32_t* clear_stats = nullptr,
                      int two_phase_kp = 0, unsigned* wgmin = nullptr, void* ctl = nullptr);
+bool ln_fusion_enabled();        // gemm_pipe.hip: false = this call / process runs no in-launch exchange between workgroups
 bool knn_batch_two_phase_applies(int64_t N, int nq, int kp, int segs);
 size_t knn_batch_two_phase_bytes();
 

@@ -608,7 +608,9 @@ bool knn_batch_two_phase_applies(int64_t N, int nq, int kp, int segs) {
     int nblk = ac::dev_info().cus / 8 * 8;
     if (nblk < 8) nblk = 8;
     const int64_t ntiles = (N + BBM - 1) / BBM;
-    return !off && nq <= BBN && ntiles >= nblk && kp <= nblk && nblk <= 64 * 8 && segs > 1;
+    // (a process that asked for "no in-launch exchanges" -- AC_LN_FUSION=0: a device shared between streams or processes, where a
+    //  grid may not be resident at once -- gets the sample stage here too)
+    return !off && ac::ln_fusion_enabled() && nq <= BBN && ntiles >= nblk && kp <= nblk && nblk <= 64 * 8 && segs > 1;
 }
 size_t knn_batch_two_phase_bytes() { return (size_t)64 * 8 * 256 * sizeof(unsigned); }       // wgmin for the largest grid
 
